@@ -1,0 +1,277 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/_build/liboracle.so (the CPU restatement,
+oracle/dbg_oracle.c) and a subprocess wrapper around oracle/_ref/ref_dbg (the real reference).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "ref_dbg")
+
+NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
+
+
+class SynthParams(C.Structure):
+    """include/dbgk_synth.h: dbgk_synth_params"""
+    _fields_ = [("genome_len", C.c_uint64), ("read_len", C.c_uint32), ("sub_thr", C.c_uint32),
+                ("n_thr", C.c_uint32), ("reserved", C.c_uint32), ("genome_seed", C.c_uint64),
+                ("read_seed", C.c_uint64), ("err_seed", C.c_uint64)]
+
+
+def synth_params(genome_len, read_len=150, sub_rate=0.005, n_rate=0.0001, cfg=2):
+    """Seeds follow SURVEY.md section 8(d): genome 0xD8B6A55E0000+cfg, reads 0x5EED0000+cfg."""
+    return SynthParams(genome_len, read_len, int(round(sub_rate * 2 ** 32)), int(round(n_rate * 2 ** 24)), 0,
+                       0xD8B6A55E0000 + cfg, 0x5EED0000 + cfg, 0xE4404000 + cfg)
+
+
+class KmerSetStruct(C.Structure):
+    _fields_ = [("e_size", C.c_uint32), ("size", C.c_uint64), ("count", C.c_uint64),
+                ("count_conflict", C.c_uint64), ("max", C.c_uint64), ("load_factor", C.c_float),
+                ("iter_ptr", C.c_uint64), ("array", C.c_void_p), ("nul_flag", C.c_void_p),
+                ("del_flag", C.c_void_p)]
+
+
+class GraphParams(C.Structure):
+    _fields_ = [("kmer_size", C.c_int), ("max_read_len", C.c_int), ("thread_num", C.c_int),
+                ("init_hash_size", C.c_double), ("max_double_hash_times", C.c_uint64),
+                ("hash_load_factor", C.c_float), ("buffer_num", C.c_int)]
+
+
+class LinkStats(C.Structure):
+    _fields_ = [("depth_stat", C.c_int64 * 256), ("total_nodes", C.c_int64), ("deleted_lowfreq", C.c_int64),
+                ("linear_nodes", C.c_int64), ("tip_nodes", C.c_int64), ("branch_nodes", C.c_int64)]
+
+
+_lib = None
+
+
+def build(force=False):
+    """make port (+ ref when /root/reference is present)"""
+    subprocess.run(["make", "-s", "-C", HERE, "port"] + (["-B"] if force else []), check=True)
+    subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    u64, vp = C.c_uint64, C.c_void_p
+    L.orc_seq2bit.restype = u64
+    L.orc_seq2bit.argtypes = [C.c_char_p, C.c_int]
+    L.orc_bit2seq.argtypes = [u64, C.c_int, C.c_char_p]
+    L.orc_rev_com_kbit.restype = u64
+    L.orc_rev_com_kbit.argtypes = [u64, C.c_int]
+    L.orc_pow_integer.restype = u64
+    L.orc_pow_integer.argtypes = [C.c_int, C.c_int]
+    L.orc_hash_code.restype = u64
+    L.orc_hash_code.argtypes = [u64]
+    L.orc_is_prime.argtypes = [u64]
+    L.orc_find_next_prime.restype = u64
+    L.orc_find_next_prime.argtypes = [u64]
+    L.orc_get_next_kmer_depth.restype = C.c_uint8
+    L.orc_get_next_kmer_depth.argtypes = [C.c_uint32, C.c_uint8]
+    L.orc_kmerset_init.restype = C.POINTER(KmerSetStruct)
+    L.orc_kmerset_init.argtypes = [u64, C.c_float]
+    L.orc_kmerset_enlarge.argtypes = [C.POINTER(KmerSetStruct), u64]
+    L.orc_kmerset_add_node.argtypes = [C.POINTER(KmerSetStruct), vp]
+    L.orc_kmerset_exist.restype = u64
+    L.orc_kmerset_exist.argtypes = [C.POINTER(KmerSetStruct), u64]
+    L.orc_kmerset_free.argtypes = [C.POINTER(KmerSetStruct)]
+    L.orc_kmerset_dump_sorted.restype = u64
+    L.orc_kmerset_dump_sorted.argtypes = [C.POINTER(KmerSetStruct), vp]
+    L.orc_nodes_digest.restype = u64
+    L.orc_nodes_digest.argtypes = [vp, u64]
+    L.orc_check_host_table.argtypes = [vp, vp, u64, u64]
+    L.orc_parse_read.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.orc_graph_default_params.argtypes = [C.POINTER(GraphParams)]
+    L.orc_graph_create.restype = vp
+    L.orc_graph_create.argtypes = [C.POINTER(GraphParams)]
+    L.orc_graph_add_file_mem.argtypes = [vp, vp, vp, u64]
+    L.orc_graph_add_file.argtypes = [vp, C.c_char_p, C.c_int]
+    L.orc_graph_finish.argtypes = [vp]
+    L.orc_graph_kmerset.restype = C.POINTER(KmerSetStruct)
+    L.orc_graph_kmerset.argtypes = [vp]
+    for f in ("orc_graph_total_reads", "orc_graph_total_kmers", "orc_graph_double_times"):
+        getattr(L, f).restype = u64
+        getattr(L, f).argtypes = [vp]
+    L.orc_graph_destroy.argtypes = [vp]
+    L.orc_calc_link_stats.argtypes = [vp, u64, C.c_int, C.POINTER(LinkStats)]
+    L.orc_read_sequences.restype = C.c_int64
+    L.orc_read_sequences.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.orc_synth_fill.argtypes = [C.POINTER(SynthParams), u64, u64, vp]
+    L.orc_synth_write_file.argtypes = [C.POINTER(SynthParams), u64, u64, C.c_char_p, C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+# ------------------------------------------------------------------------------------------------
+# convenience layer
+# ------------------------------------------------------------------------------------------------
+
+def pack_reads(seqs):
+    """list of bytes -> (bases uint8[sum], offsets uint64[n+1])"""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=len(seqs))
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+    return bases, offsets
+
+
+def synth_reads(params, first, n_reads):
+    """(bases uint8[n*L], offsets uint64[n+1]) from the counter-based generator"""
+    L = params.read_len
+    out = np.empty(n_reads * L, dtype=np.uint8)
+    lib().orc_synth_fill(C.byref(params), first, n_reads, out.ctypes.data)
+    offsets = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
+    return out, offsets
+
+
+def parse_read(seq, k, max_read_len=250):
+    n_max = max(max_read_len - k + 1, 1)
+    km = np.zeros(n_max, np.uint64)
+    lb = np.zeros(n_max, np.uint8)
+    rb = np.zeros(n_max, np.uint8)
+    n = lib().orc_parse_read(seq, len(seq), k, max_read_len, km.ctypes.data, lb.ctypes.data, rb.ctypes.data)
+    return km[:n].copy(), lb[:n].copy(), rb[:n].copy()
+
+
+class GraphResult:
+    def __init__(self, nodes, count, size, total_reads, total_kmers, double_times, conflict, max_cutoff):
+        self.nodes = nodes  # sorted structured array (kmer, l_link, r_link)
+        self.count = count
+        self.size = size
+        self.total_reads = total_reads
+        self.total_kmers = total_kmers
+        self.double_times = double_times
+        self.conflict = conflict
+        self.max = max_cutoff
+
+
+def build_graph(files_mem=None, files=None, k=31, max_read_len=250, threads=1, init_hash_size=0.001,
+                load_factor=0.7, max_double=10, buffer_num=10000, fmt=2, want_table=False):
+    """Run the restated build_debruijn_graph.  files_mem: list of (bases, offsets) pairs, one per
+    'file'; files: list of paths.  Returns GraphResult (canonical dump sorted by kmer)."""
+    L = lib()
+    p = GraphParams(k, max_read_len, threads, init_hash_size, max_double, load_factor, buffer_num)
+    g = L.orc_graph_create(C.byref(p))
+    if not g:
+        raise MemoryError("orc_graph_create")
+    try:
+        for bases, offsets in (files_mem or []):
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            L.orc_graph_add_file_mem(g, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1)
+        for path in (files or []):
+            L.orc_graph_add_file(g, os.fsencode(path), fmt)
+        L.orc_graph_finish(g)
+        ks = L.orc_graph_kmerset(g).contents
+        nodes = np.zeros(ks.count, dtype=NODE_DTYPE)
+        n = L.orc_kmerset_dump_sorted(L.orc_graph_kmerset(g), nodes.ctypes.data)
+        assert n == ks.count, (n, ks.count)
+        res = GraphResult(nodes, ks.count, ks.size, L.orc_graph_total_reads(g), L.orc_graph_total_kmers(g),
+                          L.orc_graph_double_times(g), ks.count_conflict, ks.max)
+        if want_table:
+            res.table = np.ctypeslib.as_array(C.cast(ks.array, C.POINTER(C.c_uint8)),
+                                              shape=(ks.size * 16,)).view(NODE_DTYPE).copy()
+            res.nul_flag = np.ctypeslib.as_array(C.cast(ks.nul_flag, C.POINTER(C.c_uint8)),
+                                                 shape=(ks.size // 8 + 1,)).copy()
+        return res
+    finally:
+        L.orc_graph_destroy(g)
+
+
+def nodes_digest(nodes):
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    return lib().orc_nodes_digest(nodes.ctypes.data, len(nodes))
+
+
+def check_host_table(array, nul_flag, size, expect_count):
+    array = np.ascontiguousarray(array, dtype=NODE_DTYPE)
+    nul_flag = np.ascontiguousarray(nul_flag, dtype=np.uint8)
+    return lib().orc_check_host_table(array.ctypes.data, nul_flag.ctypes.data, size, expect_count)
+
+
+def link_stats(nodes, cutoff=2):
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    st = LinkStats()
+    lib().orc_calc_link_stats(nodes.ctypes.data, len(nodes), cutoff, C.byref(st))
+    return st
+
+
+def read_sequences(path, fmt):
+    b, o = C.c_void_p(), C.c_void_p()
+    n = lib().orc_read_sequences(os.fsencode(path), fmt, C.byref(b), C.byref(o))
+    if n < 0:
+        raise OSError(path)
+    offsets = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    total = int(offsets[-1])
+    bases = (np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint8)), shape=(max(total, 1),))[:total].copy())
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(b)
+    libc.free(o)
+    return bases, offsets
+
+
+def write_reads_file(path, seqs, fmt=2, gz=False):
+    """one-line FASTA (fmt 2) / FASTQ (fmt 1) writer for test inputs"""
+    import gzip
+    op = gzip.open if gz else open
+    with op(path, "wb") as fh:
+        for i, s in enumerate(seqs):
+            if fmt == 1:
+                fh.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+            else:
+                fh.write(b">r%d\n" % i + s + b"\n")
+
+
+# ------------------------------------------------------------------------------------------------
+# the real reference (only where oracle/_ref/ref_dbg exists)
+# ------------------------------------------------------------------------------------------------
+
+def have_ref():
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def parse_dump(path):
+    """text dump 'kmer<TAB>l(%08x)<TAB>r(%08x)' (header line starts with '#') -> (header dict, nodes)"""
+    hdr = {}
+    rows = []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("#"):
+                t = line[1:].split()
+                hdr = {t[i]: int(t[i + 1]) for i in range(0, len(t), 2)}
+                continue
+            a, b, c = line.split()
+            rows.append((int(a), int(b, 16), int(c, 16)))
+    return hdr, np.array(rows, dtype=NODE_DTYPE) if rows else np.zeros(0, NODE_DTYPE)
+
+
+def write_dump(path, nodes, total_reads, total_kmers, count):
+    with open(path, "w") as fh:
+        fh.write("#reads %d kmers %d count %d\n" % (total_reads, total_kmers, count))
+        for r in nodes:
+            fh.write("%d\t%08x\t%08x\n" % (int(r["kmer"]), int(r["l_link"]), int(r["r_link"])))
+
+
+def ref_build(lib_file, k=31, max_read_len=250, threads=1, init_hash_size=0.001, load_factor=0.7,
+              max_double=10, buffer_num=10000, fmt=2, dump=None, timeout=600):
+    """Run the real reference (oracle/_ref/ref_dbg build ...).  Returns its JSON summary."""
+    cmd = [REF_BIN, "build", "-k", str(k), "-r", str(max_read_len), "-f", str(fmt), "-t", str(threads),
+           "-i", repr(float(init_hash_size)), "-l", repr(float(load_factor)), "-e", str(max_double),
+           "-b", str(buffer_num), "-q"]
+    if dump:
+        cmd += ["-d", dump]
+    cmd.append(lib_file)
+    out = subprocess.run(cmd, check=True, capture_output=True, timeout=timeout, text=True).stdout
+    return json.loads(out.strip().splitlines()[-1])

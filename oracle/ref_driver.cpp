@@ -1,0 +1,137 @@
+// TEST INFRASTRUCTURE ONLY -- driver around the *real* reference hot path.
+//
+// This file is ours; it is compiled together with the reference's own sources
+// where they lie under /root/reference/DBG_contig (seqKmer.cpp kmerSet.cpp
+// DBGgraph.cpp gzstream.cpp) by oracle/Makefile into oracle/_ref/ref_dbg.
+// Nothing from the reference is copied into this repository.
+//
+// It calls the reference's public API exactly as DBG_contig/main.cpp:162-204
+// does (set the extern globals of DBGgraph.h:25-36, reading_file_list(),
+// build_debruijn_graph()) and then prints the canonical dump used as the
+// parity artefact: every non-null slot's (kmer, l_link, r_link), sorted by kmer.
+//
+// Sub-commands
+//   ref_dbg build [-k -r -f -t -i -l -e -b as in main.cpp:166] [-d dump.txt] [-q] <reads.lib>
+//   ref_dbg kat                        known-answer values of the codec / hash helpers
+//   ref_dbg prime <n> [<n> ...]        find_next_prime(n)
+#include "DBGgraph.h"
+
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+static int cmd_build(int argc, char **argv)
+{
+	std::string dump_path;
+	int quiet = 0;
+	int c;
+	optind = 1;
+	while ((c = getopt(argc, argv, "k:r:f:t:i:l:e:b:d:q")) != -1) {
+		switch (c) {
+			case 'k': KmerSize = atoi(optarg); break;
+			case 'r': maxReadLen = atoi(optarg); break;
+			case 'f': Input_file_format = atoi(optarg); break;
+			case 't': threadNum = atoi(optarg); break;
+			case 'i': initHashSize = atof(optarg); break;
+			case 'l': hashLoadFactor = atof(optarg); break;
+			case 'e': maxDoubleHashTimes = atoi(optarg); break;
+			case 'b': BufferNum = atoi(optarg); break;
+			case 'd': dump_path = optarg; break;
+			case 'q': quiet = 1; break;
+			default: return 2;
+		}
+	}
+	if (optind >= argc) { fprintf(stderr, "ref_dbg build: missing <reads.lib>\n"); return 2; }
+	std::string lib = argv[optind];
+
+	if (quiet) { if (!freopen("/dev/null", "w", stderr)) return 3; }
+
+	std::vector<std::string> files;
+	reading_file_list(lib, files);
+
+	auto t0 = std::chrono::steady_clock::now();
+	build_debruijn_graph(files);
+	auto t1 = std::chrono::steady_clock::now();
+	double wall = std::chrono::duration<double>(t1 - t0).count();
+
+	printf("{\"reads\": %llu, \"kmers\": %llu, \"count\": %llu, \"size\": %llu, \"max\": %llu, "
+	       "\"conflict\": %llu, \"threads\": %d, \"wall_s\": %.6f}\n",
+	       (unsigned long long)Total_reads_num, (unsigned long long)Kmer_total_num,
+	       (unsigned long long)kset->count, (unsigned long long)kset->size,
+	       (unsigned long long)kset->max, (unsigned long long)kset->count_conflict,
+	       threadNum, wall);
+
+	if (!dump_path.empty()) {
+		std::vector<KmerNode> nodes;
+		nodes.reserve(kset->count);
+		for (uint64_t i = 0; i < kset->size; i++) {
+			if (!is_entity_null(kset->nul_flag, i)) nodes.push_back(kset->array[i]);
+		}
+		std::sort(nodes.begin(), nodes.end(),
+		          [](const KmerNode &a, const KmerNode &b) { return a.kmer < b.kmer; });
+		FILE *fp = fopen(dump_path.c_str(), "w");
+		if (!fp) { perror("dump"); return 4; }
+		fprintf(fp, "#reads %llu kmers %llu count %llu\n",
+		        (unsigned long long)Total_reads_num, (unsigned long long)Kmer_total_num,
+		        (unsigned long long)kset->count);
+		for (size_t i = 0; i < nodes.size(); i++) {
+			fprintf(fp, "%llu\t%08x\t%08x\n", (unsigned long long)nodes[i].kmer,
+			        nodes[i].l_link, nodes[i].r_link);
+		}
+		fclose(fp);
+	}
+	return 0;
+}
+
+static int cmd_kat()
+{
+	const char *seqs[] = {
+		"ACGTACGTACGTACGTACGTACGTACGTACG", "ANNTG", "acgtn", "TTTTTTTTTTTTTTTTT",
+		"GATTACAGATTACAGATTACAGATTACAGATT", "CCCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC", "A", "T",
+	};
+	for (size_t i = 0; i < sizeof(seqs) / sizeof(seqs[0]); i++) {
+		std::string s = seqs[i];
+		uint64_t b = seq2bit(s);
+		uint64_t rc = get_rev_com_kbit(b, (uint8_t)s.size());
+		printf("seq2bit\t%s\t%llu\trc\t%llu\tback\t%s\n", s.c_str(), (unsigned long long)b,
+		       (unsigned long long)rc, bit2seq(b, (int)s.size()).c_str());
+	}
+	const uint64_t hs[] = {0ULL, 1ULL, 2ULL, 0x0123456789ABCDEFULL, 488296166657017542ULL,
+	                       (1ULL << 62) - 1, 0xFFFFFFFFFFFFFFFFULL, 0x8000000000000000ULL};
+	for (size_t i = 0; i < sizeof(hs) / sizeof(hs[0]); i++) {
+		printf("hash_code\t%llu\t%llu\n", (unsigned long long)hs[i], (unsigned long long)hash_code(hs[i]));
+	}
+	for (int b = 0; b < 4; b++) {
+		printf("get_next_kmer_depth\t0x01020304\t%d\t%u\n", b, (unsigned)get_next_kmer_depth(0x01020304u, (uint8_t)b));
+	}
+	for (int e = 0; e <= 64; e += 8) {
+		printf("pow_integer\t2\t%d\t%llu\n", e, (unsigned long long)pow_integer(2, e));
+	}
+	const uint64_t ps[] = {9, 15, 25, 49, 121, 169, 1000003, 1000005};
+	for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); i++) {
+		printf("is_prime\t%llu\t%d\n", (unsigned long long)ps[i], is_prime(ps[i]));
+	}
+	return 0;
+}
+
+static int cmd_prime(int argc, char **argv)
+{
+	for (int i = 1; i < argc; i++) {
+		uint64_t n = strtoull(argv[i], NULL, 10);
+		printf("find_next_prime\t%llu\t%llu\n", (unsigned long long)n, (unsigned long long)find_next_prime(n));
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) { fprintf(stderr, "usage: ref_dbg build|kat|prime ...\n"); return 2; }
+	std::string cmd = argv[1];
+	if (cmd == "build") return cmd_build(argc - 1, argv + 1);
+	if (cmd == "kat") return cmd_kat();
+	if (cmd == "prime") return cmd_prime(argc - 1, argv + 1);
+	fprintf(stderr, "unknown sub-command %s\n", cmd.c_str());
+	return 2;
+}

@@ -1,0 +1,61 @@
+"""CPU, build container only: the oracle against the REAL reference binary (oracle/_ref/ref_dbg)
+on fresh random inputs.  Skipped where the reference build is absent."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def _reads(rng, n, G=3000, L=100):
+    g = "".join(rng.choice("ACGT") for _ in range(G))
+    out = []
+    for _ in range(n):
+        ln = L if rng.random() < 0.8 else rng.randint(1, L + 40)
+        s = rng.randint(0, G - ln)
+        r = list(g[s:s + ln])
+        if rng.random() < 0.5:
+            r = [COMP[c] for c in reversed(r)]
+        for j in range(len(r)):
+            x = rng.random()
+            if x < 0.01:
+                r[j] = rng.choice("ACGT")
+            elif x < 0.012:
+                r[j] = "N"
+        r = "".join(r)
+        out.append((r.lower() if rng.random() < 0.1 else r).encode())
+    return out + [b"A" * 120, b"T" * 120, b"a" * 40]
+
+
+@pytest.mark.parametrize("k,b,i,t,r,fmt", [
+    (31, 200, 0.0001, 1, 250, 2), (17, 333, 0.0001, 3, 250, 1), (31, 10000, 0.001, 8, 90, 2),
+    (32, 200, 0.0001, 1, 250, 2), (21, 60, 0.00001, 5, 100, 1), (4, 100, 0.000001, 2, 250, 2),
+    (24, 37, 0.00001, 1, 250, 2),
+])
+def test_oracle_equals_reference(oracle, tmp_path, k, b, i, t, r, fmt):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/ref_dbg not built (no /root/reference here)")
+    rng = random.Random(hash((k, b, t)) & 0xFFFF)
+    reads = _reads(rng, 1200)
+    f1, f2 = str(tmp_path / "a.txt"), str(tmp_path / "b.txt.gz")
+    oracle.write_reads_file(f1, reads[:700], fmt=fmt)
+    oracle.write_reads_file(f2, reads[700:], fmt=fmt, gz=True)
+    libf = str(tmp_path / "reads.lib")
+    open(libf, "w").write(f1 + "\n" + f2 + "\n")
+    dump = str(tmp_path / "dump.txt")
+    js = oracle.ref_build(libf, k=k, max_read_len=r, threads=t, init_hash_size=i, buffer_num=b, fmt=fmt,
+                          dump=dump, timeout=120)
+    _, ref_nodes = oracle.parse_dump(dump)
+    for threads in (1, 4):
+        res = oracle.build_graph(files=[f1, f2], k=k, max_read_len=r, threads=threads, init_hash_size=i,
+                                 buffer_num=b, fmt=fmt)
+        assert np.array_equal(res.nodes, ref_nodes)
+        assert (res.count, res.total_reads, res.total_kmers) == (js["count"], js["reads"], js["kmers"])
+        assert (res.size, res.max) == (js["size"], js["max"])
+    if t == 1:
+        assert res.conflict != js["conflict"] or True  # layout-dependent; equality checked at threads=1 below
+        one = oracle.build_graph(files=[f1, f2], k=k, max_read_len=r, threads=1, init_hash_size=i,
+                                 buffer_num=b, fmt=fmt)
+        assert one.conflict == js["conflict"]  # same insertion order => same probe count
