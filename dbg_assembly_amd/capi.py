@@ -1,0 +1,311 @@
+"""ctypes binding of the C ABI in include/dbgk.h (dbg_assembly_amd/lib/libdbgk.so).
+
+Plumbing only: every compute call goes straight into the HIP library.  There is no Python or CPU
+fallback -- loading fails loudly if the library has not been built, and dbgk_create fails if no
+gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdbgk.so")
+
+NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
+
+OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION = 0, 1, 2
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("genome_len", C.c_uint64), ("read_len", C.c_uint32), ("sub_thr", C.c_uint32),
+                ("n_thr", C.c_uint32), ("reserved", C.c_uint32), ("genome_seed", C.c_uint64),
+                ("read_seed", C.c_uint64), ("err_seed", C.c_uint64)]
+
+
+def synth_params(genome_len, read_len=150, sub_rate=0.005, n_rate=0.0001, cfg=2):
+    """SURVEY.md section 8(d) seeds: genome 0xD8B6A55E0000+cfg, reads 0x5EED0000+cfg."""
+    return SynthParams(genome_len, read_len, int(round(sub_rate * 2 ** 32)), int(round(n_rate * 2 ** 24)), 0,
+                       0xD8B6A55E0000 + cfg, 0x5EED0000 + cfg, 0xE4404000 + cfg)
+
+
+class Config(C.Structure):
+    _fields_ = [("kmer_size", C.c_int32), ("max_read_len", C.c_int32), ("table_slots", C.c_uint64),
+                ("device_id", C.c_int32), ("engine", C.c_int32), ("max_batch_bases", C.c_uint64),
+                ("expected_kmers", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("total_reads", C.c_uint64), ("total_kmers", C.c_uint64), ("stored_kmers", C.c_uint64),
+                ("count", C.c_uint64), ("count_conflict", C.c_uint64), ("table_slots", C.c_uint64),
+                ("polyA_l_link", C.c_uint32), ("polyA_r_link", C.c_uint32)]
+
+
+class LinkStats(C.Structure):
+    _fields_ = [("depth_stat", C.c_int64 * 256), ("total_nodes", C.c_int64), ("deleted_lowfreq", C.c_int64),
+                ("linear_nodes", C.c_int64), ("tip_nodes", C.c_int64), ("branch_nodes", C.c_int64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("mark_ms", C.c_float), ("insert_ms", C.c_float), ("partition_ms", C.c_float),
+                ("build_ms", C.c_float), ("fixup_ms", C.c_float), ("finalize_ms", C.c_float),
+                ("insert_launches", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+
+class DbgkError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        L = lib()
+        msg = "%s: %s" % (what, L.dbgk_strerror(status).decode())
+        if status == ERR_HIP:
+            msg += " [%s]" % L.dbgk_last_error().decode()
+        super().__init__(msg)
+
+
+# every symbol include/dbgk.h declares: (name, restype, argtypes)
+_u64, _vp, _i = C.c_uint64, C.c_void_p, C.c_int
+SYMBOLS = [
+    ("dbgk_create", _i, [C.POINTER(Config), C.POINTER(_vp)]),
+    ("dbgk_destroy", _i, [_vp]),
+    ("dbgk_reset", _i, [_vp]),
+    ("dbgk_push_reads", _i, [_vp, _vp, _vp, _u64]),
+    ("dbgk_push_reads_device", _i, [_vp, _vp, _vp, _u64, _u64]),
+    ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_sync", _i, [_vp]),
+    ("dbgk_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
+    ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
+    ("dbgk_extract_kmers", _i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("dbgk_partition_counts", _i, [_vp, C.c_uint32, _vp]),
+    ("dbgk_partition_export", _i, [_vp, C.c_uint32, _vp, _u64]),
+    ("dbgk_merge_nodes", _i, [_vp, _vp, _u64]),
+    ("dbgk_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_synth_reads_device", _i, [_vp, C.POINTER(SynthParams), _u64, _u64, _vp, _vp]),
+    ("dbgk_device_malloc", _i, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    ("dbgk_device_free", _i, [_vp, _vp]),
+    ("dbgk_memcpy_d2h", _i, [_vp, _vp, _vp, C.c_size_t]),
+    ("dbgk_memcpy_h2d", _i, [_vp, _vp, _vp, C.c_size_t]),
+    ("dbgk_get_timings", _i, [_vp, C.POINTER(Timings)]),
+    ("dbgk_reset_timings", _i, [_vp]),
+    ("dbgk_stream", _vp, [_vp]),
+    ("dbgk_measure_copy_bandwidth", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    ("dbgk_device_count", _i, []),
+    ("dbgk_abi_version", _i, []),
+    ("dbgk_strerror", C.c_char_p, [_i]),
+    ("dbgk_last_error", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libdbgk.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C dbg_assembly_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(status, what):
+    if status != OK:
+        raise DbgkError(status, what)
+
+
+class DeviceBuffer:
+    """Raw device allocation owned by a Graph handle."""
+
+    def __init__(self, graph, nbytes):
+        self.graph = graph
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        _chk(lib().dbgk_device_malloc(graph._h, nbytes, C.byref(p)), "dbgk_device_malloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            lib().dbgk_device_free(self.graph._h, self.ptr)
+            self.ptr = None
+
+    def to_host(self, dtype=np.uint8, nbytes=None):
+        n = self.nbytes if nbytes is None else nbytes
+        out = np.empty(n, dtype=np.uint8)
+        _chk(lib().dbgk_memcpy_d2h(self.graph._h, out.ctypes.data, self.ptr, n), "dbgk_memcpy_d2h")
+        return out.view(dtype)
+
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _chk(lib().dbgk_memcpy_h2d(self.graph._h, self.ptr, arr.ctypes.data, arr.nbytes), "dbgk_memcpy_h2d")
+
+
+class Graph:
+    """One GPU-resident k-mer graph under construction (thin wrapper over a dbgk_handle)."""
+
+    def __init__(self, k, table_slots, max_read_len=250, device=0, engine=ENGINE_AUTO, max_batch_bases=0,
+                 expected_kmers=0):
+        self._h = None
+        cfg = Config(k, max_read_len, table_slots, device, engine, max_batch_bases, expected_kmers)
+        h = C.c_void_p()
+        _chk(lib().dbgk_create(C.byref(cfg), C.byref(h)), "dbgk_create")
+        self._h = h
+        self.k = k
+        self.table_slots = table_slots
+        self.stats = None
+
+    def close(self):
+        if self._h:
+            lib().dbgk_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path
+    def push_reads(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(lib().dbgk_push_reads(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "dbgk_push_reads")
+
+    def push_reads_device(self, d_bases, d_offsets, n_reads, n_bases):
+        _chk(lib().dbgk_push_reads_device(self._h, d_bases, d_offsets, n_reads, n_bases), "dbgk_push_reads_device")
+
+    def finalize(self):
+        st = Stats()
+        _chk(lib().dbgk_finalize(self._h, C.byref(st)), "dbgk_finalize")
+        self.stats = st
+        return st
+
+    def sync(self):
+        _chk(lib().dbgk_sync(self._h), "dbgk_sync")
+
+    def reset(self):
+        _chk(lib().dbgk_reset(self._h), "dbgk_reset")
+        self.stats = None
+
+    # ---- results
+    def export_sorted(self):
+        n = self.stats.count
+        out = np.zeros(n, dtype=NODE_DTYPE)
+        got = C.c_uint64()
+        _chk(lib().dbgk_export_sorted(self._h, out.ctypes.data, n, C.byref(got)), "dbgk_export_sorted")
+        assert got.value == n, (got.value, n)
+        return out
+
+    def export_host_table(self, host_size=None):
+        size = self.table_slots if host_size is None else host_size
+        array = np.zeros(size, dtype=NODE_DTYPE)
+        flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+        _chk(lib().dbgk_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_export_host_table")
+        return array, flags
+
+    def digest(self):
+        d = C.c_uint64()
+        _chk(lib().dbgk_digest(self._h, C.byref(d)), "dbgk_digest")
+        return d.value
+
+    def link_stats(self, cutoff=2):
+        st = LinkStats()
+        _chk(lib().dbgk_link_stats_device(self._h, cutoff, C.byref(st)), "dbgk_link_stats_device")
+        return st
+
+    def extract_kmers(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nb = int(offsets[-1])
+        kmer = np.zeros(nb, np.uint64)
+        left = np.zeros(nb, np.uint8)
+        right = np.zeros(nb, np.uint8)
+        valid = np.zeros(nb, np.uint8)
+        _chk(lib().dbgk_extract_kmers(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                      kmer.ctypes.data, left.ctypes.data, right.ctypes.data, valid.ctypes.data),
+             "dbgk_extract_kmers")
+        return kmer, left, right, valid
+
+    # ---- multi-GPU building blocks
+    def partition_counts(self, n_parts):
+        counts = np.zeros(n_parts, np.uint64)
+        _chk(lib().dbgk_partition_counts(self._h, n_parts, counts.ctypes.data), "dbgk_partition_counts")
+        return counts
+
+    def partition_export(self, n_parts, d_nodes, capacity):
+        _chk(lib().dbgk_partition_export(self._h, n_parts, d_nodes, capacity), "dbgk_partition_export")
+
+    def merge_nodes(self, d_nodes, n):
+        _chk(lib().dbgk_merge_nodes(self._h, d_nodes, n), "dbgk_merge_nodes")
+
+    def refresh_stats(self):
+        st = Stats()
+        _chk(lib().dbgk_refresh_stats(self._h, C.byref(st)), "dbgk_refresh_stats")
+        self.stats = st
+        return st
+
+    # ---- utilities
+    def malloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synth_reads_device(self, params, first, n_reads):
+        """-> (DeviceBuffer bases, DeviceBuffer offsets, n_bases)"""
+        nb = n_reads * params.read_len
+        d_bases = self.malloc(nb + 64)
+        d_off = self.malloc((n_reads + 1) * 8)
+        _chk(lib().dbgk_synth_reads_device(self._h, C.byref(params), first, n_reads, d_bases.ptr, d_off.ptr),
+             "dbgk_synth_reads_device")
+        return d_bases, d_off, nb
+
+    def timings(self):
+        t = Timings()
+        _chk(lib().dbgk_get_timings(self._h, C.byref(t)), "dbgk_get_timings")
+        return t
+
+    def reset_timings(self):
+        _chk(lib().dbgk_reset_timings(self._h), "dbgk_reset_timings")
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        _chk(lib().dbgk_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "dbgk_measure_copy_bandwidth")
+        return g.value
+
+
+# ---- host helpers mirrored from the reference (kmerSet.cpp:72-95), needed to size tables ---------
+
+def is_prime_ref(num):
+    """kmerSet.cpp:72-81, including its float-sqrt / strict-< quirk (9, 25, 49 ... pass)."""
+    if num < 4:
+        return True
+    if num % 2 == 0:
+        return False
+    bound = int(np.sqrt(np.float32(num)))
+    i = 3
+    while i < bound:
+        if num % i == 0:
+            return False
+        i += 2
+    return True
+
+
+def find_next_prime_ref(num):
+    """kmerSet.cpp:85-95"""
+    if num % 2 == 0:
+        num += 1
+    while not is_prime_ref(num):
+        num += 2
+    return num

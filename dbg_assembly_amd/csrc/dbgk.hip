@@ -1,0 +1,880 @@
+// dbgk.hip -- host side of the C ABI declared in include/dbgk.h: device memory, stream, staging,
+// kernel launches.  gfx950 only; no CPU fallback.
+#define DBGK_HD __host__ __device__
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dbgk.h"
+#include "dbgk_kernels.h"
+
+// dbgk_sort.hip
+extern "C" int dbgk_internal_sort_pairs(uint64_t *d_keys, uint64_t *d_vals, uint64_t n, hipStream_t stream);
+
+using namespace dbgk;
+
+static_assert(sizeof(dbgk_node) == 16 && sizeof(Node) == 16, "node layout must match KmerNode (kmerSet.h:70-75)");
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char *what, int line)
+{
+	char buf[512];
+	snprintf(buf, sizeof buf, "%s failed at dbgk.hip:%d: %s", what, line, hipGetErrorString(e));
+	g_last_error = buf;
+	return DBGK_ERR_HIP;
+}
+
+#define HIPCHK(expr)                                                   \
+	do {                                                               \
+		hipError_t e__ = (expr);                                       \
+		if (e__ != hipSuccess) return hip_fail(e__, #expr, __LINE__);  \
+	} while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+enum Phase { PH_MARK = 0, PH_INSERT, PH_PARTITION, PH_BUILD, PH_FIXUP, PH_FINALIZE, PH_COUNT };
+
+struct TimedSpan {
+	hipEvent_t a, b;
+	int phase;
+};
+
+struct StageSlot {
+	char *h_bases = nullptr;
+	uint64_t *h_offsets = nullptr;
+	char *d_bases = nullptr;
+	uint64_t *d_offsets = nullptr;
+	uint32_t *d_start = nullptr;
+	uint32_t *d_dead = nullptr;
+	hipEvent_t done = nullptr;
+	bool busy = false;
+};
+
+} // namespace
+
+struct dbgk_handle {
+	dbgk_config cfg;
+	int device = 0;
+	int n_cu = 256;
+	int grid = 2048;
+	hipStream_t stream = nullptr;
+
+	Node *table = nullptr;
+	uint64_t size = 0;
+	ModMagic magic;
+
+	Counters *d_ctr = nullptr;
+	Counters *h_ctr = nullptr; // pinned
+
+	// host-buffer staging
+	StageSlot slots[2];
+	uint64_t cap_bases = 0, cap_reads = 0;
+	int next_slot = 0;
+
+	// bitmaps for the device-pointer path
+	uint32_t *dev_start = nullptr, *dev_dead = nullptr;
+	uint64_t dev_bits_words = 0;
+
+	bool finalized = false;
+	uint64_t total_reads = 0;
+
+	std::vector<TimedSpan> spans, free_spans;
+	float phase_ms[PH_COUNT] = {0};
+	uint64_t insert_launches = 0;
+
+	TableRef tref() const { return TableRef{table, size, magic}; }
+};
+
+static int use_device(dbgk_handle *h)
+{
+	HIPCHK(hipSetDevice(h->device));
+	return DBGK_OK;
+}
+
+static int span_begin(dbgk_handle *h, int phase, TimedSpan &s)
+{
+	if (!h->free_spans.empty()) {
+		s = h->free_spans.back();
+		h->free_spans.pop_back();
+	} else {
+		HIPCHK(hipEventCreate(&s.a));
+		HIPCHK(hipEventCreate(&s.b));
+	}
+	s.phase = phase;
+	HIPCHK(hipEventRecord(s.a, h->stream));
+	return DBGK_OK;
+}
+
+static int span_end(dbgk_handle *h, TimedSpan &s)
+{
+	HIPCHK(hipEventRecord(s.b, h->stream));
+	h->spans.push_back(s);
+	return DBGK_OK;
+}
+
+// after a stream synchronise: fold finished spans into the per-phase totals
+static int collect_spans(dbgk_handle *h)
+{
+	for (auto &s : h->spans) {
+		float ms = 0.f;
+		HIPCHK(hipEventElapsedTime(&ms, s.a, s.b));
+		h->phase_ms[s.phase] += ms;
+		if (s.phase == PH_INSERT) h->insert_launches++;
+		h->free_spans.push_back(s);
+	}
+	h->spans.clear();
+	return DBGK_OK;
+}
+
+static inline uint64_t bitmap_words(uint64_t n_bases) { return (n_bases >> 5) + 4; }
+
+static int grid_for(const dbgk_handle *h, uint64_t items)
+{
+	uint64_t blocks = (items + kBlock - 1) / kBlock;
+	if (blocks < 1) blocks = 1;
+	return (int)std::min<uint64_t>(blocks, (uint64_t)h->grid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// life cycle
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_abi_version(void) { return DBGK_ABI_VERSION; }
+
+extern "C" int dbgk_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" const char *dbgk_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *dbgk_strerror(int status)
+{
+	switch (status) {
+		case DBGK_OK: return "ok";
+		case DBGK_ERR_ARG: return "bad argument";
+		case DBGK_ERR_HIP: return "HIP runtime error (see dbgk_last_error)";
+		case DBGK_ERR_TABLE_FULL: return "k-mer table full";
+		case DBGK_ERR_STATE: return "call order violated";
+		case DBGK_ERR_NOMEM: return "out of memory";
+		case DBGK_ERR_CAPACITY: return "output buffer too small";
+		default: return "unknown status";
+	}
+}
+
+static void free_handle(dbgk_handle *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	for (auto &s : h->slots) {
+		if (s.h_bases) (void)hipHostFree(s.h_bases);
+		if (s.h_offsets) (void)hipHostFree(s.h_offsets);
+		if (s.d_bases) (void)hipFree(s.d_bases);
+		if (s.d_offsets) (void)hipFree(s.d_offsets);
+		if (s.d_start) (void)hipFree(s.d_start);
+		if (s.d_dead) (void)hipFree(s.d_dead);
+		if (s.done) (void)hipEventDestroy(s.done);
+	}
+	for (auto &v : {&h->spans, &h->free_spans})
+		for (auto &s : *v) {
+			(void)hipEventDestroy(s.a);
+			(void)hipEventDestroy(s.b);
+		}
+	if (h->dev_start) (void)hipFree(h->dev_start);
+	if (h->dev_dead) (void)hipFree(h->dev_dead);
+	if (h->table) (void)hipFree(h->table);
+	if (h->d_ctr) (void)hipFree(h->d_ctr);
+	if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+	if (h->stream) (void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+static int reset_state(dbgk_handle *h)
+{
+	HIPCHK(hipMemsetAsync(h->table, 0, h->size * sizeof(Node), h->stream)); // memset_parallel, kmerSet.cpp:358-386
+	HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+	HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
+	h->finalized = false;
+	h->total_reads = 0;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
+{
+	if (!cfg || !out) return DBGK_ERR_ARG;
+	*out = nullptr;
+	if (cfg->kmer_size < 1 || cfg->kmer_size > 32) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100)
+	if (cfg->max_read_len < cfg->kmer_size) return DBGK_ERR_ARG;
+	if (cfg->table_slots < 3) return DBGK_ERR_ARG;
+	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION)
+		return DBGK_ERR_ARG;
+
+	int n_dev = 0;
+	hipError_t e = hipGetDeviceCount(&n_dev);
+	if (e != hipSuccess || n_dev <= 0) {
+		g_last_error = "no HIP device visible (this library has no CPU fallback)";
+		return DBGK_ERR_HIP;
+	}
+	if (cfg->device_id < 0 || cfg->device_id >= n_dev) return DBGK_ERR_ARG;
+
+	dbgk_handle *h = new (std::nothrow) dbgk_handle();
+	if (!h) return DBGK_ERR_NOMEM;
+	h->cfg = *cfg;
+	h->device = cfg->device_id;
+	h->size = cfg->table_slots;
+	h->magic = make_mod_magic(h->size);
+
+	auto fail = [&](int rc) {
+		free_handle(h);
+		return rc;
+	};
+	if (hipSetDevice(h->device) != hipSuccess) return fail(DBGK_ERR_HIP);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return fail(DBGK_ERR_HIP);
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+		return fail(DBGK_ERR_HIP);
+	}
+	h->n_cu = prop.multiProcessorCount;
+	h->grid = h->n_cu * 8; // 8 x 256-thread blocks per CU = 32 waves/CU, the residency limit
+
+	if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DBGK_ERR_HIP);
+	if (hipMalloc(&h->table, h->size * sizeof(Node)) != hipSuccess) {
+		g_last_error = "hipMalloc of the k-mer table failed";
+		return fail(DBGK_ERR_NOMEM);
+	}
+	if (hipMalloc(&h->d_ctr, sizeof(Counters)) != hipSuccess) return fail(DBGK_ERR_NOMEM);
+	if (hipHostMalloc(&h->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return fail(DBGK_ERR_NOMEM);
+	h->cap_bases = cfg->max_batch_bases ? cfg->max_batch_bases : (256ull << 20);
+	h->cap_reads = h->cap_bases / 16 + 1024;
+	int rc = reset_state(h);
+	if (rc != DBGK_OK) return fail(rc);
+	if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(DBGK_ERR_HIP);
+	*out = h;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_destroy(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	free_handle(h);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_reset(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(h->stream));
+	rc = collect_spans(h);
+	if (rc) return rc;
+	return reset_state(h);
+}
+
+extern "C" int dbgk_sync(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(h->stream));
+	for (auto &s : h->slots) s.busy = false;
+	return collect_spans(h);
+}
+
+extern "C" void *dbgk_stream(dbgk_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------------------------
+
+// queue mark + insert for a batch that is already in device memory
+static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                        uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */)
+{
+	if (n_reads == 0) return DBGK_OK;
+	const uint64_t words = bitmap_words(n_bases);
+	TimedSpan sp;
+	int rc = span_begin(h, PH_MARK, sp);
+	if (rc) return rc;
+	HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
+	if (has_long != 0) HIPCHK(hipMemsetAsync(d_dead, 0, words * 4, h->stream));
+	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, sizeof(unsigned int), h->stream));
+	hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
+	                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr);
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	if (rc) return rc;
+	if (has_long < 0) {
+		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		has_long = h->h_ctr->any_dead ? 1 : 0;
+	}
+	h->total_reads += n_reads;
+	if (n_bases == 0) return DBGK_OK;
+
+	ReadBatch rb{d_bases, n_bases, d_start, has_long ? d_dead : nullptr, h->cfg.kmer_size};
+	const uint64_t n_chunks = (n_bases + 15) >> 4;
+	rc = span_begin(h, PH_INSERT, sp);
+	if (rc) return rc;
+	if (has_long)
+		hipLaunchKernelGGL(k_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
+	else
+		hipLaunchKernelGGL(k_extract_insert<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
+	HIPCHK(hipGetLastError());
+	return span_end(h, sp);
+}
+
+static int ensure_slot(dbgk_handle *h, StageSlot &s)
+{
+	if (s.d_bases) return DBGK_OK;
+	const uint64_t words = bitmap_words(h->cap_bases);
+	if (hipHostMalloc(&s.h_bases, h->cap_bases, hipHostMallocDefault) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipHostMalloc(&s.h_offsets, (h->cap_reads + 1) * 8, hipHostMallocDefault) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&s.d_bases, h->cap_bases + 64) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&s.d_offsets, (h->cap_reads + 1) * 8) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&s.d_start, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&s.d_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+	HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+	if (!h || !offsets || (n_reads && !bases && offsets[n_reads] != offsets[0])) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	uint64_t r0 = 0;
+	while (r0 < n_reads) {
+		// largest [r0, r1) that fits the staging buffers
+		uint64_t r1 = r0;
+		const uint64_t base0 = offsets[r0];
+		while (r1 < n_reads && (r1 - r0) < h->cap_reads && offsets[r1 + 1] - base0 <= h->cap_bases) r1++;
+		if (r1 == r0) return DBGK_ERR_ARG; // a single read larger than max_batch_bases
+		StageSlot &s = h->slots[h->next_slot];
+		rc = ensure_slot(h, s);
+		if (rc) return rc;
+		if (s.busy) {
+			HIPCHK(hipEventSynchronize(s.done));
+			s.busy = false;
+		}
+		const uint64_t nb = offsets[r1] - base0, nr = r1 - r0;
+		if (nb) memcpy(s.h_bases, bases + base0, nb);
+		int has_long = 0;
+		for (uint64_t i = 0; i <= nr; i++) {
+			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
+			s.h_offsets[i] = offsets[r0 + i] - base0;
+			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
+		}
+		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(s.done, h->stream));
+		s.busy = true;
+		h->next_slot ^= 1;
+		r0 = r1;
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_reads_device(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets,
+                                      uint64_t n_reads, uint64_t n_bases)
+{
+	if (!h || !d_offsets || (n_bases && !d_bases)) return DBGK_ERR_ARG;
+	if (((uintptr_t)d_bases & 15u) || ((uintptr_t)d_offsets & 7u)) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t words = bitmap_words(n_bases);
+	if (words > h->dev_bits_words) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (h->dev_start) (void)hipFree(h->dev_start);
+		if (h->dev_dead) (void)hipFree(h->dev_dead);
+		h->dev_start = h->dev_dead = nullptr;
+		h->dev_bits_words = 0;
+		if (hipMalloc(&h->dev_start, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		if (hipMalloc(&h->dev_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		h->dev_bits_words = words;
+	}
+	return launch_batch(h, d_bases, d_offsets, n_reads, n_bases, h->dev_start, h->dev_dead, -1);
+}
+
+static int read_counters(dbgk_handle *h)
+{
+	HIPCHK(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	for (auto &s : h->slots) s.busy = false;
+	return collect_spans(h);
+}
+
+static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
+{
+	const Counters &c = *h->h_ctr;
+	out->total_reads = h->total_reads;
+	out->total_kmers = c.total_kmers;
+	out->stored_kmers = c.stored_kmers;
+	out->count = c.n_new + 1; // + the key-0 node, always present (DBGgraph.cpp:418)
+	out->count_conflict = c.n_conflict;
+	out->table_slots = h->size;
+	out->polyA_l_link = (uint32_t)(c.polyA_links & 0xFFFFFFFFu);
+	out->polyA_r_link = (uint32_t)(c.polyA_links >> 32);
+}
+
+extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	rc = read_counters(h);
+	if (rc) return rc;
+	h->finalized = true;
+	if (out) fill_stats(h, out);
+	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+	if (h->h_ctr->n_new + 1 > h->size) return DBGK_ERR_TABLE_FULL; // no free slot left for the key-0 node
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_refresh_stats(dbgk_handle *h, dbgk_stats *out)
+{
+	if (!h || !out) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	rc = read_counters(h);
+	if (rc) return rc;
+	fill_stats(h, out);
+	return (h->h_ctr->error & 1u) ? DBGK_ERR_TABLE_FULL : DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restrict__ nodes, uint64_t size,
+                                                            const Counters *__restrict__ ctr, uint8_t *__restrict__ flags)
+{
+	const uint64_t polyA_slot = ctr->polyA_slot;
+	const uint64_t n_bytes = size / 8 + 1;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_bytes; b += stride) {
+		uint32_t byte = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++) {
+			const uint64_t i = b * 8 + j;
+			if (i < size && (nodes[i].kmer != 0ull || i == polyA_slot)) byte |= 0x80u >> j;
+		}
+		flags[b] = (uint8_t)byte;
+	}
+}
+
+extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
+{
+	if (!h || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
+
+	TableRef T = h->tref();
+	Node *tmp = nullptr;
+	uint8_t *d_flags = nullptr;
+	auto cleanup = [&]() {
+		if (tmp) (void)hipFree(tmp);
+		if (d_flags) (void)hipFree(d_flags);
+	};
+	if (host_size != h->size) {
+		if (hipMalloc(&tmp, host_size * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+		T = TableRef{tmp, host_size, make_mod_magic(host_size)};
+		if (hipMemsetAsync(tmp, 0, host_size * sizeof(Node), h->stream) != hipSuccess) { cleanup(); return DBGK_ERR_HIP; }
+		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, T, h->d_ctr);
+	}
+	if (hipMalloc(&d_flags, host_size / 8 + 1) != hipSuccess) { cleanup(); return DBGK_ERR_NOMEM; }
+	hipLaunchKernelGGL(k_place_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
+	hipLaunchKernelGGL(k_build_flags_ctr, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, T.nodes, T.size,
+	                   h->d_ctr, d_flags);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(array, T.nodes, host_size * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_unplace_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	cleanup();
+	if (e != hipSuccess) return hip_fail(e, "export_host_table", __LINE__);
+	return (h->h_ctr->error & 1u) ? DBGK_ERR_TABLE_FULL : DBGK_OK;
+}
+
+extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)
+{
+	if (!h || !out || !n_out) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t n = h->h_ctr->n_new; // non-zero keys
+	*n_out = n + 1;
+	if (capacity < n + 1) return DBGK_ERR_CAPACITY;
+	// key 0 sorts first
+	out[0].kmer = 0;
+	out[0].l_link = (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu);
+	out[0].r_link = (uint32_t)(h->h_ctr->polyA_links >> 32);
+	if (n == 0) return DBGK_OK;
+
+	uint64_t *d_keys = nullptr, *d_links = nullptr;
+	unsigned long long *d_cursor = nullptr;
+	auto cleanup = [&]() {
+		if (d_keys) (void)hipFree(d_keys);
+		if (d_links) (void)hipFree(d_links);
+		if (d_cursor) (void)hipFree(d_cursor);
+	};
+	if (hipMalloc(&d_keys, n * 8) != hipSuccess || hipMalloc(&d_links, n * 8) != hipSuccess ||
+	    hipMalloc(&d_cursor, 8) != hipSuccess) {
+		cleanup();
+		return DBGK_ERR_NOMEM;
+	}
+	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_compact, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, d_keys, d_links,
+		                   d_cursor, n);
+		e = hipGetLastError();
+	}
+	unsigned long long found = 0;
+	if (e == hipSuccess) e = hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) { cleanup(); return hip_fail(e, "export_sorted/compact", __LINE__); }
+	if (found != n) {
+		cleanup();
+		g_last_error = "export_sorted: occupied slots != counted keys";
+		return DBGK_ERR_STATE;
+	}
+	rc = dbgk_internal_sort_pairs(d_keys, d_links, n, h->stream);
+	if (rc != DBGK_OK) { cleanup(); return rc; }
+	std::vector<uint64_t> hk(n), hl(n);
+	e = hipMemcpyAsync(hk.data(), d_keys, n * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(hl.data(), d_links, n * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	cleanup();
+	if (e != hipSuccess) return hip_fail(e, "export_sorted/copy", __LINE__);
+	for (uint64_t i = 0; i < n; i++) {
+		out[i + 1].kmer = hk[i];
+		out[i + 1].l_link = (uint32_t)(hl[i] & 0xFFFFFFFFu);
+		out[i + 1].r_link = (uint32_t)(hl[i] >> 32);
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
+{
+	if (!h || !digest) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long *d_out = nullptr;
+	if (hipMalloc(&d_out, 16) != hipSuccess) return DBGK_ERR_NOMEM;
+	unsigned long long res[2] = {0, 0};
+	hipError_t e = hipMemsetAsync(d_out, 0, 16, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, d_out);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, 16, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) return hip_fail(e, "digest", __LINE__);
+	*digest = res[0] + node_digest(0ull, h->h_ctr->polyA_links);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_stats *out)
+{
+	if (!h || !out) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long *d_out = nullptr;
+	const size_t bytes = 261 * sizeof(unsigned long long);
+	if (hipMalloc(&d_out, bytes) != hipSuccess) return DBGK_ERR_NOMEM;
+	unsigned long long res[261];
+	hipError_t e = hipMemsetAsync(d_out, 0, bytes, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, (int)cutoff,
+		                   (uint64_t)h->h_ctr->polyA_links, d_out);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, bytes, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) return hip_fail(e, "link_stats", __LINE__);
+	for (int i = 0; i < 256; i++) out->depth_stat[i] = (int64_t)res[i];
+	out->total_nodes = (int64_t)res[256];
+	out->deleted_lowfreq = (int64_t)res[257];
+	out->linear_nodes = (int64_t)res[258];
+	out->tip_nodes = (int64_t)res[259];
+	out->branch_nodes = (int64_t)res[260];
+	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase A alone
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                                  uint64_t *kmer, uint8_t *left, uint8_t *right, uint8_t *valid)
+{
+	if (!h || !offsets || !kmer || !left || !right || !valid) return DBGK_ERR_ARG;
+	if (offsets[0] != 0) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t nb = offsets[n_reads];
+	if (nb == 0) return DBGK_OK;
+	const uint64_t words = bitmap_words(nb);
+	char *d_bases = nullptr;
+	uint64_t *d_off = nullptr, *d_kmer = nullptr;
+	uint32_t *d_start = nullptr, *d_dead = nullptr;
+	uint8_t *d_l = nullptr, *d_r = nullptr, *d_v = nullptr;
+	Counters *d_ctr = nullptr;
+	auto cleanup = [&]() {
+		for (void *p : {(void *)d_bases, (void *)d_off, (void *)d_kmer, (void *)d_start, (void *)d_dead, (void *)d_l, (void *)d_r,
+		                (void *)d_v, (void *)d_ctr})
+			if (p) (void)hipFree(p);
+	};
+	hipError_t e = hipMalloc(&d_bases, nb + 64);
+	if (e == hipSuccess) e = hipMalloc(&d_off, (n_reads + 1) * 8);
+	if (e == hipSuccess) e = hipMalloc(&d_kmer, nb * 8);
+	if (e == hipSuccess) e = hipMalloc(&d_start, words * 4);
+	if (e == hipSuccess) e = hipMalloc(&d_dead, words * 4);
+	if (e == hipSuccess) e = hipMalloc(&d_l, nb);
+	if (e == hipSuccess) e = hipMalloc(&d_r, nb);
+	if (e == hipSuccess) e = hipMalloc(&d_v, nb);
+	if (e == hipSuccess) e = hipMalloc(&d_ctr, sizeof(Counters));
+	if (e != hipSuccess) { cleanup(); return DBGK_ERR_NOMEM; }
+	e = hipMemcpyAsync(d_bases, bases, nb, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_start, 0, words * 4, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_dead, 0, words * 4, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_ctr, 0, sizeof(Counters), h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_off, n_reads, nb, h->cfg.kmer_size,
+		                   h->cfg.max_read_len, d_start, d_dead, d_ctr);
+		ReadBatch rb{d_bases, nb, d_start, d_dead, h->cfg.kmer_size};
+		hipLaunchKernelGGL(k_extract_store<true>, dim3(grid_for(h, (nb + 15) >> 4)), dim3(kBlock), 0, h->stream, rb, d_kmer, d_l,
+		                   d_r, d_v);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(kmer, d_kmer, nb * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(left, d_l, nb, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(right, d_r, nb, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(valid, d_v, nb, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	cleanup();
+	if (e != hipSuccess) return hip_fail(e, "extract_kmers", __LINE__);
+	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU building blocks
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts)
+{
+	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long *d_counts = nullptr;
+	if (hipMalloc(&d_counts, n_parts * 8) != hipSuccess) return DBGK_ERR_NOMEM;
+	hipError_t e = hipMemsetAsync(d_counts, 0, n_parts * 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_partition_count, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, n_parts,
+		                   d_counts);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, n_parts * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_counts);
+	if (e != hipSuccess) return hip_fail(e, "partition_counts", __LINE__);
+	counts[0] += 1; // the key-0 node travels with part 0
+	return DBGK_OK;
+}
+
+__global__ void k_write_polyA_node(Node *out, uint64_t index, const Counters *ctr)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		out[index].kmer = 0ull;
+		out[index].links = ctr->polyA_links;
+	}
+}
+
+extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity)
+{
+	if (!h || !d_nodes || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
+	if (!h->finalized) return DBGK_ERR_STATE;
+	std::vector<uint64_t> counts(n_parts);
+	int rc = dbgk_partition_counts(h, n_parts, counts.data());
+	if (rc) return rc;
+	uint64_t total = 0;
+	std::vector<unsigned long long> cursors(n_parts);
+	for (uint32_t p = 0; p < n_parts; p++) {
+		cursors[p] = total + (p == 0 ? 1 : 0); // slot 0 of part 0 is the key-0 node
+		total += counts[p];
+	}
+	if (total > capacity) return DBGK_ERR_CAPACITY;
+	unsigned long long *d_cursors = nullptr;
+	if (hipMalloc(&d_cursors, n_parts * 8) != hipSuccess) return DBGK_ERR_NOMEM;
+	hipError_t e = hipMemcpyAsync(d_cursors, cursors.data(), n_parts * 8, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_write_polyA_node, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<Node *>(d_nodes), (uint64_t)0,
+		                   h->d_ctr);
+		hipLaunchKernelGGL(k_partition_scatter, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, n_parts,
+		                   d_cursors, reinterpret_cast<Node *>(d_nodes), capacity);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_cursors);
+	if (e != hipSuccess) return hip_fail(e, "partition_export", __LINE__);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n)
+{
+	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
+	if ((uintptr_t)d_nodes & 15u) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n == 0) return DBGK_OK;
+	TimedSpan sp;
+	rc = span_begin(h, PH_FIXUP, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_merge_nodes, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, reinterpret_cast<const Node *>(d_nodes), n,
+	                   h->tref(), h->d_ctr);
+	HIPCHK(hipGetLastError());
+	return span_end(h, sp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// utilities
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_synth_reads_device(dbgk_handle *h, const dbgk_synth_params *p, uint64_t first_read, uint64_t n_reads,
+                                       char *d_bases, uint64_t *d_offsets)
+{
+	if (!h || !p || !d_bases || !d_offsets) return DBGK_ERR_ARG;
+	if (p->read_len == 0 || p->read_len > 1024 || p->genome_len < p->read_len) return DBGK_ERR_ARG;
+	if ((uintptr_t)d_bases & 15u) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t chunks = (n_reads * (uint64_t)p->read_len + 15) >> 4;
+	hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(h, std::max<uint64_t>(chunks, n_reads + 1))), dim3(kBlock), 0, h->stream, *p,
+	                   first_read, n_reads, d_bases, d_offsets);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_device_malloc(dbgk_handle *h, size_t bytes, void **d_ptr)
+{
+	if (!h || !d_ptr) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) {
+		*d_ptr = nullptr;
+		return DBGK_ERR_NOMEM;
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_device_free(dbgk_handle *h, void *d_ptr)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(h->stream));
+	HIPCHK(hipFree(d_ptr));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_memcpy_d2h(dbgk_handle *h, void *dst, const void *d_src, size_t bytes)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_memcpy_h2d(dbgk_handle *h, void *d_dst, const void *src, size_t bytes)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_get_timings(dbgk_handle *h, dbgk_timings *out)
+{
+	if (!h || !out) return DBGK_ERR_ARG;
+	memset(out, 0, sizeof(*out));
+	out->mark_ms = h->phase_ms[PH_MARK];
+	out->insert_ms = h->phase_ms[PH_INSERT];
+	out->partition_ms = h->phase_ms[PH_PARTITION];
+	out->build_ms = h->phase_ms[PH_BUILD];
+	out->fixup_ms = h->phase_ms[PH_FIXUP];
+	out->finalize_ms = h->phase_ms[PH_FINALIZE];
+	out->insert_launches = h->insert_launches;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_reset_timings(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	for (auto &v : h->phase_ms) v = 0.f;
+	h->insert_launches = 0;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int iters, double *gbps)
+{
+	if (!h || !gbps || bytes < 4096 || iters < 1) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	void *a = nullptr, *b = nullptr;
+	if (hipMalloc(&a, bytes) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&b, bytes) != hipSuccess) {
+		(void)hipFree(a);
+		return DBGK_ERR_NOMEM;
+	}
+	hipEvent_t e0, e1;
+	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, h->stream); // warm-up
+	if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+	for (int i = 0; i < iters && e == hipSuccess; i++) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, h->stream);
+	if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	float ms = 0.f;
+	if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+	(void)hipFree(a);
+	(void)hipFree(b);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	if (e != hipSuccess) return hip_fail(e, "measure_copy_bandwidth", __LINE__);
+	*gbps = (2.0 * (double)bytes * iters) / (ms * 1e-3) / 1e9; // bytes read + bytes written
+	return DBGK_OK;
+}

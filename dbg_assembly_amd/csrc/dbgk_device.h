@@ -1,0 +1,146 @@
+// dbgk_device.h -- device-side building blocks shared by all kernels (gfx950 only).
+//
+// Reference semantics (paths relative to /root/reference/):
+//   alphabet / seq2bit           DBG_contig/seqKmer.cpp:9-19,34-41
+//   get_rev_com_kbit             DBG_contig/seqKmer.cpp:89-97
+//   hash_code                    DBG_contig/kmerSet.h:105-116
+//   BitAddVal / link layout      DBG_contig/kmerSet.cpp:56, :341-344
+//   canonical pick + neighbours  DBG_contig/DBGgraph.cpp:76-89
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dbgk {
+
+// ---- 64-bit modulo / divide by the run-time table size ------------------------------------
+// slot = hash_code(key) % size with size a run-time "prime" (DBGgraph.cpp:167).  A hardware 64-bit
+// divide is ~40 VALU ops with a long dependent chain; with m = floor(2^64/d) the quotient estimate
+// mulhi(h, m) is at most 1 too small (proof in DESIGN.md), so one multiply-high, one multiply-low
+// and a conditional subtract give exact q and r.
+struct ModMagic {
+	uint64_t d;
+	uint64_t m;
+};
+
+static inline ModMagic make_mod_magic(uint64_t d)
+{
+	ModMagic g;
+	g.d = d;
+	g.m = (uint64_t)((((unsigned __int128)1) << 64) / d); // d >= 2
+	return g;
+}
+
+__device__ __forceinline__ uint64_t fast_divmod(uint64_t h, const ModMagic g, uint64_t &q_out)
+{
+	uint64_t q = __umul64hi(h, g.m);
+	uint64_t r = h - q * g.d;
+	if (r >= g.d) { r -= g.d; q++; }
+	if (r >= g.d) { r -= g.d; q++; } // never taken; keeps the result exact even if the bound were off by one
+	q_out = q;
+	return r;
+}
+
+__device__ __forceinline__ uint64_t fast_mod(uint64_t h, const ModMagic g)
+{
+	uint64_t q;
+	return fast_divmod(h, g, q);
+}
+
+// ---- hash_code (kmerSet.h:105-116) and its inverse ------------------------------------------
+__host__ __device__ __forceinline__ uint64_t hash_code(uint64_t k)
+{
+	k += ~(k << 32);
+	k ^= (k >> 22);
+	k += ~(k << 13);
+	k ^= (k >> 8);
+	k += (k << 3);
+	k ^= (k >> 15);
+	k += ~(k << 27);
+	k ^= (k >> 31);
+	return k;
+}
+
+// splitmix64 finaliser (digest only; not part of the reference)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+	uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+__host__ __device__ __forceinline__ uint64_t node_digest(uint64_t kmer, uint64_t links_lr)
+{
+	// links_lr as stored in memory (l_link low word, r_link high word); digest is defined on
+	// (l_link << 32) | r_link
+	uint64_t v = (links_lr << 32) | (links_lr >> 32);
+	return mix64(kmer ^ mix64(v));
+}
+
+// ---- 2-bit codec ----------------------------------------------------------------------------
+// 4 ASCII bases (one little-endian dword, first base in the low byte) -> 8 bits, first base in
+// bits 7..6.  A,a,N,n -> 0; C,c -> 1; G,g -> 2; T,t -> 3 (seqKmer.cpp:9-19).  Other bytes are
+// outside the input contract and map to an unspecified base.
+__device__ __forceinline__ uint32_t pack4_ascii(uint32_t w)
+{
+	uint32_t x = (w >> 1) & 0x03030303u;                 // A0 C1 T2 G3
+	x ^= (x >> 1) & 0x01010101u;                         // swap G/T -> A0 C1 G2 T3
+	uint32_t t = (w & 0x5F5F5F5Fu) ^ 0x4E4E4E4Eu;        // zero byte where the base is N / n
+	uint32_t nz = (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; // 0x80 where byte != 0
+	x &= (nz >> 7) * 3u;                                  // N -> 0
+	return (x * 0x40100401u) >> 24;                       // gather the four 2-bit codes MSB-first
+}
+
+// 16 ASCII bases -> one dword of 2-bit codes, base 0 in bits 31..30
+__device__ __forceinline__ uint32_t pack16_ascii(const uint4 v)
+{
+	return (pack4_ascii(v.x) << 24) | (pack4_ascii(v.y) << 16) | (pack4_ascii(v.z) << 8) | pack4_ascii(v.w);
+}
+
+// reverse complement of a 2-bit packed k-mer (seqKmer.cpp:89-97): complement = ~, reverse the 32
+// groups with one v_bfrev per half plus a swap of the two bits inside each group
+__device__ __forceinline__ uint64_t revcomp_kbit(uint64_t kbit, int k)
+{
+	uint64_t x = __brevll(~kbit);
+	x = ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
+	return x >> (64 - 2 * k);
+}
+
+// ---- link words -------------------------------------------------------------------------------
+// A node's two link words are handled as ONE little-endian 64-bit word at byte offset 8 of the
+// node: l_link = low dword, r_link = high dword.  Counter of base b (0..3) sits at bits
+// (3-b)*8 of its dword (kmerSet.cpp:56, :341-344).
+
+// one observation: +1 on the left counter of base lb and the right counter of base rb (4 = none),
+// each saturating at 255 (DBGgraph.cpp:188-194)
+__device__ __forceinline__ uint64_t links_observe(uint64_t links, uint32_t lb, uint32_t rb)
+{
+	if (lb != 4u) {
+		uint32_t sh = (3u - lb) * 8u;
+		if (((links >> sh) & 0xFFu) != 0xFFu) links += 1ULL << sh;
+	}
+	if (rb != 4u) {
+		uint32_t sh = 32u + (3u - rb) * 8u;
+		if (((links >> sh) & 0xFFu) != 0xFFu) links += 1ULL << sh;
+	}
+	return links;
+}
+
+// per-byte saturating add of eight packed counters: min(255, a+b) in every byte
+__host__ __device__ __forceinline__ uint64_t links_sat_add(uint64_t a, uint64_t b)
+{
+	const uint64_t H = 0x8080808080808080ULL;
+	uint64_t lo = (a & ~H) + (b & ~H);          // 7-bit sums, carry lands in bit 7 of each byte
+	uint64_t s = lo ^ ((a ^ b) & H);            // wrapped byte sums
+	uint64_t carry = ((a & b) | ((a | b) & lo)) & H;
+	return s | ((carry >> 7) * 0xFFULL);
+}
+
+// ---- the graph node ---------------------------------------------------------------------------
+struct alignas(16) Node {
+	uint64_t kmer;
+	uint64_t links; // l_link | r_link << 32
+};
+
+} // namespace dbgk

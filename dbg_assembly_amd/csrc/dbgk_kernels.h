@@ -1,0 +1,673 @@
+// dbgk_kernels.h -- the HIP kernels of the k-mer graph construction path (gfx950 only).
+//
+// Data layout in HBM:
+//   bases       ASCII read bases back to back, no separators (what dbgk_push_reads* receives)
+//   start_bits  1 bit per base position, LSB-first in dwords: set where a read starts
+//   dead_bits   1 bit per base position: set on bases beyond maxReadLen of their read (only
+//               allocated/used when a batch contains such reads)
+//   table       Node[size], the reference's open-addressed KmerSet array: slot of a key is
+//               hash_code(key) % size, linear probing, key 0 = empty (kmerSet.h:70-75,
+//               DBGgraph.cpp:167-205)
+//
+// Work decomposition of the extraction: one lane owns 16 consecutive base positions (one 16-byte
+// ASCII chunk -> one packed dword) and slides the 2-bit window over them in registers; a wave
+// covers 1 KiB of contiguous read bytes per step, so the ASCII loads are fully coalesced
+// 16-byte-per-lane loads.  Read boundaries come from the bitmap, so no lane ever searches the
+// offsets array.
+#pragma once
+
+#include "dbgk_device.h"
+
+namespace dbgk {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kPosPerLane = 16;      // one uint4 of ASCII per lane
+constexpr int kGroup = 4;            // positions resolved together (independent table loads in flight)
+
+// device-side counters of one handle (zeroed by reset)
+struct Counters {
+	unsigned long long n_new;          // keys claimed (distinct non-zero keys)
+	unsigned long long n_conflict;     // probe steps
+	unsigned long long total_reads;
+	unsigned long long total_kmers;    // Kmer_total_num semantics (untrimmed)
+	unsigned long long stored_kmers;   // windows extracted
+	unsigned long long polyA_links;    // key-0 node, l_link | r_link << 32
+	unsigned int       error;          // bit 0: table full
+	unsigned int       any_dead;       // some read longer than maxReadLen in the current batch
+	unsigned long long polyA_slot;     // where the key-0 node was placed for export (or ~0)
+	unsigned long long scratch[4];
+};
+
+struct TableRef {
+	Node *nodes;
+	uint64_t size;
+	ModMagic magic;
+};
+
+struct ReadBatch {
+	const char *bases;
+	uint64_t n_bases;
+	const uint32_t *start_bits;
+	const uint32_t *dead_bits; // may be null
+	int k;
+};
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	return v; // valid in lane 0
+}
+
+// sum over the block; result valid in thread 0.  `lds` holds kBlock/64 entries per reduced value.
+__device__ __forceinline__ unsigned long long block_sum(unsigned long long v, unsigned long long *lds)
+{
+	v = wave_sum(v);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__syncthreads();
+	if (lane == 0) lds[wave] = v;
+	__syncthreads();
+	unsigned long long s = 0;
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int w = 0; w < kBlock / 64; w++) s += lds[w];
+	}
+	return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mark: read boundaries + the reference's totals, one thread per read
+//   start bit at offsets[r]; dead bits on [offsets[r]+maxReadLen, offsets[r+1]) (DBGgraph.cpp:63);
+//   Kmer_total_num += len-K+1 for len >= K (untrimmed, :101); Total_reads_num += 1 (:274)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                                                 uint64_t n_bases, int k, int max_read_len,
+                                                 uint32_t *__restrict__ start_bits, uint32_t *__restrict__ dead_bits,
+                                                 Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long tot = 0, stored = 0;
+	unsigned int dead_seen = 0;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_reads; r += stride) {
+		const uint64_t s = offsets[r], e = offsets[r + 1];
+		const uint64_t len = e - s;
+		if (s < n_bases) atomicOr(&start_bits[s >> 5], 1u << (s & 31u));
+		if (len >= (uint64_t)k) {
+			tot += len - (uint64_t)k + 1;
+			const uint64_t rl = len > (uint64_t)max_read_len ? (uint64_t)max_read_len : len;
+			if (rl >= (uint64_t)k) stored += rl - (uint64_t)k + 1;
+		}
+		if (len > (uint64_t)max_read_len) {
+			dead_seen = 1;
+			if (dead_bits) {
+				for (uint64_t p = s + (uint64_t)max_read_len; p < e;) { // rare path: long reads only
+					const uint32_t bit = (uint32_t)(p & 31u);
+					const uint64_t span = (e - p < 32u - bit) ? e - p : 32u - bit;
+					const uint32_t mask = (span == 32u) ? 0xFFFFFFFFu : (((1u << span) - 1u) << bit);
+					atomicOr(&dead_bits[p >> 5], mask);
+					p += span;
+				}
+			}
+		}
+	}
+	unsigned long long a = block_sum(tot, red);
+	unsigned long long b = block_sum(stored, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->total_kmers, a);
+		if (b) atomicAdd(&ctr->stored_kmers, b);
+	}
+	if (dead_seen) atomicOr(&ctr->any_dead, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// window extraction for the 16 positions owned by one lane
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_packed_chunk(const char *__restrict__ bases, uint64_t n_bases, uint64_t chunk)
+{
+	const uint64_t off = chunk * 16u;
+	if (off + 16u <= n_bases) {
+		return pack16_ascii(*reinterpret_cast<const uint4 *>(bases + off));
+	}
+	if (off >= n_bases) return 0u;
+	uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // tail chunk: pad with 'A'
+	for (uint64_t i = 0; off + i < n_bases; i++) {
+		const uint32_t c = (uint8_t)bases[off + i];
+		w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3u) * 8u))) | (c << ((i & 3u) * 8u));
+	}
+	return pack16_ascii(make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+// 64 bits of a position bitmap starting at bit position p0 (p0 % 16 == 0)
+__device__ __forceinline__ uint64_t load_bits64(const uint32_t *__restrict__ bits, uint64_t p0)
+{
+	const uint64_t wi = p0 >> 5;
+	const uint32_t sh = (uint32_t)(p0 & 31u);
+	const uint64_t lo = (uint64_t)bits[wi] | ((uint64_t)bits[wi + 1] << 32);
+	if (sh == 0) return lo;
+	return (lo >> sh) | ((uint64_t)bits[wi + 2] << (64u - sh));
+}
+
+struct LaneWindow {
+	uint64_t hi, lo;     // 2-bit codes of bases p0.. (MSB first), 48 loaded
+	uint64_t S, D;       // start / dead bits, bit t <-> position p0+t
+	uint32_t prev_code;  // code of base p0-1
+	uint64_t p0;
+};
+
+template <bool HAS_DEAD>
+__device__ __forceinline__ LaneWindow load_lane_window(const ReadBatch &rb, uint64_t chunk)
+{
+	LaneWindow w;
+	w.p0 = chunk * 16u;
+	const uint32_t w0 = load_packed_chunk(rb.bases, rb.n_bases, chunk);
+	const uint32_t w1 = load_packed_chunk(rb.bases, rb.n_bases, chunk + 1);
+	const uint32_t w2 = load_packed_chunk(rb.bases, rb.n_bases, chunk + 2);
+	w.hi = ((uint64_t)w0 << 32) | w1;
+	w.lo = (uint64_t)w2 << 32;
+	w.prev_code = 0;
+	if (chunk > 0) w.prev_code = pack4_ascii((uint32_t)(uint8_t)rb.bases[w.p0 - 1]) >> 6;
+	w.S = load_bits64(rb.start_bits, w.p0);
+	w.D = HAS_DEAD ? load_bits64(rb.dead_bits, w.p0) : 0ull;
+	return w;
+}
+
+struct Triple {
+	uint64_t key;
+	uint32_t lb, rb;
+	bool valid;
+};
+
+// k-mer starting at the window's current first base, then slide by one base
+// (DBGgraph.cpp:64-98 restated per position; N is A; tie kbit == rc -> forward :80)
+template <bool HAS_DEAD>
+__device__ __forceinline__ Triple next_triple(LaneWindow &w, uint32_t i, int k, uint64_t n_bases)
+{
+	Triple t;
+	const uint64_t p = w.p0 + i;
+	const uint64_t kbit = w.hi >> (64 - 2 * k);
+	const uint32_t right = (k < 32) ? (uint32_t)(w.hi >> (62 - 2 * k)) & 3u : (uint32_t)(w.lo >> 62);
+	const uint32_t left = w.prev_code;
+	const uint64_t inner = (k > 1) ? ((w.S >> 1) & ((1ull << (k - 1)) - 1ull)) : 0ull;
+	bool valid = (p + (uint64_t)k <= n_bases) && inner == 0ull;
+	bool has_left = (p > 0) && !(w.S & 1ull);
+	bool has_right = (p + (uint64_t)k < n_bases) && !((w.S >> k) & 1ull);
+	if (HAS_DEAD) {
+		const uint64_t km = (k < 64) ? ((1ull << k) - 1ull) : ~0ull;
+		valid = valid && (w.D & km) == 0ull;
+		has_right = has_right && !((w.D >> k) & 1ull);
+	}
+	const uint64_t rc = revcomp_kbit(kbit, k);
+	if (kbit <= rc) {
+		t.key = kbit;
+		t.lb = has_left ? left : 4u;
+		t.rb = has_right ? right : 4u;
+	} else {
+		t.key = rc;
+		t.rb = has_left ? 3u - left : 4u;
+		t.lb = has_right ? 3u - right : 4u;
+	}
+	t.valid = valid;
+	// slide
+	w.prev_code = (uint32_t)(w.hi >> 62);
+	w.hi = (w.hi << 2) | (w.lo >> 62);
+	w.lo <<= 2;
+	w.S >>= 1;
+	if (HAS_DEAD) w.D >>= 1;
+	return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// insertion into the global table (thread_updatekmers, DBGgraph.cpp:153-205, for many writers per
+// key): claim with a 64-bit CAS on the key word, count with a 64-bit CAS loop on the link word so
+// that every byte saturates exactly at 255.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void links_cas_observe(unsigned long long *addr, uint64_t guess, uint32_t lb, uint32_t rb)
+{
+	uint64_t old = guess;
+	for (;;) {
+		const uint64_t upd = links_observe(old, lb, rb);
+		if (upd == old) return; // nothing to add (no neighbour, or both counters already 255: counters only grow)
+		const uint64_t prev = atomicCAS(addr, (unsigned long long)old, (unsigned long long)upd);
+		if (prev == old) return;
+		old = prev;
+	}
+}
+
+__device__ __forceinline__ void links_cas_merge(unsigned long long *addr, uint64_t guess, uint64_t add)
+{
+	uint64_t old = guess;
+	for (;;) {
+		const uint64_t upd = links_sat_add(old, add);
+		if (upd == old) return;
+		const uint64_t prev = atomicCAS(addr, (unsigned long long)old, (unsigned long long)upd);
+		if (prev == old) return;
+		old = prev;
+	}
+}
+
+// Finds or claims the slot of `key` (key != 0) starting at `slot`, with `first` the node value
+// already loaded from that slot.  Returns the slot index, or ~0 when the table is full.
+// n_new / n_conf are per-thread tallies.
+__device__ __forceinline__ uint64_t find_or_claim(const TableRef &T, uint64_t key, uint64_t slot, Node first,
+                                                  uint64_t &links_guess, unsigned long long &n_new,
+                                                  unsigned long long &n_conf)
+{
+	Node cur = first;
+	for (uint64_t steps = 0; steps <= T.size; steps++) {
+		uint64_t seen = cur.kmer;
+		if (seen == 0ull) {
+			seen = atomicCAS(reinterpret_cast<unsigned long long *>(&T.nodes[slot].kmer), 0ull, (unsigned long long)key);
+			if (seen == 0ull) {
+				n_new++;
+				links_guess = 0ull;
+				return slot;
+			}
+			cur.links = 0ull; // somebody else just claimed it; its links are about to grow from 0
+		}
+		if (seen == key) {
+			links_guess = cur.links;
+			return slot;
+		}
+		n_conf++;
+		slot = (slot + 1 == T.size) ? 0 : slot + 1;
+		const uint4 v = *reinterpret_cast<const uint4 *>(&T.nodes[slot]);
+		cur.kmer = ((uint64_t)v.y << 32) | v.x;
+		cur.links = ((uint64_t)v.w << 32) | v.z;
+	}
+	return ~0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_extract_insert: DIRECT engine -- fused thread_parseBlock + thread_updatekmers
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_DEAD>
+__global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRef T, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	unsigned long long *polyA = &ctr->polyA_links;
+
+	for (uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x; chunk < n_chunks; chunk += stride) {
+		LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+#pragma unroll 1
+		for (uint32_t g = 0; g < kPosPerLane; g += kGroup) {
+			Triple t[kGroup];
+			uint64_t slot[kGroup];
+			Node first[kGroup];
+#pragma unroll
+			for (int u = 0; u < kGroup; u++) {
+				t[u] = next_triple<HAS_DEAD>(w, g + u, rb.k, rb.n_bases);
+				slot[u] = fast_mod(hash_code(t[u].key), T.magic);
+			}
+#pragma unroll
+			for (int u = 0; u < kGroup; u++) { // independent loads, all in flight together
+				if (t[u].valid && t[u].key != 0ull) {
+					const uint4 v = *reinterpret_cast<const uint4 *>(&T.nodes[slot[u]]);
+					first[u].kmer = ((uint64_t)v.y << 32) | v.x;
+					first[u].links = ((uint64_t)v.w << 32) | v.z;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < kGroup; u++) {
+				if (!t[u].valid) continue;
+				if (t[u].key == 0ull) { // poly-A / poly-T side node (DBGgraph.cpp:153-164)
+					links_cas_observe(polyA, 0ull, t[u].lb, t[u].rb);
+					continue;
+				}
+				uint64_t guess;
+				const uint64_t s = find_or_claim(T, t[u].key, slot[u], first[u], guess, n_new, n_conf);
+				if (s == ~0ull) { full = true; continue; }
+				links_cas_observe(reinterpret_cast<unsigned long long *>(&T.nodes[s].links), guess, t[u].lb, t[u].rb);
+			}
+		}
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_extract_store: phase A alone, position-indexed outputs (parity of the extraction)
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_DEAD>
+__global__ __launch_bounds__(kBlock) void k_extract_store(ReadBatch rb, uint64_t *__restrict__ kmer,
+                                                          uint8_t *__restrict__ left, uint8_t *__restrict__ right,
+                                                          uint8_t *__restrict__ valid)
+{
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x; chunk < n_chunks; chunk += stride) {
+		LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+		for (uint32_t i = 0; i < kPosPerLane; i++) {
+			const Triple t = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
+			const uint64_t p = chunk * 16u + i;
+			if (p >= rb.n_bases) break;
+			valid[p] = t.valid ? 1 : 0;
+			kmer[p] = t.valid ? t.key : 0ull;
+			left[p] = t.valid ? (uint8_t)t.lb : 4;
+			right[p] = t.valid ? (uint8_t)t.rb : 4;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// table-wide passes (one thread per slot, grid-stride)
+// ---------------------------------------------------------------------------------------------
+
+// merge pre-aggregated nodes: insert-if-absent + per-byte saturating add (multi-GPU merge, rehash)
+__global__ __launch_bounds__(kBlock) void k_merge_nodes(const Node *__restrict__ in, uint64_t n, TableRef T,
+                                                        Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(&in[i]);
+		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+		const uint64_t add = ((uint64_t)v.w << 32) | v.z;
+		if (key == 0ull) {
+			// the key-0 node of another shard; an all-zero record is padding and adds nothing
+			links_cas_merge(&ctr->polyA_links, 0ull, add);
+			continue;
+		}
+		uint64_t slot = fast_mod(hash_code(key), T.magic);
+		const uint4 f = *reinterpret_cast<const uint4 *>(&T.nodes[slot]);
+		Node first;
+		first.kmer = ((uint64_t)f.y << 32) | f.x;
+		first.links = ((uint64_t)f.w << 32) | f.z;
+		uint64_t guess;
+		const uint64_t s = find_or_claim(T, key, slot, first, guess, n_new, n_conf);
+		if (s == ~0ull) { full = true; continue; }
+		links_cas_merge(reinterpret_cast<unsigned long long *>(&T.nodes[s].links), guess, add);
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// re-seat every node of `src` into `dst` (different size): keys are unique, so the claim is the
+// only atomic needed (device counterpart of enlarge_kmerset_parallel, kmerSet.cpp:132-189)
+__global__ __launch_bounds__(kBlock) void k_rehash(const Node *__restrict__ src, uint64_t src_size, TableRef dst,
+                                                   Counters *__restrict__ ctr)
+{
+	bool full = false;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < src_size; i += stride) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(&src[i]);
+		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+		if (key == 0ull) continue;
+		const uint64_t links = ((uint64_t)v.w << 32) | v.z;
+		uint64_t slot = fast_mod(hash_code(key), dst.magic);
+		bool placed = false;
+		for (uint64_t steps = 0; steps <= dst.size; steps++) {
+			const unsigned long long seen =
+			    atomicCAS(reinterpret_cast<unsigned long long *>(&dst.nodes[slot].kmer), 0ull, (unsigned long long)key);
+			if (seen == 0ull) {
+				dst.nodes[slot].links = links;
+				placed = true;
+				break;
+			}
+			slot = (slot + 1 == dst.size) ? 0 : slot + 1;
+		}
+		if (!placed) full = true;
+	}
+	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// place the key-0 node on key 0's probe chain for export (add_node_to_kmerset, kmerSet.cpp:253-273:
+// first free slot from hash_code(0) % size).  Single thread.  The slot keeps kmer == 0; only its
+// link word is written, and k_unplace_polyA undoes it so later merges still see an empty slot.
+__global__ void k_place_polyA(TableRef T, Counters *ctr)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	uint64_t slot = fast_mod(hash_code(0ull), T.magic);
+	for (uint64_t steps = 0; steps < T.size; steps++) {
+		if (T.nodes[slot].kmer == 0ull) {
+			T.nodes[slot].links = ctr->polyA_links;
+			ctr->polyA_slot = slot;
+			return;
+		}
+		slot = (slot + 1 == T.size) ? 0 : slot + 1;
+	}
+	ctr->polyA_slot = ~0ull;
+	atomicOr(&ctr->error, 1u);
+}
+
+__global__ void k_unplace_polyA(TableRef T, Counters *ctr)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	if (ctr->polyA_slot != ~0ull) T.nodes[ctr->polyA_slot].links = 0ull;
+	ctr->polyA_slot = ~0ull;
+}
+
+// nul_flag bitmap of the reference (bit i = byte i/8, mask 128 >> (i%8); kmerSet.cpp:53):
+// one thread per flag BYTE (8 slots)
+__global__ __launch_bounds__(kBlock) void k_build_flags(const Node *__restrict__ nodes, uint64_t size,
+                                                        uint64_t polyA_slot, uint8_t *__restrict__ flags)
+{
+	const uint64_t n_bytes = size / 8 + 1;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_bytes; b += stride) {
+		uint32_t byte = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++) {
+			const uint64_t i = b * 8 + j;
+			if (i < size && (nodes[i].kmer != 0ull || i == polyA_slot)) byte |= 0x80u >> j;
+		}
+		flags[b] = (uint8_t)byte;
+	}
+}
+
+// compact the occupied slots into SoA (keys, links) for sorting; order arbitrary
+__global__ __launch_bounds__(kBlock) void k_compact(const Node *__restrict__ nodes, uint64_t size,
+                                                    uint64_t *__restrict__ keys, uint64_t *__restrict__ links,
+                                                    unsigned long long *__restrict__ cursor, uint64_t capacity)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	const uint64_t n_iter = (size + stride - 1) / stride;
+	for (uint64_t it = 0; it < n_iter; it++) {
+		const uint64_t i = it * stride + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+		Node nd;
+		nd.kmer = 0;
+		nd.links = 0;
+		if (i < size) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(&nodes[i]);
+			nd.kmer = ((uint64_t)v.y << 32) | v.x;
+			nd.links = ((uint64_t)v.w << 32) | v.z;
+		}
+		const bool occ = nd.kmer != 0ull;
+		const unsigned long long ballot = __ballot(occ);
+		const int lane = threadIdx.x & 63;
+		unsigned long long base = 0;
+		if (lane == 0 && ballot) base = atomicAdd(cursor, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, 0, 64);
+		if (occ) {
+			const uint64_t dst = base + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+			if (dst < capacity) {
+				keys[dst] = nd.kmer;
+				links[dst] = nd.links;
+			}
+		}
+	}
+}
+
+// order-independent digest + occupied count
+__global__ __launch_bounds__(kBlock) void k_digest(const Node *__restrict__ nodes, uint64_t size,
+                                                   unsigned long long *__restrict__ out /* [0]=digest [1]=count */)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long acc = 0, cnt = 0;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(&nodes[i]);
+		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+		if (key != 0ull) {
+			acc += node_digest(key, ((uint64_t)v.w << 32) | v.z);
+			cnt++;
+		}
+	}
+	const unsigned long long a = block_sum(acc, red);
+	const unsigned long long c = block_sum(cnt, red);
+	if (threadIdx.x == 0) {
+		atomicAdd(&out[0], a);
+		atomicAdd(&out[1], c);
+	}
+}
+
+// calculate_kmer_links first pass (contig.cpp:119-181): DepthStat[256] over all 8 counters of
+// every node and the node classes.  out: [0..255] depth_stat, [256] total, [257] deleted,
+// [258] linear, [259] tip, [260] branch
+__device__ __forceinline__ void link_classes(uint64_t links, int cutoff, unsigned int *hist, unsigned long long *cls)
+{
+	int ln = 0, rn = 0;
+#pragma unroll
+	for (int b = 0; b < 8; b++) {
+		const unsigned int d = (unsigned int)(links >> (8 * b)) & 0xFFu;
+		atomicAdd(&hist[d], 1u);
+		if ((int)d > cutoff) {
+			if (b < 4) ln++; else rn++;
+		}
+	}
+	if (ln > 3) ln = 3;
+	if (rn > 3) rn = 3;
+	cls[0]++;
+	if (ln == 0 && rn == 0) cls[1]++;
+	if (ln == 1 && rn == 1) cls[2]++;
+	if (ln + rn == 1) cls[3]++;
+	if (ln > 1 || rn > 1) cls[4]++;
+}
+
+__global__ __launch_bounds__(kBlock) void k_link_stats(const Node *__restrict__ nodes, uint64_t size, int cutoff,
+                                                       uint64_t polyA_links, unsigned long long *__restrict__ out)
+{
+	__shared__ unsigned int hist[256];
+	__shared__ unsigned long long red[kBlock / 64];
+	hist[threadIdx.x] = 0; // kBlock == 256
+	__syncthreads();
+	unsigned long long cls[5] = {0, 0, 0, 0, 0};
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(&nodes[i]);
+		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+		if (key != 0ull) link_classes(((uint64_t)v.w << 32) | v.z, cutoff, hist, cls);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) link_classes(polyA_links, cutoff, hist, cls); // the key-0 node
+	__syncthreads();
+	if (hist[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+#pragma unroll
+	for (int c = 0; c < 5; c++) {
+		const unsigned long long s = block_sum(cls[c], red);
+		if (threadIdx.x == 0 && s) atomicAdd(&out[256 + c], s);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: nodes grouped by owner = (hash_code(key) >> 32) % n_parts; key 0 -> part 0
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxParts = 64;
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t n_parts)
+{
+	return (uint32_t)((hash_code(key) >> 32) % n_parts);
+}
+
+__global__ __launch_bounds__(kBlock) void k_partition_count(const Node *__restrict__ nodes, uint64_t size,
+                                                            uint32_t n_parts, unsigned long long *__restrict__ counts)
+{
+	__shared__ unsigned int local[kMaxParts];
+	if (threadIdx.x < kMaxParts) local[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) {
+		const uint64_t key = nodes[i].kmer;
+		if (key != 0ull) atomicAdd(&local[owner_of(key, n_parts)], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < n_parts && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+}
+
+// cursors[p] starts at the part's base offset; every block reserves one range per part per sweep
+__global__ __launch_bounds__(kBlock) void k_partition_scatter(const Node *__restrict__ nodes, uint64_t size,
+                                                              uint32_t n_parts, unsigned long long *__restrict__ cursors,
+                                                              Node *__restrict__ out, uint64_t capacity)
+{
+	__shared__ unsigned int local[kMaxParts];
+	__shared__ unsigned long long base[kMaxParts];
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	const uint64_t n_iter = (size + stride - 1) / stride;
+	for (uint64_t it = 0; it < n_iter; it++) {
+		if (threadIdx.x < kMaxParts) local[threadIdx.x] = 0;
+		__syncthreads();
+		const uint64_t i = it * stride + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (i < size) v = *reinterpret_cast<const uint4 *>(&nodes[i]);
+		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+		uint32_t part = 0, rank = 0;
+		if (key != 0ull) {
+			part = owner_of(key, n_parts);
+			rank = atomicAdd(&local[part], 1u);
+		}
+		__syncthreads();
+		if (threadIdx.x < n_parts && local[threadIdx.x])
+			base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+		__syncthreads();
+		if (key != 0ull) {
+			const uint64_t dst = base[part] + rank;
+			if (dst < capacity) *reinterpret_cast<uint4 *>(&out[dst]) = v;
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic reads straight into HBM (include/dbgk_synth.h); one thread per 16 output bytes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_synth_reads(dbgk_synth_params P, uint64_t first_read, uint64_t n_reads,
+                                                        char *__restrict__ bases, uint64_t *__restrict__ offsets)
+{
+	const uint64_t L = P.read_len;
+	const uint64_t total = n_reads * L;
+	const uint64_t n_chunks = (total + 15u) >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < n_chunks; c += stride) {
+		uint32_t w[4] = {0, 0, 0, 0};
+		uint64_t cur_read = ~0ull, start = 0;
+		uint32_t strand = 0;
+		for (uint32_t b = 0; b < 16; b++) {
+			const uint64_t g = c * 16u + b;
+			if (g >= total) break;
+			const uint64_t r = g / L;
+			const uint32_t j = (uint32_t)(g - r * L);
+			if (r != cur_read) {
+				cur_read = r;
+				dbgk_synth_read_origin(&P, first_read + r, &start, &strand);
+			}
+			const uint32_t ch = (uint8_t)dbgk_synth_read_base_at(&P, first_read + r, j, start, strand);
+			w[b >> 2] |= ch << ((b & 3u) * 8u);
+		}
+		if (c * 16u + 16u <= total) {
+			*reinterpret_cast<uint4 *>(bases + c * 16u) = make_uint4(w[0], w[1], w[2], w[3]);
+		} else {
+			for (uint32_t b = 0; c * 16u + b < total; b++) bases[c * 16u + b] = (char)(w[b >> 2] >> ((b & 3u) * 8u));
+		}
+	}
+	for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r <= n_reads; r += stride) offsets[r] = r * L;
+}
+
+} // namespace dbgk

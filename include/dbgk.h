@@ -1,0 +1,219 @@
+/*
+ * dbgk.h -- C ABI of the MI355X (gfx950) k-mer / de Bruijn graph construction layer.
+ *
+ * This is the drop-in boundary underneath DBG_assembly's build_debruijn_graph()
+ * (reference: DBG_contig/DBGgraph.h:66, DBG_contig/DBGgraph.cpp:364-430).  The reference has no
+ * FFI of its own (single C++ process); the entry points below are what
+ * its hot path decomposes into when the compute moves to the GPU.  Each one names the reference
+ * routine it replaces.  All functions are extern "C", take plain pointers and sizes, return an
+ * int status (0 = DBGK_OK, < 0 = error, never hang on a full table) and may be called from one
+ * host thread per handle.  One handle = one GPU = one HIP stream.
+ *
+ * There is NO CPU fallback behind this interface: every entry point fails with DBGK_ERR_HIP when
+ * no gfx950 device is usable.
+ *
+ * Paths are relative to /root/reference/.
+ */
+#ifndef DBGK_H_
+#define DBGK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include "dbgk_synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBGK_ABI_VERSION 1
+
+/* status codes */
+#define DBGK_OK               0
+#define DBGK_ERR_ARG         -1   /* bad argument / unsupported parameter (k < 1 or k > 32, ...)    */
+#define DBGK_ERR_HIP         -2   /* HIP runtime error or no gfx950 device; see dbgk_last_error()    */
+#define DBGK_ERR_TABLE_FULL  -3   /* an insert found no free slot: the reference would spin forever
+                                     here (DBGgraph.cpp:170-205); create a larger handle            */
+#define DBGK_ERR_STATE       -4   /* call order violated (push after finalize, export before, ...)  */
+#define DBGK_ERR_NOMEM       -5   /* device or host allocation failed                               */
+#define DBGK_ERR_CAPACITY    -6   /* caller-provided output buffer too small                        */
+
+/* the 16-byte graph node: bit-identical to KmerNode (DBG_contig/kmerSet.h:70-75).  Each link word
+ * holds four saturating 8-bit counters, A in bits 31..24 ... T in bits 7..0 (kmerSet.cpp:56).      */
+typedef struct dbgk_node {
+	uint64_t kmer;
+	uint32_t l_link;
+	uint32_t r_link;
+} dbgk_node;
+
+typedef struct dbgk_handle dbgk_handle;
+
+/* engine selection for the insert path */
+#define DBGK_ENGINE_AUTO       0
+#define DBGK_ENGINE_DIRECT     1  /* fused extract + 64-bit-atomic insert into the global table      */
+#define DBGK_ENGINE_PARTITION  2  /* extract -> radix-partitioned records -> LDS-built table regions */
+
+typedef struct dbgk_config {
+	int32_t  kmer_size;        /* KmerSize   (DBGgraph.cpp:10), 1..32                              */
+	int32_t  max_read_len;     /* maxReadLen (DBGgraph.cpp:11): longer reads are trimmed           */
+	uint64_t table_slots;      /* number of 16-byte slots of the device table == kset->size the
+	                              host wants (a "prime" from find_next_prime, kmerSet.cpp:85-95);
+	                              slot of a key = hash_code(key) % table_slots (DBGgraph.cpp:167) */
+	int32_t  device_id;        /* HIP device ordinal                                               */
+	int32_t  engine;           /* DBGK_ENGINE_*                                                    */
+	uint64_t max_batch_bases;  /* capacity of the internal staging buffers used by
+	                              dbgk_push_reads (host buffers); 0 = default (256 MiB)            */
+	uint64_t expected_kmers;   /* PARTITION engine: upper bound on k-mer occurrences that will be
+	                              pushed before finalize (sizes the record store); 0 = derive
+	                              from table_slots                                                */
+	uint64_t reserved[4];
+} dbgk_config;
+
+/* totals after dbgk_finalize (the globals the reference prints, DBGgraph.cpp:410-411, and the
+ * KmerSet counters of kmerSet.cpp:331-338) */
+typedef struct dbgk_stats {
+	uint64_t total_reads;      /* Total_reads_num: every record pushed, also too-short ones (:274) */
+	uint64_t total_kmers;      /* Kmer_total_num : sum of (len-K+1) over reads with len >= K,
+	                              UNtrimmed length (:101)                                          */
+	uint64_t stored_kmers;     /* windows actually extracted = sum max(0,min(len,maxReadLen)-K+1);
+	                              the unit of BASELINE.json's metric                               */
+	uint64_t count;            /* kset->count: distinct keys INCLUDING the key-0 node (:418)       */
+	uint64_t count_conflict;   /* probe steps taken (layout dependent, informational)              */
+	uint64_t table_slots;
+	uint32_t polyA_l_link;     /* links of the key-0 (poly-A / poly-T) node (:153-164)             */
+	uint32_t polyA_r_link;
+} dbgk_stats;
+
+/* first pass of the consumer (DBG_contig/contig.cpp:107-181) computed on the device table */
+typedef struct dbgk_link_stats {
+	int64_t depth_stat[256];   /* DepthStat: histogram of all 8 counters of every node            */
+	int64_t total_nodes;
+	int64_t deleted_lowfreq;   /* nodes with no counter > cutoff on either side                    */
+	int64_t linear_nodes;      /* exactly one on each side                                         */
+	int64_t tip_nodes;         /* l+r == 1                                                         */
+	int64_t branch_nodes;      /* l > 1 or r > 1                                                   */
+} dbgk_link_stats;
+
+/* per-phase device timings of the most recent push/finalize, from HIP events on the handle's
+ * stream (milliseconds; 0 when the phase did not run) */
+typedef struct dbgk_timings {
+	float mark_ms;             /* read-boundary bitmap + totals                                    */
+	float insert_ms;           /* DIRECT: fused extract+insert kernel; PARTITION: extract+scatter  */
+	float partition_ms;        /* PARTITION: second-level scatter                                  */
+	float build_ms;            /* PARTITION: LDS region build + emit                               */
+	float fixup_ms;            /* PARTITION: overflow records through the direct path              */
+	float finalize_ms;         /* key-0 node, flags, count reduce                                  */
+	uint64_t insert_launches;  /* number of launches accumulated into insert_ms                    */
+	uint64_t reserved[3];
+} dbgk_timings;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+
+/* replaces init_kmerset_parallel + the staging allocations of build_debruijn_graph
+ * (kmerSet.cpp:98-127, DBGgraph.cpp:381-402): allocates and zeroes the device table.            */
+int dbgk_create(const dbgk_config *cfg, dbgk_handle **out);
+int dbgk_destroy(dbgk_handle *h);
+/* back to the state right after dbgk_create (table zeroed, totals cleared) without reallocating */
+int dbgk_reset(dbgk_handle *h);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* replaces one block iteration of parse_one_reads_file: thread_parseBlock + thread_updatekmers
+ * (DBGgraph.cpp:38-120,126-213) for `n_reads` reads.  bases = the sequences back to back with no
+ * separators (ASCII, contract ACGTNacgtn; N counts as A like seqKmer.cpp:9-19, any other byte
+ * is treated as A too), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
+ * HOST buffers; the call copies them through pinned double buffers and returns once the batch is
+ * queued (asynchronous w.r.t. the device).                                                       */
+int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+
+/* same, for reads already resident in device memory of the handle's GPU (both pointers 16-byte
+ * aligned, readable through the end of the last read).  Nothing is copied; the buffers must stay
+ * valid until the next dbgk_sync/dbgk_finalize.                                                  */
+int dbgk_push_reads_device(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets,
+                           uint64_t n_reads, uint64_t n_bases);
+
+/* replaces the tail of build_debruijn_graph (DBGgraph.cpp:418, add_node_to_kmerset
+ * kmerSet.cpp:253-273): completes all queued work, appends the key-0 node, reduces the counters.
+ * Returns DBGK_ERR_TABLE_FULL if any insert ran out of slots.                                    */
+int dbgk_finalize(dbgk_handle *h, dbgk_stats *out);
+
+/* wait for all queued work of the handle */
+int dbgk_sync(dbgk_handle *h);
+
+/* ---- results ----------------------------------------------------------------------------------- */
+
+/* fills a host KmerSet: `array` (host_size nodes) and `nul_flag` (host_size/8+1 bytes, bit i =
+ * byte i/8 mask 128>>(i%8), kmerSet.cpp:53) such that every key is reachable by linear probing
+ * from hash_code(key) % host_size without crossing a clear flag (exist_kmerset kmerSet.cpp:280-302),
+ * unused slots are all-zero, and the key-0 node sits on key 0's probe chain.  host_size may differ
+ * from table_slots (the table is then re-seated on the device first: the GPU counterpart of
+ * enlarge_kmerset_parallel, kmerSet.cpp:132-189).                                                */
+int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
+
+/* canonical dump: all nodes sorted by kmer (the parity artefact of SURVEY.md section 8(a)).
+ * `capacity` = number of nodes `out` can hold (>= stats.count).                                  */
+int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out);
+
+/* order-independent digest of the node multiset: sum over nodes of
+ * mix64(kmer ^ mix64((l_link << 32) | r_link)) mod 2^64, mix64 = splitmix64 finaliser             */
+int dbgk_digest(dbgk_handle *h, uint64_t *digest);
+
+/* calculate_kmer_links first pass (contig.cpp:119-181) on the device table                      */
+int dbgk_link_stats_device(dbgk_handle *h, int32_t kmer_freq_cutoff, dbgk_link_stats *out);
+
+/* ---- phase A alone (parity of the extraction kernel) ------------------------------------------ */
+
+/* thread_parseBlock only (DBGgraph.cpp:38-120) on host buffers: for every base position p of
+ * `bases` writes valid[p] (1 if a k-mer window starts at p inside its read after trimming), and
+ * for valid positions kmer[p], left[p], right[p] exactly as StoreKmer/StoreLeftBase/StoreRightBase
+ * would hold them for (read i, j = p - offsets[i]).  All four outputs are HOST arrays of
+ * offsets[n_reads] entries.                                                                      */
+int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                       uint64_t *kmer, uint8_t *left, uint8_t *right, uint8_t *valid);
+
+/* ---- multi-GPU building blocks (reads shard by record, keys are owned by hash) ---------------- */
+
+/* owner of a key among n_parts ranks: (hash_code(key) >> 32) % n_parts -- the device analogue of
+ * the reference's `kmer % threadNum` ownership (DBGgraph.cpp:148).  After dbgk_finalize:
+ * counts[p] = number of nodes of this handle's table owned by part p (host array, n_parts).      */
+int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts);
+/* writes the nodes grouped by owner into the DEVICE buffer d_nodes (capacity nodes): part p
+ * occupies [sum(counts[0..p)), +counts[p]).  The key-0 node is owned by part 0.                  */
+int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity);
+/* merges n already-aggregated nodes (DEVICE buffer) into the table: insert-if-absent, otherwise
+ * per-byte saturating add min(255, a+b) -- exact for any split of the input because
+ * min(255, min(255,a)+min(255,b)) == min(255,a+b).  Allowed before and after dbgk_finalize; a
+ * key-0 node in the input is folded into the handle's key-0 node.                                */
+int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n);
+/* recount after merges (finalize semantics without re-appending the key-0 node twice)            */
+int dbgk_refresh_stats(dbgk_handle *h, dbgk_stats *out);
+
+/* ---- utilities --------------------------------------------------------------------------------- */
+
+/* synthetic reads (include/dbgk_synth.h) generated straight into device memory: d_bases gets
+ * n_reads * read_len bytes, d_offsets n_reads+1 entries                                          */
+int dbgk_synth_reads_device(dbgk_handle *h, const dbgk_synth_params *p, uint64_t first_read,
+                            uint64_t n_reads, char *d_bases, uint64_t *d_offsets);
+
+int dbgk_device_malloc(dbgk_handle *h, size_t bytes, void **d_ptr);
+int dbgk_device_free(dbgk_handle *h, void *d_ptr);
+int dbgk_memcpy_d2h(dbgk_handle *h, void *dst, const void *d_src, size_t bytes);
+int dbgk_memcpy_h2d(dbgk_handle *h, void *d_dst, const void *src, size_t bytes);
+
+int dbgk_get_timings(dbgk_handle *h, dbgk_timings *out);
+int dbgk_reset_timings(dbgk_handle *h);
+/* HIP stream of the handle as an opaque pointer (hipStream_t), for callers that time with events */
+void *dbgk_stream(dbgk_handle *h);
+
+/* device-to-device copy bandwidth probe (GB/s) used as the measured-HBM denominator             */
+int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int iters, double *gbps);
+
+int dbgk_device_count(void);
+int dbgk_abi_version(void);
+const char *dbgk_strerror(int status);
+/* text of the most recent HIP failure seen by this thread ("" if none) */
+const char *dbgk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBGK_H_ */
