@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mer hashing throughput of the MI355X path on BASELINE.json's metric.
+
+  python bench.py --gpus 1 --steps K --warmup W            (single process)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one whole pass of the hot path over one batch of synthetic reads that is already
+resident in HBM: zero the table (init_kmerset_parallel), mark read boundaries, fused
+extract + canonicalise + hash-insert of every k-mer, finalize (counters, key-0 node); for N > 1
+additionally the owner exchange of SURVEY.md section 8(e) (bucket-count all-reduce, all-to-all of
+aggregated nodes over RCCL/xGMI, owner merge).  Workload at every N: BASELINE.json configs[1]
+per GPU (10 M x 150 bp reads, k = 31, 30x of a 50 Mb genome per GPU => weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
+dominant kernel (timed with HIP events on the library's own stream) and `cpu_baseline` (the real
+reference, oracle/_ref, on a bounded sample of the same reads; the oracle port if that binary is
+absent) -- the CPU baseline is a reported number, not something the GPU path calls.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = 33.25          # algorithmic bytes per k-mer, k=31 L=150: 1.25 B bases + 16 B node read + 16 B node write
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--genome-per-gpu", type=int, default=50_000_000)
+    ap.add_argument("--kmer", type=int, default=31)
+    ap.add_argument("--table-slots", type=int, default=600_000_000, help="rounded up by find_next_prime")
+    ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc run")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, genome_len):
+    """Time the reference's own pthreaded CPU path (oracle/_ref/ref_dbg) on the first
+    --cpu-sample-reads reads of rank 0's workload; fall back to the oracle port when the binary
+    did not travel.  Checker code: used here only as the thing timed NEXT TO the GPU path."""
+    import tempfile
+    from oracle import oracle_py as O
+    import ctypes as C
+    # threads actually used: the box's CPU share for one GPU (16), never more than the cores visible
+    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
+    n = args.cpu_sample_reads
+    P = O.synth_params(genome_len, 150, cfg=2)
+    init = max(2.2 * n * (150 - args.kmer + 1) / 1e9 * 0.75, 0.001)  # distinct <= kmers; load <= ~0.6
+    sample = "first %d reads of the N=1 workload (%d k-mers), -t %d -i %.3f -b 10000" % (
+        n, n * (150 - args.kmer + 1), cores, init)
+    if O.have_ref():
+        with tempfile.TemporaryDirectory() as tmp:
+            fa = os.path.join(tmp, "sample.fa")
+            O.lib().orc_synth_write_file(C.byref(P), 0, n, os.fsencode(fa), 2, 0)
+            libf = os.path.join(tmp, "reads.lib")
+            open(libf, "w").write(fa + "\n")
+            js = O.ref_build(libf, k=args.kmer, max_read_len=250, threads=cores, init_hash_size=init,
+                             buffer_num=10000, fmt=2, timeout=900)
+        return {"value": js["kmers"] / js["wall_s"] / 1e6, "unit": "M k-mers/s", "cores": cores,
+                "kind": "reference", "sample": sample + ", one-line FASTA from local disk, wall %.2f s" % js["wall_s"]}
+    bases, offsets = O.synth_reads(P, 0, n)
+    t0 = time.perf_counter()
+    res = O.build_graph(files_mem=[(bases, offsets)], k=args.kmer, threads=cores, init_hash_size=init)
+    dt = time.perf_counter() - t0
+    return {"value": res.total_kmers / dt / 1e6, "unit": "M k-mers/s", "cores": cores, "kind": "port",
+            "sample": sample + ", reads pre-loaded in memory, wall %.2f s" % dt}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import HipEngine, exchange_and_merge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n_reads = args.reads_per_gpu
+    genome_len = args.genome_per_gpu * world
+    kpr = 150 - args.kmer + 1
+    size = capi.find_next_prime_ref(args.table_slots)
+    P = capi.synth_params(genome_len, 150, cfg=2)
+
+    g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine)
+    d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
+    engine = HipEngine(g, device)
+
+    def step():
+        g.reset()
+        g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        st = g.finalize()
+        if world > 1:
+            return exchange_and_merge(engine)
+        return {"stored_kmers": int(st.stored_kmers), "count": int(st.count)}
+
+    def fence():
+        g.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    g.sync()
+    g.reset_timings()
+    fence()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tm = g.timings()
+
+    total_kmers = res["stored_kmers"]  # all ranks
+    ms_per_step = dt / args.steps * 1e3
+    value = total_kmers / (dt / args.steps) / 1e6
+
+    if rank == 0:
+        launches = max(int(tm.insert_launches), 1)
+        kern_ms = tm.insert_ms / launches
+        kmers_per_launch = n_reads * kpr
+        achieved = kmers_per_launch * B_ALG / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "M k-mers/s hashed (k=31, 150 bp)", "value": value, "unit": "M k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31",
+                       "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
+                       "nodes": res["count"], "engine": "direct" if args.engine in (0, 1) else "partition",
+                       "parallelism": "reads sharded by record x%d, keys owned by hash" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_extract_insert", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.traffic_bytes, "kernel_ms": kern_ms, "bytes_per_kmer": B_ALG,
+                         "kmers_per_launch": kmers_per_launch},
+            "phases_ms_per_step": {"mark": tm.mark_ms / args.steps, "insert": tm.insert_ms / args.steps,
+                                   "partition": tm.partition_ms / args.steps, "build": tm.build_ms / args.steps,
+                                   "merge": tm.fixup_ms / args.steps},
+        }
+        if world == 1:
+            try:
+                out["copy_bandwidth_GBs"] = g.copy_bandwidth(1 << 30, 10)
+            except Exception as e:  # noqa: BLE001
+                out["copy_bandwidth_GBs"] = None
+                print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args, genome_len)
+        print(json.dumps(out), flush=True)
+
+    d_bases.free()
+    d_off.free()
+    g.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

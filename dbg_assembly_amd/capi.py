@@ -73,6 +73,8 @@ SYMBOLS = [
     ("dbgk_push_reads_device", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_sync", _i, [_vp]),
+    ("dbgk_resize_table", _i, [_vp, _u64]),
+    ("dbgk_copy_nodes_peer", _i, [_vp, _vp, _vp, _vp, _u64]),
     ("dbgk_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
@@ -200,6 +202,10 @@ class Graph:
     def reset(self):
         _chk(lib().dbgk_reset(self._h), "dbgk_reset")
         self.stats = None
+
+    def resize_table(self, new_slots):
+        _chk(lib().dbgk_resize_table(self._h, new_slots), "dbgk_resize_table")
+        self.table_slots = new_slots
 
     # ---- results
     def export_sorted(self):

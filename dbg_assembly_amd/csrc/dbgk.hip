@@ -299,6 +299,42 @@ extern "C" int dbgk_sync(dbgk_handle *h)
 
 extern "C" void *dbgk_stream(dbgk_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
+{
+	if (!h || new_slots < 3) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	rc = dbgk_sync(h);
+	if (rc) return rc;
+	if (new_slots == h->size) return DBGK_OK;
+	Node *fresh = nullptr;
+	if (hipMalloc(&fresh, new_slots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	TableRef dst{fresh, new_slots, make_mod_magic(new_slots)};
+	hipError_t e = hipMemsetAsync(fresh, 0, new_slots * sizeof(Node), h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, dst, h->d_ctr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) {
+		(void)hipFree(fresh);
+		return hip_fail(e, "resize_table", __LINE__);
+	}
+	if (h->h_ctr->error & 1u) { // new table too small for the existing nodes: keep the old one
+		(void)hipFree(fresh);
+		HIPCHK(hipMemsetAsync(&h->d_ctr->error, 0, sizeof(unsigned int), h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		return DBGK_ERR_TABLE_FULL;
+	}
+	(void)hipFree(h->table);
+	h->table = fresh;
+	h->size = new_slots;
+	h->magic = dst.magic;
+	h->cfg.table_slots = new_slots;
+	return DBGK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------------------------
@@ -763,6 +799,18 @@ extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64
 	                   h->tref(), h->d_ctr);
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp);
+}
+
+extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_handle *src, const dbgk_node *d_src, uint64_t n)
+{
+	if (!dst || !src || (n && (!d_dst || !d_src))) return DBGK_ERR_ARG;
+	if (n == 0) return DBGK_OK;
+	int rc = dbgk_sync(src);
+	if (rc) return rc;
+	rc = use_device(dst);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyPeer(d_dst, dst->device, d_src, src->device, n * sizeof(dbgk_node)));
+	return DBGK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

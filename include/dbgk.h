@@ -119,8 +119,8 @@ int dbgk_reset(dbgk_handle *h);
 
 /* replaces one block iteration of parse_one_reads_file: thread_parseBlock + thread_updatekmers
  * (DBGgraph.cpp:38-120,126-213) for `n_reads` reads.  bases = the sequences back to back with no
- * separators (ASCII, contract ACGTNacgtn; N counts as A like seqKmer.cpp:9-19, any other byte
- * is treated as A too), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
+ * separators (ASCII, contract ACGTNacgtn; N counts as A like seqKmer.cpp:9-19; any other byte is
+ * outside the contract -- undefined behaviour in the reference, an unspecified base here), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
  * HOST buffers; the call copies them through pinned double buffers and returns once the batch is
  * queued (asynchronous w.r.t. the device).                                                       */
 int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
@@ -138,6 +138,11 @@ int dbgk_finalize(dbgk_handle *h, dbgk_stats *out);
 
 /* wait for all queued work of the handle */
 int dbgk_sync(dbgk_handle *h);
+
+/* replaces enlarge_kmerset_parallel (kmerSet.cpp:132-189) for the DEVICE table: allocates a table
+ * of new_slots, re-seats every node, frees the old one.  Content (the node multiset) is unchanged.
+ * Allowed between pushes (it synchronises first).                                               */
+int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots);
 
 /* ---- results ----------------------------------------------------------------------------------- */
 
@@ -184,8 +189,12 @@ int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, 
  * min(255, min(255,a)+min(255,b)) == min(255,a+b).  Allowed before and after dbgk_finalize; a
  * key-0 node in the input is folded into the handle's key-0 node.                                */
 int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n);
-/* recount after merges (finalize semantics without re-appending the key-0 node twice)            */
+/* recount after merges (finalize semantics without re-appending the key-0 node twice); also
+ * usable between pushes to watch the load of the table                                          */
 int dbgk_refresh_stats(dbgk_handle *h, dbgk_stats *out);
+/* single-process multi-GPU: copy n nodes from a device buffer of src's GPU into a device buffer
+ * of dst's GPU (peer copy over xGMI), synchronous                                               */
+int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_handle *src, const dbgk_node *d_src, uint64_t n);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
 
