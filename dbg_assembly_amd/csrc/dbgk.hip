@@ -13,6 +13,7 @@
 
 #include "dbgk.h"
 #include "dbgk_kernels.h"
+#include "dbgk_partition.h"
 
 // dbgk_sort.hip
 extern "C" int dbgk_internal_sort_pairs(uint64_t *d_keys, uint64_t *d_vals, uint64_t n, hipStream_t stream);
@@ -90,6 +91,13 @@ struct dbgk_handle {
 
 	bool finalized = false;
 	uint64_t total_reads = 0;
+
+	// PARTITION engine
+	bool part = false;            // records are partitioned at push time, table built at finalize
+	bool part_built = false;      // finalize already turned the records into the table
+	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
+	PartGeom geom;
+	PartStore store;
 
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
@@ -197,6 +205,11 @@ static void free_handle(dbgk_handle *h)
 		}
 	if (h->dev_start) (void)hipFree(h->dev_start);
 	if (h->dev_dead) (void)hipFree(h->dev_dead);
+	if (h->part) {
+		for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
+		                (void *)h->store.spill, (void *)h->store.ovf_n})
+			if (p) (void)hipFree(p);
+	}
 	if (h->table) (void)hipFree(h->table);
 	if (h->d_ctr) (void)hipFree(h->d_ctr);
 	if (h->h_ctr) (void)hipHostFree(h->h_ctr);
@@ -204,13 +217,93 @@ static void free_handle(dbgk_handle *h)
 	delete h;
 }
 
-static int reset_state(dbgk_handle *h)
+static int zero_table_now(dbgk_handle *h)
 {
 	HIPCHK(hipMemsetAsync(h->table, 0, h->size * sizeof(Node), h->stream)); // memset_parallel, kmerSet.cpp:358-386
+	h->zero_pending = false;
+	return DBGK_OK;
+}
+
+static int reset_state(dbgk_handle *h)
+{
+	if (h->part) {
+		// the region build of finalize overwrites every slot, so the 16 B/slot memset is only needed
+		// if a direct-path write (merge) happens first
+		h->zero_pending = true;
+		h->part_built = false;
+		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n1 * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.n1 * h->geom.n2 * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
+	} else {
+		int rc = zero_table_now(h);
+		if (rc) return rc;
+	}
 	HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
 	HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
 	h->finalized = false;
 	h->total_reads = 0;
+	return DBGK_OK;
+}
+
+// Decide whether the PARTITION engine is used and allocate its record stores.
+//   geometry: level-1 bucket = slot >> r, r >= 20 chosen so that n1 = ceil(size / 2^r) <= 1024;
+//   final bucket = slot >> 12 (one 4096-slot region); n2 = 2^(r-12) sub-buckets per level-1 bucket.
+//   An 8-byte record must hold q = hash / size, r slot bits and 6 neighbour bits.
+static int setup_partition(dbgk_handle *h)
+{
+	h->part = false;
+	memset(&h->store, 0, sizeof h->store);
+	memset(&h->geom, 0, sizeof h->geom);
+	const int want = h->cfg.engine;
+	if (want == DBGK_ENGINE_DIRECT) return DBGK_OK;
+	if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
+	uint32_t r = 20;
+	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kMaxBuckets) r++;
+	const uint64_t qmax = ~0ull / h->size;
+	int qbits = 0;
+	while (qbits < 64 && (qmax >> qbits)) qbits++;
+	const bool feasible = (r - kRegionBits) <= 10 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26);
+	if (!feasible) {
+		if (want == DBGK_ENGINE_PARTITION) {
+			g_last_error = "PARTITION engine needs 2^26 <= table_slots < 2^32";
+			return DBGK_ERR_ARG;
+		}
+		return DBGK_OK;
+	}
+	for (uint64_t x : {0ull, 1ull, 0x0123456789ABCDEFull, ~0ull, 488296166657017542ull}) {
+		if (hash_code_inverse(hash_code(x)) != x) {
+			g_last_error = "hash_code_inverse self-check failed";
+			return DBGK_ERR_STATE;
+		}
+	}
+	PartGeom &G = h->geom;
+	G.size = h->size;
+	G.magic = h->magic;
+	G.r = r;
+	G.n1 = (uint32_t)((h->size + (1ull << r) - 1) >> r);
+	G.n2 = 1u << (r - kRegionBits);
+	G.n_final = (uint32_t)((h->size + kRegionSlots - 1) >> kRegionBits);
+	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2;
+	const double per_slot = (double)expected / (double)h->size;
+	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05) + 65536;
+	G.cap2 = (uint64_t)(per_slot * (double)kRegionSlots * 1.15) + 512;
+	PartStore &P = h->store;
+	P.ovf_cap = expected / 64 + (1ull << 20);
+	P.spill_cap = (uint64_t)G.n_final * 8 + (1ull << 16);
+	const size_t l1_bytes = (size_t)G.n1 * G.cap1 * 8, l2_bytes = (size_t)G.n1 * G.n2 * G.cap2 * 8;
+	if (hipMalloc(&P.l1, l1_bytes) != hipSuccess || hipMalloc(&P.l2, l2_bytes) != hipSuccess ||
+	    hipMalloc(&P.cnt1, (size_t)G.n1 * 4) != hipSuccess || hipMalloc(&P.cnt2, (size_t)G.n1 * G.n2 * 4) != hipSuccess ||
+	    hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) != hipSuccess || hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) != hipSuccess ||
+	    hipMalloc(&P.ovf_n, 16) != hipSuccess) {
+		g_last_error = "hipMalloc of the PARTITION record stores failed";
+		h->part = true; // so that free_handle releases what was allocated
+		return DBGK_ERR_NOMEM;
+	}
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	h->part = true;
 	return DBGK_OK;
 }
 
@@ -262,6 +355,10 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	if (hipHostMalloc(&h->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return fail(DBGK_ERR_NOMEM);
 	h->cap_bases = cfg->max_batch_bases ? cfg->max_batch_bases : (256ull << 20);
 	h->cap_reads = h->cap_bases / 16 + 1024;
+	{
+		const int prc = setup_partition(h);
+		if (prc != DBGK_OK) return fail(prc);
+	}
 	int rc = reset_state(h);
 	if (rc != DBGK_OK) return fail(rc);
 	if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(DBGK_ERR_HIP);
@@ -368,10 +465,18 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
-	if (has_long)
+	if (h->part) {
+		const uint64_t n_tiles = (n_chunks + kTileThreads - 1) / kTileThreads;
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
+		if (has_long)
+			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kTileThreads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else
+			hipLaunchKernelGGL(k_extract_scatter<false>, dim3(grid), dim3(kTileThreads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+	} else if (has_long) {
 		hipLaunchKernelGGL(k_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
-	else
+	} else {
 		hipLaunchKernelGGL(k_extract_insert<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
+	}
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp);
 }
@@ -473,16 +578,52 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 	out->polyA_r_link = (uint32_t)(c.polyA_links >> 32);
 }
 
+// PARTITION engine: records -> final buckets -> table regions, then the stragglers
+static int build_from_records(dbgk_handle *h)
+{
+	const PartGeom &G = h->geom;
+	TimedSpan sp;
+	int rc = span_begin(h, PH_PARTITION, sp);
+	if (rc) return rc;
+	const uint32_t tiles = (uint32_t)((G.cap1 + kTileRecords - 1) / kTileRecords);
+	hipLaunchKernelGGL(k_scatter_l2, dim3(tiles, G.n1), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->d_ctr);
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	if (rc) return rc;
+	rc = span_begin(h, PH_BUILD, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_build_regions, dim3(G.n_final), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	if (rc) return rc;
+	h->zero_pending = false; // every slot has just been written
+	rc = span_begin(h, PH_FIXUP, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
+	                   h->tref(), h->d_ctr);
+	hipLaunchKernelGGL(k_insert_triples, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap,
+	                   h->tref(), h->d_ctr);
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	h->part_built = true;
+	return rc;
+}
+
 extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 {
 	if (!h) return DBGK_ERR_ARG;
 	int rc = use_device(h);
 	if (rc) return rc;
+	if (h->part && !h->part_built && !h->finalized) {
+		rc = build_from_records(h);
+		if (rc) return rc;
+	}
 	rc = read_counters(h);
 	if (rc) return rc;
 	h->finalized = true;
 	if (out) fill_stats(h, out);
 	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+	if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY; // PARTITION overflow stores exhausted (expected_kmers too small)
 	if (h->h_ctr->n_new + 1 > h->size) return DBGK_ERR_TABLE_FULL; // no free slot left for the key-0 node
 	return DBGK_OK;
 }
@@ -792,6 +933,11 @@ extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (n == 0) return DBGK_OK;
+	if (h->zero_pending) { // PARTITION handle used as a plain merge target: the region build will not run
+		rc = zero_table_now(h);
+		if (rc) return rc;
+		h->part_built = true;
+	}
 	TimedSpan sp;
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;

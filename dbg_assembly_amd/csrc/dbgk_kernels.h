@@ -78,6 +78,22 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 	return s;
 }
 
+template <int THREADS>
+__device__ __forceinline__ unsigned long long block_sum_n(unsigned long long v, unsigned long long *lds)
+{
+	v = wave_sum(v);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__syncthreads();
+	if (lane == 0) lds[wave] = v;
+	__syncthreads();
+	unsigned long long s = 0;
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int w = 0; w < THREADS / 64; w++) s += lds[w];
+	}
+	return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_mark: read boundaries + the reference's totals, one thread per read
 //   start bit at offsets[r]; dead bits on [offsets[r]+maxReadLen, offsets[r+1]) (DBGgraph.cpp:63);
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRe
 			for (int u = 0; u < kGroup; u++) {
 				if (!t[u].valid) continue;
 				if (t[u].key == 0ull) { // poly-A / poly-T side node (DBGgraph.cpp:153-164)
-					links_cas_observe(polyA, 0ull, t[u].lb, t[u].rb);
+					links_cas_observe(polyA, *reinterpret_cast<volatile unsigned long long *>(polyA), t[u].lb, t[u].rb);
 					continue;
 				}
 				uint64_t guess;

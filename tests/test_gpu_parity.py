@@ -245,3 +245,94 @@ def test_full_size_properties_cfg2_sample(capi):
         assert g2.digest() == dig
         for b in (d_bases, d_off, e_bases, e_off, f_bases, f_off, buf):
             b.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# PARTITION engine (records -> radix partition by final slot range -> LDS-built regions)
+# ------------------------------------------------------------------------------------------------
+PART_SLOTS = 70000000  # the engine needs >= 2^26 slots (8-byte records)
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=golden_case_ids())
+def test_partition_engine_golden_cases(capi, oracle, case):
+    p, ref = case["params"], case["ref"]
+    if case["name"] == "enlarge_cap_e1":
+        pytest.skip("reference drops reads at the -e cap")
+    files = case_reads(case, oracle)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    n_bases = sum(int(o[-1]) for _, o in files)
+    g = capi.Graph(k=p["k"], table_slots=size, max_read_len=p["max_read_len"], engine=capi.ENGINE_PARTITION,
+                   expected_kmers=max(n_bases, 1))
+    try:
+        for bases, offsets in files:
+            g.push_reads(bases, offsets)
+        st = g.finalize()
+        assert (st.total_reads, st.total_kmers, st.count) == (ref["reads"], ref["kmers"], ref["count"])
+        nodes = g.export_sorted()
+        assert dump_sha256(nodes, st.total_reads, st.total_kmers, st.count) == case["dump_sha256"]
+        array, flags = g.export_host_table()
+        assert oracle.check_host_table(array, flags, size, st.count) == 0  # valid linear-probing layout
+    finally:
+        g.close()
+
+
+def test_partition_engine_equals_direct_and_oracle(capi, oracle):
+    n_reads, G = 200000, 1000000
+    P, PO = capi.synth_params(G, 150, cfg=1), oracle.synth_params(G, 150, cfg=1)
+    bases, offsets = oracle.synth_reads(PO, 0, n_reads)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=n_reads * 150) as g:
+        d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+        # two pushes (records accumulate), then one finalize
+        half = n_reads // 2
+        g.push_reads_device(d_bases.ptr, d_off.ptr, half, half * 150)
+        h_off = np.arange(n_reads - half + 1, dtype=np.uint64) * np.uint64(150)
+        d_off2 = g.malloc(h_off.nbytes)
+        d_off2.from_host(h_off)
+        g.push_reads_device(d_bases.ptr + half * 150 - (half * 150) % 16, d_off2.ptr, 0, 0)  # empty push is harmless
+        tail = g.malloc((n_reads - half) * 150 + 64)
+        tail.from_host(bases[half * 150:])
+        g.push_reads_device(tail.ptr, d_off2.ptr, n_reads - half, (n_reads - half) * 150)
+        st = g.finalize()
+        nodes = g.export_sorted()
+        dig = g.digest()
+        ls = g.link_stats(2)
+        array, flags = g.export_host_table()
+        assert oracle.check_host_table(array, flags, size, st.count) == 0
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.02, threads=1)
+    assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+    assert np.array_equal(nodes, ref.nodes)
+    assert dig == oracle.nodes_digest(ref.nodes)
+    assert list(ls.depth_stat) == list(oracle.link_stats(ref.nodes, 2).depth_stat)
+
+
+def test_partition_engine_bucket_overflow_goes_through_direct_path(capi, oracle):
+    """expected_kmers far too small + one heavily repeated read: bucket capacities overflow and
+    the excess records take the global-atomic path; the result must not change"""
+    rng = random.Random(21)
+    reads = rand_reads(rng, 1500, G=6000) + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 3000
+    bases, offsets = oracle.pack_reads(reads)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=1) as g:
+        g.push_reads(bases, offsets)
+        st = g.finalize()
+        nodes = g.export_sorted()
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    assert st.count == ref.count and np.array_equal(nodes, ref.nodes)
+
+
+def test_full_size_direct_vs_partition_digest(capi):
+    """2 M reads of the cfg2 workload: two independent GPU implementations must agree bit for bit"""
+    n_reads, G = 2000000, 10000000
+    P = capi.synth_params(G, 150, cfg=2)
+    size = capi.find_next_prime_ref(150000000)
+    res = []
+    for engine in (capi.ENGINE_DIRECT, capi.ENGINE_PARTITION):
+        with capi.Graph(k=31, table_slots=size, engine=engine, expected_kmers=n_reads * 150) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st = g.finalize()
+            res.append((st.count, st.stored_kmers, g.digest(), list(g.link_stats(2).depth_stat)))
+            d_bases.free()
+            d_off.free()
+    assert res[0] == res[1]
