@@ -98,6 +98,7 @@ struct dbgk_handle {
 	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
 	PartGeom geom;
 	PartStore store;
+	uint32_t *tile_prefix = nullptr; // [n1 + 1] level-2 tile plan
 
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
@@ -209,6 +210,7 @@ static void free_handle(dbgk_handle *h)
 		for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
 		                (void *)h->store.spill, (void *)h->store.ovf_n})
 			if (p) (void)hipFree(p);
+		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
 	}
 	if (h->table) (void)hipFree(h->table);
 	if (h->d_ctr) (void)hipFree(h->d_ctr);
@@ -294,7 +296,7 @@ static int setup_partition(dbgk_handle *h)
 	if (hipMalloc(&P.l1, l1_bytes) != hipSuccess || hipMalloc(&P.l2, l2_bytes) != hipSuccess ||
 	    hipMalloc(&P.cnt1, (size_t)G.n1 * 4) != hipSuccess || hipMalloc(&P.cnt2, (size_t)G.n1 * G.n2 * 4) != hipSuccess ||
 	    hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) != hipSuccess || hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) != hipSuccess ||
-	    hipMalloc(&P.ovf_n, 16) != hipSuccess) {
+	    hipMalloc(&P.ovf_n, 16) != hipSuccess || hipMalloc(&h->tile_prefix, (kMaxBuckets + 1) * 4) != hipSuccess) {
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		h->part = true; // so that free_handle releases what was allocated
 		return DBGK_ERR_NOMEM;
@@ -585,8 +587,8 @@ static int build_from_records(dbgk_handle *h)
 	TimedSpan sp;
 	int rc = span_begin(h, PH_PARTITION, sp);
 	if (rc) return rc;
-	const uint32_t tiles = (uint32_t)((G.cap1 + kTileRecords - 1) / kTileRecords);
-	hipLaunchKernelGGL(k_scatter_l2, dim3(tiles, G.n1), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->d_ctr);
+	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, G, h->store, h->tile_prefix);
+	hipLaunchKernelGGL(k_scatter_l2, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;

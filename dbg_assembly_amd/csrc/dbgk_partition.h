@@ -101,6 +101,15 @@ __device__ __forceinline__ void push_overflow(const PartStore &P, uint64_t key, 
 	}
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), which would stall every tile on its own global stores, prefetched
+// loads and reservation atomics; all data exchanged between the threads of these kernels goes
+// through LDS, so waiting for the LDS counter is sufficient.
+__device__ __forceinline__ void lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- workgroup-wide bucket scatter of up to 16 records per thread ------------------------------
 struct ScatterLds {
 	uint64_t stage[kTileRecords];
@@ -122,7 +131,7 @@ __device__ __forceinline__ void scan_hist(ScatterLds &L)
 		if (lane >= off) inc += n;
 	}
 	if (lane == 63) L.wave_tot[wave] = inc;
-	__syncthreads();
+	lds_barrier();
 	uint32_t before = 0;
 	for (int w = 0; w < wave; w++) before += L.wave_tot[w];
 	L.lbase[t] = before + inc - v;
@@ -139,18 +148,23 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
 {
 	const int t = threadIdx.x;
 	L.hist[t] = 0;
-	__syncthreads();
+	lds_barrier();
 	uint32_t rank[PER_THREAD];
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) rank[u] = (bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u;
-	__syncthreads();
+	lds_barrier();
+	// reserve space in the global buckets: issued now, consumed only at copy-out, so the atomic's
+	// round trip overlaps the scan and the staging writes
+	const uint32_t my_count = L.hist[t];
+	uint32_t my_gbase = 0;
+	if ((uint32_t)t < n_buckets && my_count) my_gbase = atomicAdd(&cnt[t], my_count);
 	scan_hist(L);
-	if ((uint32_t)t < n_buckets && L.hist[t]) L.gbase[t] = atomicAdd(&cnt[t], L.hist[t]);
-	__syncthreads();
+	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++)
 		if (bkt[u] != 0xFFFFu) L.stage[L.lbase[bkt[u]] + rank[u]] = rec[u];
-	__syncthreads();
+	L.gbase[t] = my_gbase;
+	lds_barrier();
 	// copy-out: each wave takes buckets wave, wave+16, ...; a run is written with contiguous 8-byte lanes
 	const int lane = t & 63, wave = t >> 6;
 	for (uint32_t b = wave; b < n_buckets; b += kTileThreads / 64) {
@@ -169,7 +183,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
 			}
 		}
 	}
-	__syncthreads();
+	lds_barrier(); // stage / hist are reused by the next tile; the global stores keep draining
 }
 
 // ---- level 1: extraction fused with the first scatter ------------------------------------------
@@ -213,29 +227,79 @@ __global__ __launch_bounds__(kTileThreads) void k_extract_scatter(ReadBatch rb, 
 }
 
 // ---- level 2: split every level-1 bucket into its n2 final buckets -----------------------------
-// grid = (tiles per bucket, n1); workgroups whose tile lies beyond the bucket's fill exit at once
-__global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartStore P, Counters *__restrict__ ctr)
+// k_plan_l2 (one workgroup): tile_prefix[b1] = number of 16384-record tiles in buckets < b1.
+__global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P, uint32_t *__restrict__ tile_prefix)
 {
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	ScatterLds &L = *reinterpret_cast<ScatterLds *>(lds_raw);
-	const uint32_t b1 = blockIdx.y;
+	__shared__ uint32_t tot[kMaxBuckets / 64];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	uint32_t v = 0;
+	if ((uint32_t)t < G.n1) {
+		const uint64_t filled = P.cnt1[t] < G.cap1 ? P.cnt1[t] : G.cap1;
+		v = (uint32_t)((filled + kTileRecords - 1) / kTileRecords);
+	}
+	uint32_t inc = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t n = __shfl_up(inc, off, 64);
+		if (lane >= off) inc += n;
+	}
+	if (lane == 63) tot[wave] = inc;
+	__syncthreads();
+	uint32_t before = 0;
+	for (int w = 0; w < wave; w++) before += tot[w];
+	if ((uint32_t)t < G.n1) tile_prefix[t] = before + inc - v;
+	if ((uint32_t)t == G.n1 - 1) tile_prefix[G.n1] = before + inc;
+}
+
+// Persistent workgroups (one per CU) walk the flattened tile list; the records of tile i+1 are
+// loaded into registers before tile i is scattered, so HBM reads, the LDS work and the (undrained)
+// stores of consecutive tiles overlap.
+__device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore &P, const uint32_t *__restrict__ tile_prefix,
+                                             uint32_t g, uint32_t n_tiles, uint64_t (&rec)[16], uint32_t &b1_out)
+{
+	b1_out = 0;
+#pragma unroll
+	for (int u = 0; u < 16; u++) rec[u] = ~0ull;
+	if (g >= n_tiles) return;
+	uint32_t lo = 0, hi = G.n1; // last b1 with tile_prefix[b1] <= g
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (tile_prefix[mid] <= g) lo = mid; else hi = mid;
+	}
+	const uint32_t b1 = lo;
+	b1_out = b1;
 	const uint64_t filled = P.cnt1[b1] < G.cap1 ? P.cnt1[b1] : G.cap1;
-	const uint64_t first = (uint64_t)blockIdx.x * kTileRecords;
-	if (first >= filled) return;
+	const uint64_t first = (uint64_t)(g - tile_prefix[b1]) * kTileRecords;
 	const uint64_t *in = P.l1 + (uint64_t)b1 * G.cap1;
-	uint64_t rec[16];
-	uint32_t bkt[16];
 #pragma unroll
 	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
 		const uint64_t i = first + (uint64_t)u * kTileThreads + threadIdx.x;
-		bkt[u] = 0xFFFFu;
-		rec[u] = 0;
-		if (i < filled) {
-			rec[u] = in[i];
-			bkt[u] = (uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u);
-		}
+		if (i < filled) rec[u] = __builtin_nontemporal_load(in + i);
 	}
-	scatter_tile<16>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)b1 * G.n2, P.l2 + (uint64_t)b1 * G.n2 * G.cap2, G.cap2, b1, false, G, P, ctr);
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
+                                                             Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	ScatterLds &L = *reinterpret_cast<ScatterLds *>(lds_raw);
+	const uint32_t n_tiles = tile_prefix[G.n1];
+	uint64_t nxt[16];
+	uint32_t nxt_b1;
+	l2_load_tile(G, P, tile_prefix, blockIdx.x, n_tiles, nxt, nxt_b1);
+	for (uint32_t g = blockIdx.x; g < n_tiles; g += gridDim.x) {
+		uint64_t rec[16];
+		uint32_t bkt[16];
+		const uint32_t b1 = nxt_b1;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			rec[u] = nxt[u];
+			// an all-ones word is never a record: the neighbour fields only take the values 0..4
+			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
+		}
+		l2_load_tile(G, P, tile_prefix, g + gridDim.x, n_tiles, nxt, nxt_b1); // in flight during the scatter below
+		scatter_tile<16>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)b1 * G.n2, P.l2 + (uint64_t)b1 * G.n2 * G.cap2, G.cap2, b1, false, G, P, ctr);
+	}
 }
 
 // ---- build: one workgroup per 4096-slot region ---------------------------------------------------
@@ -255,50 +319,61 @@ __global__ __launch_bounds__(kBuildThreads) void k_build_regions(PartGeom G, Par
 	const uint64_t region_base = (uint64_t)f << kRegionBits;
 	const uint32_t region_len = (uint32_t)((G.size - region_base < (uint64_t)kRegionSlots) ? G.size - region_base : kRegionSlots);
 	const int t = threadIdx.x;
+	const uint64_t filled = P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2;
+	const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
 
 	for (int i = t; i < kRegionSlots + kSpillSlots; i += kBuildThreads) {
 		L.ident[i] = 0ull;
 		L.links[i] = 0ull;
 	}
-	__syncthreads();
+	lds_barrier();
 
-	const uint64_t filled = P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2;
-	const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
 	unsigned long long n_new = 0, n_conf = 0;
-	for (uint64_t i = t; i < filled; i += kBuildThreads) {
-		const uint64_t rec = in[i];
-		const unsigned long long id = (rec >> 6) + 1ull;
-		const uint32_t lb = (uint32_t)(rec >> 3) & 7u, rb = (uint32_t)rec & 7u;
-		uint32_t idx = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
-		bool placed = false;
-		while (idx < (uint32_t)(kRegionSlots + kSpillSlots)) {
-			unsigned long long cur = L.ident[idx];
-			if (cur == 0ull) {
-				cur = atomicCAS(&L.ident[idx], 0ull, id);
-				if (cur == 0ull) {
-					if (idx < region_len) n_new++; // spilled nodes are counted when they are merged
-					placed = true;
-					break;
-				}
-			}
-			if (cur == id) { placed = true; break; }
-			n_conf++;
-			idx++;
+	constexpr int kBatch = 8; // records per thread loaded together before any LDS work
+	for (uint64_t base = 0; base < filled; base += (uint64_t)kBatch * kBuildThreads) {
+		uint64_t recs[kBatch];
+#pragma unroll
+		for (int u = 0; u < kBatch; u++) {
+			const uint64_t i = base + (uint64_t)u * kBuildThreads + t;
+			recs[u] = (i < filled) ? __builtin_nontemporal_load(in + i) : ~0ull;
 		}
-		if (placed) {
-			unsigned long long old = L.links[idx];
-			for (;;) {
-				const unsigned long long upd = links_observe(old, lb, rb);
-				if (upd == old) break;
-				const unsigned long long prev = atomicCAS(&L.links[idx], old, upd);
-				if (prev == old) break;
-				old = prev;
+#pragma unroll
+		for (int u = 0; u < kBatch; u++) {
+			const uint64_t rec = recs[u];
+			if (rec == ~0ull) continue;
+			const unsigned long long id = (rec >> 6) + 1ull;
+			const uint32_t lb = (uint32_t)(rec >> 3) & 7u, rb = (uint32_t)rec & 7u;
+			uint32_t idx = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
+			bool placed = false;
+			while (idx < (uint32_t)(kRegionSlots + kSpillSlots)) {
+				unsigned long long cur = L.ident[idx];
+				if (cur == 0ull) {
+					cur = atomicCAS(&L.ident[idx], 0ull, id);
+					if (cur == 0ull) {
+						if (idx < region_len) n_new++; // spilled nodes are counted when they are merged
+						placed = true;
+						break;
+					}
+				}
+				if (cur == id) { placed = true; break; }
+				n_conf++;
+				idx++;
 			}
-		} else {
-			push_overflow(P, record_key(rec, b1, G), lb, rb, ctr); // region + spill area completely full
+			if (placed) {
+				unsigned long long old = L.links[idx];
+				for (;;) {
+					const unsigned long long upd = links_observe(old, lb, rb);
+					if (upd == old) break;
+					const unsigned long long prev = atomicCAS(&L.links[idx], old, upd);
+					if (prev == old) break;
+					old = prev;
+				}
+			} else {
+				push_overflow(P, record_key(rec, b1, G), lb, rb, ctr); // region + spill area completely full
+			}
 		}
 	}
-	__syncthreads();
+	lds_barrier();
 
 	// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot))
 	for (uint32_t i = t; i < region_len; i += kBuildThreads) {
