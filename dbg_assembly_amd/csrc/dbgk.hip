@@ -281,6 +281,7 @@ static int setup_partition(dbgk_handle *h)
 	PartGeom &G = h->geom;
 	G.size = h->size;
 	G.magic = h->magic;
+	G.div = make_div32_magic((uint32_t)h->size);
 	G.r = r;
 	G.n1 = (uint32_t)((h->size + (1ull << r) - 1) >> r);
 	G.n2 = 1u << (r - kRegionBits);
@@ -301,8 +302,10 @@ static int setup_partition(dbgk_handle *h)
 		h->part = true; // so that free_handle releases what was allocated
 		return DBGK_ERR_NOMEM;
 	}
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	h->part = true;
@@ -468,12 +471,17 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
 	if (h->part) {
-		const uint64_t n_tiles = (n_chunks + kTileThreads - 1) / kTileThreads;
+		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
-		if (has_long)
-			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kTileThreads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
+		if (dbg_mode == 1)
+			hipLaunchKernelGGL((k_extract_scatter<false, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (dbg_mode == 2)
+			hipLaunchKernelGGL((k_extract_scatter<false, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (has_long)
+			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else
-			hipLaunchKernelGGL(k_extract_scatter<false>, dim3(grid), dim3(kTileThreads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+			hipLaunchKernelGGL(k_extract_scatter<false>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 	} else if (has_long) {
 		hipLaunchKernelGGL(k_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
 	} else {

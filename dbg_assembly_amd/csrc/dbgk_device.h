@@ -47,6 +47,62 @@ __device__ __forceinline__ uint64_t fast_mod(uint64_t h, const ModMagic g)
 	return fast_divmod(h, g, q);
 }
 
+// ---- exact 64-bit / 32-bit division by a run-time invariant divisor ----------------------------
+// For tables below 2^32 slots (always true for the PARTITION engine) the divisor fits one dword and
+// hash / size, hash % size are two steps of the Moller-Granlund "2-by-1" division with a precomputed
+// reciprocal (Improved division by invariant integers, IEEE TC 2011, Alg. 4): one 32x32->64
+// multiply and one 32-bit multiply per step instead of the ~11 quarter-rate multiplies of the
+// generic 64-bit path.
+struct Div32Magic {
+	uint32_t dn;   // divisor << s (normalised: top bit set)
+	uint32_t v;    // floor((2^64 - 1) / dn) - 2^32
+	uint32_t s;    // clz(divisor)
+	uint32_t d;    // the divisor
+};
+
+static inline Div32Magic make_div32_magic(uint32_t d)
+{
+	Div32Magic g;
+	g.d = d;
+	g.s = (uint32_t)__builtin_clz(d);
+	g.dn = d << g.s;
+	g.v = (uint32_t)((~0ull / g.dn) - (1ull << 32));
+	return g;
+}
+
+// (u1:u0) / dn with u1 < dn, dn normalised
+__device__ __forceinline__ uint32_t div_2by1(uint32_t u1, uint32_t u0, const Div32Magic g, uint32_t &rem)
+{
+	uint64_t p = (uint64_t)g.v * u1;
+	p += ((uint64_t)u1 << 32) | u0;
+	uint32_t q1 = (uint32_t)(p >> 32) + 1u;
+	const uint32_t q0 = (uint32_t)p;
+	uint32_t r = u0 - q1 * g.dn;
+	if (r > q0) { q1--; r += g.dn; }
+	if (r >= g.dn) { q1++; r -= g.dn; }
+	rem = r;
+	return q1;
+}
+
+// h = q * d + r, d < 2^32; returns r, q in q_out (q < 2^64 / d)
+__device__ __forceinline__ uint32_t divmod_u64_u32(uint64_t h, const Div32Magic g, uint64_t &q_out)
+{
+	const uint32_t a = (uint32_t)(h >> 32), b = (uint32_t)h;
+	uint32_t u2, u1, u0;
+	if (g.s) { // wave-uniform
+		u2 = a >> (32u - g.s);
+		u1 = (a << g.s) | (b >> (32u - g.s));
+		u0 = b << g.s;
+	} else {
+		u2 = 0u; u1 = a; u0 = b;
+	}
+	uint32_t r1, r2;
+	const uint32_t qh = div_2by1(u2, u1, g, r1);
+	const uint32_t ql = div_2by1(r1, u0, g, r2);
+	q_out = ((uint64_t)qh << 32) | ql;
+	return r2 >> g.s;
+}
+
 // ---- hash_code (kmerSet.h:105-116) and its inverse ------------------------------------------
 __host__ __device__ __forceinline__ uint64_t hash_code(uint64_t k)
 {

@@ -25,9 +25,12 @@ namespace dbgk {
 constexpr int kRegionBits = 12;                 // 4096 slots = 64 KiB of nodes per region
 constexpr int kRegionSlots = 1 << kRegionBits;
 constexpr int kSpillSlots = 128;                // LDS slots past the region end: probe overflow
-constexpr int kTileThreads = 1024;              // scatter kernels: 16 waves, one workgroup per CU
-constexpr int kTileRecords = kTileThreads * 16; // 16384 records staged in LDS (128 KiB)
+constexpr int kTileThreads = 1024;              // scatter kernels: 16 waves
+constexpr int kTileRecords = kTileThreads * 16; // level 2: 16384 records staged in LDS (128 KiB), one workgroup per CU
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
+constexpr int kBPT = kMaxBuckets / kTileThreads; // histogram entries owned by one thread
+constexpr int kL1Threads = kTileThreads;        // level-1 kernel: same tile geometry as level 2
+constexpr int kL1BPT = kMaxBuckets / kL1Threads;
 constexpr int kBuildThreads = 512;
 
 // ---- inverse of hash_code ------------------------------------------------------------------
@@ -65,6 +68,7 @@ struct PartGeom {
 	uint32_t n_final;    // ceil(size / 4096)
 	uint64_t cap1;       // records per level-1 bucket
 	uint64_t cap2;       // records per final bucket
+	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h)
 };
 
 struct PartStore {
@@ -119,12 +123,14 @@ struct ScatterLds {
 	uint32_t wave_tot[kTileThreads / 64];
 };
 
-// exclusive prefix sum of hist[0..kMaxBuckets) into lbase, one entry per thread (1024 threads)
+// exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries kBPT*t .. kBPT*t+kBPT-1
 __device__ __forceinline__ void scan_hist(ScatterLds &L)
 {
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const uint32_t v = L.hist[t];
-	uint32_t inc = v;
+	uint32_t v[kBPT], sum = 0;
+#pragma unroll
+	for (int j = 0; j < kBPT; j++) { v[j] = L.hist[kBPT * t + j]; sum += v[j]; }
+	uint32_t inc = sum;
 #pragma unroll
 	for (int off = 1; off < 64; off <<= 1) {
 		const uint32_t n = __shfl_up(inc, off, 64);
@@ -132,42 +138,48 @@ __device__ __forceinline__ void scan_hist(ScatterLds &L)
 	}
 	if (lane == 63) L.wave_tot[wave] = inc;
 	lds_barrier();
-	uint32_t before = 0;
-	for (int w = 0; w < wave; w++) before += L.wave_tot[w];
-	L.lbase[t] = before + inc - v;
+	uint32_t run = inc - sum;
+	for (int w = 0; w < wave; w++) run += L.wave_tot[w];
+#pragma unroll
+	for (int j = 0; j < kBPT; j++) { L.lbase[kBPT * t + j] = run; run += v[j]; }
 }
 
-// rec[u] valid iff bkt[u] != 0xFFFF.  Appends every record to bucket bkt[u] of `out` (bucket b
-// occupies out[(bucket_index0 + b) * cap ..]), reserving space with one global atomic per non-empty
-// bucket per tile; records beyond a bucket's capacity are decoded and pushed to the overflow list.
-template <int PER_THREAD>
-__device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&bkt)[PER_THREAD],
-                                             uint32_t n_buckets, uint32_t *__restrict__ cnt, uint64_t *__restrict__ out,
-                                             uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
-                                             const PartStore &P, Counters *ctr)
+// Phases of the workgroup-wide bucket scatter of one tile (<= 16 records per thread).
+//   br[u] = (bucket << 16) | rank-within-bucket, bucket 0xFFFF = no record
+
+// after every record has been ranked (hist complete): reserve global space, scan
+__device__ __forceinline__ void scatter_reserve_scan(ScatterLds &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[kBPT])
 {
 	const int t = threadIdx.x;
-	L.hist[t] = 0;
-	lds_barrier();
-	uint32_t rank[PER_THREAD];
-#pragma unroll
-	for (int u = 0; u < PER_THREAD; u++) rank[u] = (bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u;
-	lds_barrier();
-	// reserve space in the global buckets: issued now, consumed only at copy-out, so the atomic's
+	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
 	// round trip overlaps the scan and the staging writes
-	const uint32_t my_count = L.hist[t];
-	uint32_t my_gbase = 0;
-	if ((uint32_t)t < n_buckets && my_count) my_gbase = atomicAdd(&cnt[t], my_count);
+#pragma unroll
+	for (int j = 0; j < kBPT; j++) {
+		const uint32_t b = kBPT * t + j, c = L.hist[b];
+		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b], c) : 0u;
+	}
 	scan_hist(L);
 	lds_barrier();
+}
+
+// bucket-sorted staging of the records, then the coalesced copy-out.  Records beyond a bucket's
+// capacity are decoded and pushed to the overflow list.
+template <int PER_THREAD, int DBG = 0>
+__device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
+                                                   const uint32_t (&my_gbase)[kBPT], uint32_t n_buckets, uint64_t *__restrict__ out,
+                                                   uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
+                                                   const PartStore &P, Counters *ctr)
+{
+	const int t = threadIdx.x;
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++)
-		if (bkt[u] != 0xFFFFu) L.stage[L.lbase[bkt[u]] + rank[u]] = rec[u];
-	L.gbase[t] = my_gbase;
+		if ((br[u] >> 16) != 0xFFFFu) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
+#pragma unroll
+	for (int j = 0; j < kBPT; j++) L.gbase[kBPT * t + j] = my_gbase[j];
 	lds_barrier();
 	// copy-out: each wave takes buckets wave, wave+16, ...; a run is written with contiguous 8-byte lanes
 	const int lane = t & 63, wave = t >> 6;
-	for (uint32_t b = wave; b < n_buckets; b += kTileThreads / 64) {
+	for (uint32_t b = wave; b < (DBG == 2 ? 0u : n_buckets); b += kTileThreads / 64) {
 		const uint32_t n = L.hist[b];
 		if (n == 0) continue;
 		const uint32_t src = L.lbase[b];
@@ -186,43 +198,247 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
 	lds_barrier(); // stage / hist are reused by the next tile; the global stores keep draining
 }
 
-// ---- level 1: extraction fused with the first scatter ------------------------------------------
+// whole scatter for records held in registers (level 2)
+template <int PER_THREAD, int DBG = 0>
+__device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], uint32_t (&bkt)[PER_THREAD],
+                                             uint32_t n_buckets, uint32_t *__restrict__ cnt, uint64_t *__restrict__ out,
+                                             uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
+                                             const PartStore &P, Counters *ctr)
+{
+	const int t = threadIdx.x;
+#pragma unroll
+	for (int j = 0; j < kBPT; j++) L.hist[kBPT * t + j] = 0;
+	lds_barrier();
+#pragma unroll
+	for (int u = 0; u < PER_THREAD; u++) bkt[u] = (bkt[u] << 16) | ((bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u);
+	lds_barrier();
+	uint32_t my_gbase[kBPT];
+	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
+	scatter_stage_copy<PER_THREAD, DBG>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
+}
+
+// ---- lean extraction for the partition path -----------------------------------------------------
+// Same semantics as load_lane_window/next_triple (dbgk_kernels.h; DBGgraph.cpp:64-98) with the
+// per-position work cut down: forward and reverse k-mers ROLL by one base per position as in the
+// reference (:71-73) instead of being re-derived from the window; the three per-position predicates
+// (window inside one read, has left / right neighbour) are computed once per 16 positions as bit
+// masks with log-step sliding ORs over the boundary bitmap; nothing branches per position.
+
+// bit i of the result = OR of bits i .. i+w-1 of x (w wave-uniform, 0..63)
+__device__ __forceinline__ uint64_t sliding_or(uint64_t x, uint32_t w)
+{
+	uint64_t res = 0ull, cur = x;
+	uint32_t done = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < 6; j++) {
+		if (w & (1u << j)) {
+			res |= cur >> done;
+			done += 1u << j;
+		}
+		cur |= cur >> (1u << j);
+	}
+	return res;
+}
+
+struct Chunk16 {
+	uint64_t kbit, rc;   // forward / reverse-complement k-mer of the window at position 0
+	uint32_t nb;         // bases k .. k+15: right neighbour of position i = entering base of position i+1
+	uint32_t lw;         // bases -1 .. 14: left neighbour of position i
+	uint32_t valid, has_l, has_r; // 16-bit masks, bit i <-> position p0 + i
+};
+
+__device__ __forceinline__ uint4 load_ascii16(const char *__restrict__ bases, uint64_t n_bases, uint64_t chunk)
+{
+	const uint64_t off = chunk * 16u;
+	if (off + 16u <= n_bases) return *reinterpret_cast<const uint4 *>(bases + off);
+	uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // beyond the end: 'A'
+	for (uint64_t i = 0; off + i < n_bases && i < 16; i++) {
+		const uint32_t c = (uint8_t)bases[off + i];
+		w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3u) * 8u))) | (c << ((i & 3u) * 8u));
+	}
+	return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Raw (not yet decoded) inputs of the 16 positions of one lane.  Kept separate from the decode so
+// that the loads of tile i+1 can be issued before tile i is processed: nothing in load_raw waits.
+// Lane l of a wave owns chunk c0+l; the two following packed words come from lanes l+1, l+2 by
+// shuffle, and from the HALO chunks c0+64, c0+65 (loaded by lanes 0 and 1) at the wave's end.
+struct RawChunk {
+	uint4 a0;        // 16 ASCII bases of this lane's chunk
+	uint4 halo;      // lanes 0,1: chunks c0+64, c0+65
+	uint32_t prevb;  // lane 0: the byte before the wave's first base
+	uint32_t s0, s1, s2, d0, d1, d2; // boundary bitmap words covering positions p0 .. p0+63 (+31)
+};
+
+template <bool HAS_DEAD, bool GUARDED>
+__device__ __forceinline__ RawChunk load_raw(const ReadBatch &rb, uint64_t chunk, uint64_t n_chunks)
+{
+	RawChunk r;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t halo_chunk = chunk - lane + 64u + lane; // == chunk + 64 for lanes 0,1
+	r.a0 = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+	r.halo = r.a0;
+	r.prevb = 0x41u;
+	if (GUARDED) {
+		if (chunk < n_chunks) r.a0 = load_ascii16(rb.bases, rb.n_bases, chunk);
+		if (lane < 2u && halo_chunk < n_chunks) r.halo = load_ascii16(rb.bases, rb.n_bases, halo_chunk);
+	} else {
+		r.a0 = *reinterpret_cast<const uint4 *>(rb.bases + chunk * 16u);
+		if (lane < 2u) r.halo = *reinterpret_cast<const uint4 *>(rb.bases + halo_chunk * 16u);
+	}
+	if (lane == 0u && chunk > 0u && (!GUARDED || chunk <= n_chunks)) r.prevb = (uint8_t)rb.bases[chunk * 16u - 1u];
+	const uint64_t p0 = chunk * 16u;
+	const uint64_t wi = p0 >> 5; // the bitmaps are padded by 4 words, safe for every chunk < n_chunks
+	r.s0 = r.s1 = r.s2 = r.d0 = r.d1 = r.d2 = 0u;
+	if (!GUARDED || chunk < n_chunks) {
+		r.s0 = rb.start_bits[wi];
+		r.s1 = rb.start_bits[wi + 1];
+		r.s2 = rb.start_bits[wi + 2];
+		if (HAS_DEAD) {
+			r.d0 = rb.dead_bits[wi];
+			r.d1 = rb.dead_bits[wi + 1];
+			r.d2 = rb.dead_bits[wi + 2];
+		}
+	}
+	return r;
+}
+
+__device__ __forceinline__ uint64_t bits64_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
+{
+	const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
+	return sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;
+}
+
 template <bool HAS_DEAD>
-__global__ __launch_bounds__(kTileThreads) void k_extract_scatter(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
+__device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const ReadBatch &rb, uint64_t chunk)
+{
+	Chunk16 c;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t p0 = chunk * 16u;
+	const uint32_t w0 = pack16_ascii(raw.a0);
+	const uint32_t hw = pack16_ascii(raw.halo);
+	const uint32_t hw0 = __builtin_amdgcn_readlane(hw, 0), hw1 = __builtin_amdgcn_readlane(hw, 1);
+	uint32_t w1 = __shfl_down(w0, 1, 64), w2 = __shfl_down(w0, 2, 64);
+	if (lane == 63u) { w1 = hw0; w2 = hw1; }
+	if (lane == 62u) w2 = hw0;
+	uint32_t prev = __shfl_up(w0, 1, 64) & 3u; // last base of the previous lane's chunk
+	const uint32_t pb = pack4_ascii(__builtin_amdgcn_readlane(raw.prevb, 0)) >> 6;
+	if (lane == 0u) prev = pb;
+	if (chunk == 0u) prev = 0u;
+	const uint64_t S = bits64_from_words(raw.s0, raw.s1, raw.s2, (uint32_t)(p0 & 31u));
+	const uint64_t hi = ((uint64_t)w0 << 32) | w1, mid = ((uint64_t)w1 << 32) | w2;
+	const uint32_t sh = 64u - 2u * k;                 // wave-uniform
+	c.kbit = hi >> sh;
+	c.rc = revcomp_kbit(c.kbit, (int)k);
+	c.nb = (sh < 32u) ? (uint32_t)(mid >> sh) : (uint32_t)(hi >> (sh - 32u));
+	c.lw = (prev << 30) | (w0 >> 2);
+	// window i is inside one read iff no read starts at positions i+1 .. i+k-1
+	uint64_t bad = sliding_or(S >> 1, k - 1u);
+	uint64_t no_r = S >> k;
+	if (HAS_DEAD) {
+		const uint64_t D = bits64_from_words(raw.d0, raw.d1, raw.d2, (uint32_t)(p0 & 31u));
+		bad |= sliding_or(D, k);
+		no_r |= D >> k;
+	}
+	// positions whose window / right neighbour lie inside the buffer
+	const uint64_t room = rb.n_bases > p0 ? rb.n_bases - p0 : 0ull;
+	const uint32_t nv = room >= k ? (uint32_t)(room - k + 1u < 16u ? room - k + 1u : 16u) : 0u;
+	const uint32_t nr = room > k ? (uint32_t)(room - k < 16u ? room - k : 16u) : 0u;
+	c.valid = ~(uint32_t)bad & ((1u << nv) - 1u);
+	c.has_r = ~(uint32_t)no_r & ((1u << nr) - 1u);
+	c.has_l = ~(uint32_t)S & 0xFFFFu & (p0 ? 0xFFFFu : 0xFFFEu);
+	return c;
+}
+
+// complement of a neighbour code that may be 4 (= none): 0<->3, 1<->2, 4 -> 4
+__device__ __forceinline__ uint32_t comp_code(uint32_t x) { return (0x4053u >> (x * 3u)) & 7u; } // packs {3,2,1,0,4}
+
+// ---- level 1: extraction fused with the first scatter ------------------------------------------
+// (A variant without LDS staging -- every lane storing its own 8-byte records into the reserved
+// bucket ranges -- was measured at 24.5 ms against 10.4 ms for the staged form: uncoalesced 8-byte
+// stores are the wrong trade on this chip even though the L2 merges them into lines.)
+// DBG != 0 are timing experiments selected with DBGK_DEBUG_MODE (results are wrong): 1 = extraction
+// only, 2 = no copy-out
+template <bool HAS_DEAD, int DBG = 0>
+__global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	ScatterLds &L = *reinterpret_cast<ScatterLds *>(lds_raw);
 	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
-	const uint64_t n_tiles = (n_chunks + kTileThreads - 1) / kTileThreads;
-	unsigned long long *polyA = &ctr->polyA_links;
+	const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;  // KmerHeadMaskVal, DBGgraph.cpp:371
+	const uint32_t rc_shift = 2u * k - 2u;                                      // KmerRCOrVal[b] = (3-b) << (2k-2), :373-376
 
+	// a tile is INTERIOR when every chunk it touches (incl. the two halo chunks past its end) is a
+	// full 16 bytes inside the buffer: its loads need no guards and are issued back to back
+	auto interior = [&](uint64_t tile) { return ((tile + 1u) * kL1Threads + 2u) * 16u <= rb.n_bases; };
+	auto fetch = [&](uint64_t tile) {
+		const uint64_t ch = tile * kL1Threads + threadIdx.x;
+		if (tile >= n_tiles) return RawChunk{};
+		return interior(tile) ? load_raw<HAS_DEAD, false>(rb, ch, n_chunks) : load_raw<HAS_DEAD, true>(rb, ch, n_chunks);
+	};
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const uint64_t chunk = tile * kTileThreads + threadIdx.x;
-		uint64_t rec[16];
-		uint32_t bkt[16];
-		if (chunk < n_chunks) {
-			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+		const RawChunk raw = fetch(tile); // all loads of the tile issued back to back, one round trip
+		const uint64_t chunk = tile * kL1Threads + threadIdx.x;
+		uint32_t bkt[16]; // (bucket << 16) | rank once the position has been processed
+		L.hist[threadIdx.x] = 0;
+		lds_barrier();
+		uint32_t zero_mask = 0; // valid positions whose canonical k-mer is 0 (poly-A / poly-T): rare, handled below
+		{
+			Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
+			if (chunk >= n_chunks) c.valid = 0u;
 #pragma unroll
 			for (uint32_t i = 0; i < 16; i++) {
-				const Triple tr = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
-				bkt[i] = 0xFFFFu;
-				rec[i] = 0;
-				if (tr.valid) {
-					if (tr.key == 0ull) {
-						links_cas_observe(polyA, *reinterpret_cast<volatile unsigned long long *>(polyA), tr.lb, tr.rb);
-					} else {
-						uint64_t q;
-						const uint64_t slot = fast_divmod(hash_code(tr.key), G.magic, q);
-						rec[i] = make_record(q, slot, G.r, tr.lb, tr.rb);
-						bkt[i] = (uint32_t)(slot >> G.r);
-					}
-				}
+				const uint32_t left = (c.lw >> (30u - 2u * i)) & 3u, right = (c.nb >> (30u - 2u * i)) & 3u;
+				const bool fwd = c.kbit <= c.rc;                        // tie -> forward (DBGgraph.cpp:80)
+				const uint64_t key = fwd ? c.kbit : c.rc;
+				const uint32_t lc = ((c.has_l >> i) & 1u) ? left : 4u, rcd = ((c.has_r >> i) & 1u) ? right : 4u;
+				const uint32_t lb = fwd ? lc : comp_code(rcd), rbb = fwd ? rcd : comp_code(lc);
+				const bool valid = (c.valid >> i) & 1u;
+				uint64_t q;
+				const uint32_t slot = divmod_u64_u32(hash_code(key), G.div, q);
+				// park the record in the (still unused) stage buffer, column i of this thread, and rank it
+				// right away: only one packed register per position stays live across the tile
+				L.stage[i * kL1Threads + threadIdx.x] = (q << (G.r + 6u)) | ((uint64_t)(slot & ((1u << G.r) - 1u)) << 6) | (uint64_t)((lb << 3) | rbb);
+				const bool zero = key == 0ull;
+				const uint32_t b = (valid && !zero) ? (slot >> G.r) : 0xFFFFu;
+				bkt[i] = (b << 16) | ((b != 0xFFFFu) ? atomicAdd(&L.hist[b], 1u) : 0u);
+				zero_mask |= (valid && zero) ? (1u << i) : 0u;
+				// roll to the next position (DBGgraph.cpp:71-73)
+				c.kbit = ((c.kbit << 2) | right) & head_mask;
+				c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
+				// keep the scheduler from interleaving all 16 positions (register pressure: the
+				// workgroup has 1024 threads, so 128 VGPRs per lane is the ceiling)
+				if ((i & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
 			}
-		} else {
-#pragma unroll
-			for (uint32_t i = 0; i < 16; i++) { bkt[i] = 0xFFFFu; rec[i] = 0; }
 		}
-		scatter_tile<16>(L, rec, bkt, G.n1, P.cnt1, P.l1, G.cap1, 0u, true, G, P, ctr);
+		if (zero_mask) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
+			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+#pragma unroll 1
+			for (uint32_t i = 0; i < 16; i++) {
+				const Triple tr = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
+				if (tr.valid && tr.key == 0ull)
+					links_cas_observe(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links), tr.lb, tr.rb);
+			}
+		}
+		if (DBG == 1) {
+			uint64_t x = 0;
+#pragma unroll
+			for (int u = 0; u < 16; u++) x ^= L.stage[u * kL1Threads + threadIdx.x] + bkt[u];
+			if (x == 0x1234567u) P.l1[threadIdx.x] = x;
+			lds_barrier();
+			continue;
+		}
+		lds_barrier(); // hist complete
+		uint32_t my_gbase[kBPT];
+		scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
+		uint64_t rec[16];
+#pragma unroll
+		for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + threadIdx.x];
+		lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
+		scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1, G.cap1, 0u, true, G, P, ctr);
 	}
 }
 
