@@ -5,9 +5,11 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one whole pass of the hot path over one batch of synthetic reads that is already
-resident in HBM: zero the table (init_kmerset_parallel), mark read boundaries, fused
-extract + canonicalise + hash-insert of every k-mer, finalize (counters, key-0 node); for N > 1
-additionally the owner exchange of SURVEY.md section 8(e) (bucket-count all-reduce, all-to-all of
+resident in HBM: reset (init_kmerset_parallel), mark read boundaries, extract + canonicalise +
+hash every k-mer into 8-byte records partitioned by final table slot range, second-level
+partition, build every 4096-slot region of the reference-layout table in LDS and write it out,
+finalize (counters, key-0 node) -- the PARTITION engine; --engine 1 selects the DIRECT engine
+(fused extract + global-atomic insert).  For N > 1 additionally the owner exchange of SURVEY.md section 8(e) (bucket-count all-reduce, all-to-all of
 aggregated nodes over RCCL/xGMI, owner merge).  Workload at every N: BASELINE.json configs[1]
 per GPU (10 M x 150 bp reads, k = 31, 30x of a 50 Mb genome per GPU => weak scaling).
 
@@ -38,13 +40,28 @@ def parse_args():
     ap.add_argument("--genome-per-gpu", type=int, default=50_000_000)
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--table-slots", type=int, default=600_000_000, help="rounded up by find_next_prime")
-    ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--engine", type=int, default=2, help="1 = DIRECT (global atomics), 2 = PARTITION (default)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
+
+
+def measured_traffic(args, size, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_r*.json), only
+    when this run is the workload those passes were taken on; else None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        with open(path) as fh:
+            t = json.load(fh)
+        w = t.get("workload", {})
+        if (w.get("reads_per_gpu"), w.get("kmer"), w.get("table_slots"), w.get("engine")) == \
+                (args.reads_per_gpu, args.kmer, size, args.engine) and kernel in t.get("bytes_per_launch", {}):
+            best = t["bytes_per_launch"][kernel]
+    return best
 
 
 def cpu_baseline(args, genome_len):
@@ -112,9 +129,17 @@ def main():
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     engine = HipEngine(g, device)
 
+    debug_mode = int(os.environ.get("DBGK_DEBUG_MODE", "0"))  # kernel timing experiments: results are wrong
+
     def step():
         g.reset()
         g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        if debug_mode:
+            try:
+                st = g.finalize()
+            except capi.DbgkError:
+                st = g.refresh_stats() if False else capi.Stats()
+            return {"stored_kmers": n_reads * kpr, "count": 0}
         st = g.finalize()
         if world > 1:
             return exchange_and_merge(engine)
@@ -166,11 +191,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31",
                        "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
-                       "nodes": res["count"], "engine": "direct" if args.engine in (0, 1) else "partition",
+                       "nodes": res["count"], "engine": "partition" if args.engine == capi.ENGINE_PARTITION else "direct",
                        "parallelism": "reads sharded by record x%d, keys owned by hash" % world},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes, "kernel_ms": kern_ms, "bytes_per_kmer": B_ALG,
+                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, dom_kernel),
+                         "kernel_ms": kern_ms, "bytes_per_kmer": B_ALG,
                          "kmers_per_launch": kmers_per_launch,
                          "all_kernels_ms": phase_kernels,
                          "pipeline_frac": kmers_per_launch * B_ALG / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -1,0 +1,54 @@
+"""GPU (-m gpu): the product multi-GPU path (HipEngine + torch.distributed/NCCL=RCCL collectives)
+on the one GPU a test box has: a single-rank process group exercises the same code the 8-GPU
+bench runs (count all-reduce, all-to-all of nodes through torch CUDA tensors, owner merge into a
+reset table, scalar all-reduce).  world > 1 plumbing is covered on CPU by test_multigpu_gloo.py."""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_exchange_and_merge_single_rank_nccl(engine):
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import HipEngine, exchange_and_merge
+
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_reads, G = 300000, 2000000
+        P = capi.synth_params(G, 150, cfg=2)
+        size = capi.find_next_prime_ref(80000000)
+        with capi.Graph(k=31, table_slots=size, engine=engine, expected_kmers=n_reads * 150) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st = g.finalize()
+            want = (st.count, st.total_kmers, st.total_reads, g.digest())
+            out = exchange_and_merge(HipEngine(g, torch.device("cuda", 0)))
+            assert (out["count"], out["total_kmers"], out["total_reads"]) == want[:3]
+            assert out["sent_nodes"] == out["recv_nodes"] == st.count
+            assert g.digest() == want[3]          # the owner table after the exchange == the local table
+            # and the handle is reusable for the next step (bench loop)
+            g.reset()
+            g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st2 = g.finalize()
+            assert (st2.count, g.digest()) == (want[0], want[3])
+            d_bases.free()
+            d_off.free()
+    finally:
+        dist.destroy_process_group()
