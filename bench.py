@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--table-slots", type=int, default=600_000_000, help="rounded up by find_next_prime")
     ap.add_argument("--engine", type=int, default=2, help="1 = DIRECT (global atomics), 2 = PARTITION (default)")
+    ap.add_argument("--exchange", choices=["records", "nodes"], default="records",
+                    help="N > 1: 'records' = slot-range ownership, level-1 buckets exchanged (default); "
+                         "'nodes' = local tables, aggregated nodes exchanged by hash owner")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +104,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
-    from dbg_assembly_amd.multigpu import HipEngine, exchange_and_merge
+    from dbg_assembly_amd.multigpu import HipEngine, exchange_and_merge, sharded_finalize
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,11 +124,17 @@ def main():
     n_reads = args.reads_per_gpu
     genome_len = args.genome_per_gpu * world
     kpr = 150 - args.kmer + 1
-    size = capi.find_next_prime_ref(args.table_slots)
     P = capi.synth_params(genome_len, 150, cfg=2)
+    # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
+    # (PARTITION engine, slot-range ownership; needs < 2^32 slots in total).  --exchange nodes selects
+    # the older flow (local tables, aggregated nodes shipped to hash owners).
+    sharded = world > 1 and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
+    per_gpu_slots = args.table_slots if world == 1 else min(args.table_slots, (2 ** 32 - 2 ** 22) // world)
+    size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
-                   expected_kmers=n_reads * 150 if args.engine == capi.ENGINE_PARTITION else 0)
+                   expected_kmers=n_reads * 150 if args.engine == capi.ENGINE_PARTITION else 0,
+                   shard_count=world if sharded else 0, shard_index=rank if sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     engine = HipEngine(g, device)
 
@@ -140,6 +149,8 @@ def main():
             except capi.DbgkError:
                 st = g.refresh_stats() if False else capi.Stats()
             return {"stored_kmers": n_reads * kpr, "count": 0}
+        if sharded:
+            return sharded_finalize(g, device)
         st = g.finalize()
         if world > 1:
             return exchange_and_merge(engine)
@@ -192,7 +203,10 @@ def main():
             "config": {"workload": "cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31",
                        "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
                        "nodes": res["count"], "engine": "partition" if args.engine == capi.ENGINE_PARTITION else "direct",
-                       "parallelism": "reads sharded by record x%d, keys owned by hash" % world},
+                       "parallelism": ("reads sharded by record x%d, k-mers owned by slot range of one global table "
+                                       "(all-to-all of level-1 record buckets)" % world) if sharded else
+                                      ("reads sharded by record x%d, keys owned by hash (aggregated nodes exchanged)" % world
+                                       if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, dom_kernel),

@@ -33,7 +33,15 @@ def synth_params(genome_len, read_len=150, sub_rate=0.005, n_rate=0.0001, cfg=2)
 class Config(C.Structure):
     _fields_ = [("kmer_size", C.c_int32), ("max_read_len", C.c_int32), ("table_slots", C.c_uint64),
                 ("device_id", C.c_int32), ("engine", C.c_int32), ("max_batch_bases", C.c_uint64),
-                ("expected_kmers", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("expected_kmers", C.c_uint64), ("shard_count", C.c_uint32), ("shard_index", C.c_uint32),
+                ("reserved", C.c_uint64 * 3)]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("table_slots_global", C.c_uint64),
+                ("slot_lo", C.c_uint64), ("slot_hi", C.c_uint64), ("d_send", C.c_void_p), ("d_recv", C.c_void_p),
+                ("chunk_bytes", C.c_uint64), ("d_send_cnt", C.c_void_p), ("d_recv_cnt", C.c_void_p),
+                ("cnt_chunk_bytes", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -84,6 +92,13 @@ SYMBOLS = [
     ("dbgk_partition_export", _i, [_vp, C.c_uint32, _vp, _u64]),
     ("dbgk_merge_nodes", _i, [_vp, _vp, _u64]),
     ("dbgk_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_shard_buffers", _i, [_vp, C.POINTER(ShardInfo)]),
+    ("dbgk_shard_mark_exchanged", _i, [_vp]),
+    ("dbgk_shard_outgoing", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("dbgk_shard_overflow", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("dbgk_shard_merge", _i, [_vp, _vp, _u64, _i, _i]),
+    ("dbgk_add_polyA", _i, [_vp, C.c_uint32, C.c_uint32]),
+    ("dbgk_memcpy_d2d", _i, [_vp, _vp, _vp, C.c_size_t]),
     ("dbgk_synth_reads_device", _i, [_vp, C.POINTER(SynthParams), _u64, _u64, _vp, _vp]),
     ("dbgk_device_malloc", _i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("dbgk_device_free", _i, [_vp, _vp]),
@@ -154,9 +169,10 @@ class Graph:
     """One GPU-resident k-mer graph under construction (thin wrapper over a dbgk_handle)."""
 
     def __init__(self, k, table_slots, max_read_len=250, device=0, engine=ENGINE_AUTO, max_batch_bases=0,
-                 expected_kmers=0):
+                 expected_kmers=0, shard_count=0, shard_index=0):
         self._h = None
-        cfg = Config(k, max_read_len, table_slots, device, engine, max_batch_bases, expected_kmers)
+        cfg = Config(k, max_read_len, table_slots, device, engine, max_batch_bases, expected_kmers,
+                     shard_count, shard_index)
         h = C.c_void_p()
         _chk(lib().dbgk_create(C.byref(cfg), C.byref(h)), "dbgk_create")
         self._h = h
@@ -263,6 +279,34 @@ class Graph:
         _chk(lib().dbgk_refresh_stats(self._h, C.byref(st)), "dbgk_refresh_stats")
         self.stats = st
         return st
+
+    # ---- sharded table (slot-range ownership)
+    def shard_info(self):
+        info = ShardInfo()
+        _chk(lib().dbgk_shard_buffers(self._h, C.byref(info)), "dbgk_shard_buffers")
+        return info
+
+    def shard_mark_exchanged(self):
+        _chk(lib().dbgk_shard_mark_exchanged(self._h), "dbgk_shard_mark_exchanged")
+
+    def shard_outgoing(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().dbgk_shard_outgoing(self._h, C.byref(p), C.byref(n)), "dbgk_shard_outgoing")
+        return p.value, n.value
+
+    def shard_overflow(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().dbgk_shard_overflow(self._h, C.byref(p), C.byref(n)), "dbgk_shard_overflow")
+        return p.value, n.value
+
+    def shard_merge(self, d_nodes, n, is_triple=False, from_previous_shard=False):
+        _chk(lib().dbgk_shard_merge(self._h, d_nodes, n, int(is_triple), int(from_previous_shard)), "dbgk_shard_merge")
+
+    def add_polyA(self, l_link, r_link):
+        _chk(lib().dbgk_add_polyA(self._h, l_link, r_link), "dbgk_add_polyA")
+
+    def memcpy_d2d(self, dst, src, nbytes):
+        _chk(lib().dbgk_memcpy_d2d(self._h, dst, src, nbytes), "dbgk_memcpy_d2d")
 
     # ---- utilities
     def malloc(self, nbytes):

@@ -74,7 +74,8 @@ struct dbgk_handle {
 	hipStream_t stream = nullptr;
 
 	Node *table = nullptr;
-	uint64_t size = 0;
+	uint64_t size = 0;            // hash modulus: slot = hash_code(key) % size (the GLOBAL table when sharded)
+	uint64_t tslots = 0;          // slots held by `table` (== size unless sharded)
 	ModMagic magic;
 
 	Counters *d_ctr = nullptr;
@@ -98,7 +99,12 @@ struct dbgk_handle {
 	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
 	PartGeom geom;
 	PartStore store;
-	uint32_t *tile_prefix = nullptr; // [n1 + 1] level-2 tile plan
+	uint32_t *tile_prefix = nullptr; // [n_ranks * B + 1] level-2 tile plan
+	// sharding: the handle owns slots [geom.slot_lo, geom.slot_hi) of a GLOBAL table of `size` slots
+	bool sharded = false;         // shard_count > 1
+	bool exchanged = false;       // the caller has filled the inbox (all-to-all) for this step
+	uint64_t *inbox = nullptr;    // [n_ranks][B][cap1]
+	uint32_t *inbox_cnt = nullptr;
 
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
@@ -211,6 +217,10 @@ static void free_handle(dbgk_handle *h)
 		                (void *)h->store.spill, (void *)h->store.ovf_n})
 			if (p) (void)hipFree(p);
 		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
+		if (h->inbox) (void)hipFree(h->inbox);
+		if (h->inbox_cnt) (void)hipFree(h->inbox_cnt);
+		if (h->store.outgoing) (void)hipFree(h->store.outgoing);
+		if (h->store.outgoing_n) (void)hipFree(h->store.outgoing_n);
 	}
 	if (h->table) (void)hipFree(h->table);
 	if (h->d_ctr) (void)hipFree(h->d_ctr);
@@ -221,7 +231,7 @@ static void free_handle(dbgk_handle *h)
 
 static int zero_table_now(dbgk_handle *h)
 {
-	HIPCHK(hipMemsetAsync(h->table, 0, h->size * sizeof(Node), h->stream)); // memset_parallel, kmerSet.cpp:358-386
+	HIPCHK(hipMemsetAsync(h->table, 0, h->tslots * sizeof(Node), h->stream)); // memset_parallel, kmerSet.cpp:358-386
 	h->zero_pending = false;
 	return DBGK_OK;
 }
@@ -233,9 +243,11 @@ static int reset_state(dbgk_handle *h)
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
 		h->part_built = false;
-		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n1 * 4, h->stream));
-		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.n1 * h->geom.n2 * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
+		h->exchanged = false;
 	} else {
 		int rc = zero_table_now(h);
 		if (rc) return rc;
@@ -251,23 +263,30 @@ static int reset_state(dbgk_handle *h)
 //   geometry: level-1 bucket = slot >> r, r >= 20 chosen so that n1 = ceil(size / 2^r) <= 1024;
 //   final bucket = slot >> 12 (one 4096-slot region); n2 = 2^(r-12) sub-buckets per level-1 bucket.
 //   An 8-byte record must hold q = hash / size, r slot bits and 6 neighbour bits.
-static int setup_partition(dbgk_handle *h)
+static int plan_partition(dbgk_handle *h)
 {
 	h->part = false;
+	h->sharded = false;
 	memset(&h->store, 0, sizeof h->store);
 	memset(&h->geom, 0, sizeof h->geom);
+	h->tslots = h->size;
+	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
 	const int want = h->cfg.engine;
-	if (want == DBGK_ENGINE_DIRECT) return DBGK_OK;
-	if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
+	const bool want_shard = h->cfg.shard_count >= 1; // shard_count == 1: one-rank sharded handle (same protocol, for testing)
+	if (want_shard && h->cfg.shard_index >= n_ranks) return DBGK_ERR_ARG;
+	if (!want_shard) {
+		if (want == DBGK_ENGINE_DIRECT) return DBGK_OK;
+		if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
+	}
 	uint32_t r = 20;
 	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kMaxBuckets) r++;
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
-	const bool feasible = (r - kRegionBits) <= 10 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26);
-	if (!feasible) {
-		if (want == DBGK_ENGINE_PARTITION) {
-			g_last_error = "PARTITION engine needs 2^26 <= table_slots < 2^32";
+	const bool feasible = (r - kRegionBits) <= 10 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26) && h->size < (1ull << 32);
+	if (!feasible || (want_shard && want == DBGK_ENGINE_DIRECT)) {
+		if (want == DBGK_ENGINE_PARTITION || want_shard) {
+			g_last_error = "PARTITION engine (and any sharded handle) needs 2^26 <= table_slots < 2^32";
 			return DBGK_ERR_ARG;
 		}
 		return DBGK_OK;
@@ -286,29 +305,60 @@ static int setup_partition(dbgk_handle *h)
 	G.n1 = (uint32_t)((h->size + (1ull << r) - 1) >> r);
 	G.n2 = 1u << (r - kRegionBits);
 	G.n_final = (uint32_t)((h->size + kRegionSlots - 1) >> kRegionBits);
-	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2;
+	G.n_ranks = n_ranks;
+	G.rank = want_shard ? h->cfg.shard_index : 0;
+	G.B = (G.n1 + n_ranks - 1) / n_ranks;
+	G.b_lo = std::min(G.rank * G.B, G.n1);
+	G.nb_own = std::min(G.B, G.n1 - G.b_lo);
+	G.slot_lo = (uint64_t)G.b_lo << r;
+	G.slot_hi = std::min<uint64_t>(h->size, ((uint64_t)G.b_lo + G.nb_own) << r);
+	G.n_regions_own = (uint32_t)((G.slot_hi - G.slot_lo + kRegionSlots - 1) >> kRegionBits);
+	if (G.nb_own == 0 || (uint64_t)n_ranks * G.B > (uint64_t)kMaxInboxEntries) {
+		g_last_error = "shard_count too large for this table size";
+		return DBGK_ERR_ARG;
+	}
+	// expected_kmers = occurrences THIS handle extracts; a region receives the global density
+	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2 / n_ranks;
 	const double per_slot = (double)expected / (double)h->size;
 	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05) + 65536;
-	G.cap2 = (uint64_t)(per_slot * (double)kRegionSlots * 1.15) + 512;
+	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
+	h->tslots = G.slot_hi - G.slot_lo;
+	h->sharded = want_shard;
+	h->part = true;
+	return DBGK_OK;
+}
+
+// allocate the record stores of the PARTITION engine (geometry already planned)
+static int setup_partition(dbgk_handle *h)
+{
+	if (!h->part) return DBGK_OK;
+	const PartGeom &G = h->geom;
 	PartStore &P = h->store;
+	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2 / G.n_ranks;
 	P.ovf_cap = expected / 64 + (1ull << 20);
-	P.spill_cap = (uint64_t)G.n_final * 8 + (1ull << 16);
-	const size_t l1_bytes = (size_t)G.n1 * G.cap1 * 8, l2_bytes = (size_t)G.n1 * G.n2 * G.cap2 * 8;
-	if (hipMalloc(&P.l1, l1_bytes) != hipSuccess || hipMalloc(&P.l2, l2_bytes) != hipSuccess ||
-	    hipMalloc(&P.cnt1, (size_t)G.n1 * 4) != hipSuccess || hipMalloc(&P.cnt2, (size_t)G.n1 * G.n2 * 4) != hipSuccess ||
-	    hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) != hipSuccess || hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) != hipSuccess ||
-	    hipMalloc(&P.ovf_n, 16) != hipSuccess || hipMalloc(&h->tile_prefix, (kMaxBuckets + 1) * 4) != hipSuccess) {
+	P.spill_cap = (uint64_t)G.n_regions_own * 8 + (1ull << 16);
+	P.outgoing_cap = 1ull << 16;
+	const size_t n_entries = (size_t)G.n_ranks * G.B;
+	const size_t l1_bytes = n_entries * G.cap1 * 8, l2_bytes = (size_t)G.nb_own * G.n2 * G.cap2 * 8;
+	bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
+	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
+	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) == hipSuccess &&
+	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->tile_prefix, (n_entries + 1) * 4) == hipSuccess &&
+	          hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.outgoing_n, 8) == hipSuccess;
+	if (ok && h->sharded)
+		ok = hipMalloc(&h->inbox, l1_bytes) == hipSuccess && hipMalloc(&h->inbox_cnt, n_entries * 4) == hipSuccess;
+	if (!ok) {
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
-		h->part = true; // so that free_handle releases what was allocated
 		return DBGK_ERR_NOMEM;
 	}
+	P.inbox = h->sharded ? h->inbox : P.l1;
+	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	h->part = true;
 	return DBGK_OK;
 }
 
@@ -336,6 +386,13 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->device = cfg->device_id;
 	h->size = cfg->table_slots;
 	h->magic = make_mod_magic(h->size);
+	{
+		const int prc = plan_partition(h); // geometry first: a sharded handle holds only its slot range
+		if (prc != DBGK_OK) {
+			delete h;
+			return prc;
+		}
+	}
 
 	auto fail = [&](int rc) {
 		free_handle(h);
@@ -352,7 +409,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->grid = h->n_cu * 8; // 8 x 256-thread blocks per CU = 32 waves/CU, the residency limit
 
 	if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DBGK_ERR_HIP);
-	if (hipMalloc(&h->table, h->size * sizeof(Node)) != hipSuccess) {
+	if (hipMalloc(&h->table, h->tslots * sizeof(Node)) != hipSuccess) {
 		g_last_error = "hipMalloc of the k-mer table failed";
 		return fail(DBGK_ERR_NOMEM);
 	}
@@ -409,6 +466,10 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 	rc = dbgk_sync(h);
 	if (rc) return rc;
 	if (new_slots == h->size) return DBGK_OK;
+	if (h->part) {
+		g_last_error = "dbgk_resize_table: the PARTITION engine's geometry is fixed at create";
+		return DBGK_ERR_STATE;
+	}
 	Node *fresh = nullptr;
 	if (hipMalloc(&fresh, new_slots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
 	TableRef dst{fresh, new_slots, make_mod_magic(new_slots)};
@@ -432,6 +493,7 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 	(void)hipFree(h->table);
 	h->table = fresh;
 	h->size = new_slots;
+	h->tslots = new_slots;
 	h->magic = dst.magic;
 	h->cfg.table_slots = new_slots;
 	return DBGK_OK;
@@ -581,9 +643,10 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 	out->total_reads = h->total_reads;
 	out->total_kmers = c.total_kmers;
 	out->stored_kmers = c.stored_kmers;
-	out->count = c.n_new + 1; // + the key-0 node, always present (DBGgraph.cpp:418)
+	// + the key-0 node, always present (DBGgraph.cpp:418); of a sharded table only shard 0 reports it
+	out->count = c.n_new + ((h->sharded && h->geom.rank != 0) ? 0 : 1);
 	out->count_conflict = c.n_conflict;
-	out->table_slots = h->size;
+	out->table_slots = h->tslots;
 	out->polyA_l_link = (uint32_t)(c.polyA_links & 0xFFFFFFFFu);
 	out->polyA_r_link = (uint32_t)(c.polyA_links >> 32);
 }
@@ -602,17 +665,24 @@ static int build_from_records(dbgk_handle *h)
 	if (rc) return rc;
 	rc = span_begin(h, PH_BUILD, sp);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_build_regions, dim3(G.n_final), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	hipLaunchKernelGGL(k_build_regions, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
-	                   h->tref(), h->d_ctr);
-	hipLaunchKernelGGL(k_insert_triples, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap,
-	                   h->tref(), h->d_ctr);
+	if (!h->sharded) {
+		hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
+		                   h->tref(), h->d_ctr);
+		hipLaunchKernelGGL(k_insert_triples, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap,
+		                   h->tref(), h->d_ctr);
+	} else {
+		// spill nodes of this shard's regions stay in the shard unless they run off its end (-> outgoing);
+		// overflow triples may belong to any shard: the caller exchanges them (dbgk_shard_overflow)
+		hipLaunchKernelGGL(k_merge_sharded, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], (uint64_t)0,
+		                   h->store.spill_cap, 0, 0, G, h->store, h->table, h->d_ctr);
+	}
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	h->part_built = true;
@@ -625,6 +695,10 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (h->part && !h->part_built && !h->finalized) {
+		if (h->sharded && !h->exchanged) {
+			g_last_error = "sharded handle: exchange the level-1 buckets (dbgk_shard_buffers) and call dbgk_shard_mark_exchanged first";
+			return DBGK_ERR_STATE;
+		}
 		rc = build_from_records(h);
 		if (rc) return rc;
 	}
@@ -634,7 +708,7 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 	if (out) fill_stats(h, out);
 	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
 	if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY; // PARTITION overflow stores exhausted (expected_kmers too small)
-	if (h->h_ctr->n_new + 1 > h->size) return DBGK_ERR_TABLE_FULL; // no free slot left for the key-0 node
+	if (h->h_ctr->n_new + 1 > h->tslots) return DBGK_ERR_TABLE_FULL; // no free slot left for the key-0 node
 	return DBGK_OK;
 }
 
@@ -675,6 +749,20 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 	if (!h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
+	if (h->sharded) { // the shard's slice of the global table: slots [slot_lo, slot_hi), key-0 node not placed
+		if (host_size != h->tslots) return DBGK_ERR_ARG;
+		uint8_t *d_fl = nullptr;
+		if (hipMalloc(&d_fl, host_size / 8 + 1) != hipSuccess) return DBGK_ERR_NOMEM;
+		hipLaunchKernelGGL(k_build_flags_ctr, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, h->table, h->tslots,
+		                   h->d_ctr, d_fl);
+		hipError_t es = hipGetLastError();
+		if (es == hipSuccess) es = hipMemcpyAsync(array, h->table, host_size * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
+		if (es == hipSuccess) es = hipMemcpyAsync(nul_flag, d_fl, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+		if (es == hipSuccess) es = hipStreamSynchronize(h->stream);
+		(void)hipFree(d_fl);
+		if (es != hipSuccess) return hip_fail(es, "export_host_table(shard)", __LINE__);
+		return DBGK_OK;
+	}
 	if (h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
 
 	TableRef T = h->tref();
@@ -715,12 +803,14 @@ extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capac
 	int rc = use_device(h);
 	if (rc) return rc;
 	const uint64_t n = h->h_ctr->n_new; // non-zero keys
-	*n_out = n + 1;
-	if (capacity < n + 1) return DBGK_ERR_CAPACITY;
-	// key 0 sorts first
-	out[0].kmer = 0;
-	out[0].l_link = (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu);
-	out[0].r_link = (uint32_t)(h->h_ctr->polyA_links >> 32);
+	const uint64_t z = (h->sharded && h->geom.rank != 0) ? 0 : 1; // the key-0 node is reported by shard 0 only
+	*n_out = n + z;
+	if (capacity < n + z) return DBGK_ERR_CAPACITY;
+	if (z) { // key 0 sorts first
+		out[0].kmer = 0;
+		out[0].l_link = (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu);
+		out[0].r_link = (uint32_t)(h->h_ctr->polyA_links >> 32);
+	}
 	if (n == 0) return DBGK_OK;
 
 	uint64_t *d_keys = nullptr, *d_links = nullptr;
@@ -737,7 +827,7 @@ extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capac
 	}
 	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_compact, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, d_keys, d_links,
+		hipLaunchKernelGGL(k_compact, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_keys, d_links,
 		                   d_cursor, n);
 		e = hipGetLastError();
 	}
@@ -759,9 +849,9 @@ extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capac
 	cleanup();
 	if (e != hipSuccess) return hip_fail(e, "export_sorted/copy", __LINE__);
 	for (uint64_t i = 0; i < n; i++) {
-		out[i + 1].kmer = hk[i];
-		out[i + 1].l_link = (uint32_t)(hl[i] & 0xFFFFFFFFu);
-		out[i + 1].r_link = (uint32_t)(hl[i] >> 32);
+		out[i + z].kmer = hk[i];
+		out[i + z].l_link = (uint32_t)(hl[i] & 0xFFFFFFFFu);
+		out[i + z].r_link = (uint32_t)(hl[i] >> 32);
 	}
 	return DBGK_OK;
 }
@@ -777,14 +867,14 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 	unsigned long long res[2] = {0, 0};
 	hipError_t e = hipMemsetAsync(d_out, 0, 16, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, d_out);
+		hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, 16, hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	(void)hipFree(d_out);
 	if (e != hipSuccess) return hip_fail(e, "digest", __LINE__);
-	*digest = res[0] + node_digest(0ull, h->h_ctr->polyA_links);
+	*digest = res[0] + ((h->sharded && h->geom.rank != 0) ? 0ull : node_digest(0ull, h->h_ctr->polyA_links));
 	return DBGK_OK;
 }
 
@@ -800,8 +890,8 @@ extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_
 	unsigned long long res[261];
 	hipError_t e = hipMemsetAsync(d_out, 0, bytes, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, (int)cutoff,
-		                   (uint64_t)h->h_ctr->polyA_links, d_out);
+		hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, (int)cutoff,
+		                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->geom.rank != 0) ? 0 : 1, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, bytes, hipMemcpyDeviceToHost, h->stream);
@@ -879,14 +969,14 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
 extern "C" int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts)
 {
 	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
-	if (!h->finalized) return DBGK_ERR_STATE;
+	if (!h->finalized || h->sharded) return DBGK_ERR_STATE; // a sharded table is already owned by slot range
 	int rc = use_device(h);
 	if (rc) return rc;
 	unsigned long long *d_counts = nullptr;
 	if (hipMalloc(&d_counts, n_parts * 8) != hipSuccess) return DBGK_ERR_NOMEM;
 	hipError_t e = hipMemsetAsync(d_counts, 0, n_parts * 8, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_partition_count, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, n_parts,
+		hipLaunchKernelGGL(k_partition_count, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, n_parts,
 		                   d_counts);
 		e = hipGetLastError();
 	}
@@ -909,7 +999,7 @@ __global__ void k_write_polyA_node(Node *out, uint64_t index, const Counters *ct
 extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity)
 {
 	if (!h || !d_nodes || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
-	if (!h->finalized) return DBGK_ERR_STATE;
+	if (!h->finalized || h->sharded) return DBGK_ERR_STATE;
 	std::vector<uint64_t> counts(n_parts);
 	int rc = dbgk_partition_counts(h, n_parts, counts.data());
 	if (rc) return rc;
@@ -926,7 +1016,7 @@ extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_write_polyA_node, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<Node *>(d_nodes), (uint64_t)0,
 		                   h->d_ctr);
-		hipLaunchKernelGGL(k_partition_scatter, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, n_parts,
+		hipLaunchKernelGGL(k_partition_scatter, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, n_parts,
 		                   d_cursors, reinterpret_cast<Node *>(d_nodes), capacity);
 		e = hipGetLastError();
 	}
@@ -940,6 +1030,7 @@ extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64
 {
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
 	if ((uintptr_t)d_nodes & 15u) return DBGK_ERR_ARG;
+	if (h->sharded) return DBGK_ERR_STATE; // use dbgk_shard_merge
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (n == 0) return DBGK_OK;
@@ -966,6 +1057,114 @@ extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_han
 	rc = use_device(dst);
 	if (rc) return rc;
 	HIPCHK(hipMemcpyPeer(d_dst, dst->device, d_src, src->device, n * sizeof(dbgk_node)));
+	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sharded tables (one handle per GPU, each owning a contiguous slot range of one global table)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
+{
+	if (!h || !out) return DBGK_ERR_ARG;
+	if (!h->part) return DBGK_ERR_STATE;
+	const PartGeom &G = h->geom;
+	memset(out, 0, sizeof(*out));
+	out->n_ranks = G.n_ranks;
+	out->rank = G.rank;
+	out->slot_lo = G.slot_lo;
+	out->slot_hi = G.slot_hi;
+	out->table_slots_global = h->size;
+	out->chunk_bytes = (uint64_t)G.B * G.cap1 * 8;
+	out->cnt_chunk_bytes = (uint64_t)G.B * 4;
+	out->d_send = h->store.l1;
+	out->d_send_cnt = h->store.cnt1;
+	out->d_recv = h->sharded ? (void *)h->inbox : (void *)h->store.l1;
+	out->d_recv_cnt = h->sharded ? (void *)h->inbox_cnt : (void *)h->store.cnt1;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_shard_mark_exchanged(dbgk_handle *h)
+{
+	if (!h || !h->sharded) return DBGK_ERR_STATE;
+	h->exchanged = true;
+	return DBGK_OK;
+}
+
+static int shard_list(dbgk_handle *h, Node *list, unsigned long long *d_n, uint64_t cap, dbgk_node **d_nodes, uint64_t *n)
+{
+	if (!h || !d_nodes || !n) return DBGK_ERR_ARG;
+	if (!h->part || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	*d_nodes = reinterpret_cast<dbgk_node *>(list);
+	*n = v < cap ? v : cap;
+	return v > cap ? DBGK_ERR_CAPACITY : DBGK_OK;
+}
+
+extern "C" int dbgk_shard_outgoing(dbgk_handle *h, dbgk_node **d_nodes, uint64_t *n)
+{
+	if (!h) return DBGK_ERR_ARG;
+	return shard_list(h, h->store.outgoing, h->store.outgoing_n, h->store.outgoing_cap, d_nodes, n);
+}
+
+extern "C" int dbgk_shard_overflow(dbgk_handle *h, dbgk_node **d_triples, uint64_t *n)
+{
+	if (!h) return DBGK_ERR_ARG;
+	return shard_list(h, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, d_triples, n);
+}
+
+extern "C" int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n, int is_triple, int from_previous_shard)
+{
+	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
+	if (!h->sharded || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n == 0) return DBGK_OK;
+	TimedSpan sp;
+	rc = span_begin(h, PH_FIXUP, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_merge_sharded, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, reinterpret_cast<const Node *>(d_nodes),
+	                   (const unsigned long long *)nullptr, n, n, is_triple ? 1 : 0, from_previous_shard ? 1 : 0, h->geom, h->store, h->table,
+	                   h->d_ctr);
+	HIPCHK(hipGetLastError());
+	return span_end(h, sp);
+}
+
+extern "C" int dbgk_add_polyA(dbgk_handle *h, uint32_t l_link, uint32_t r_link)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	Node nd;
+	nd.kmer = 0;
+	nd.links = (uint64_t)l_link | ((uint64_t)r_link << 32);
+	Node *d = nullptr;
+	if (hipMalloc(&d, sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	hipError_t e = hipMemcpyAsync(d, &nd, sizeof(Node), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		if (h->sharded)
+			hipLaunchKernelGGL(k_merge_sharded, dim3(1), dim3(kBlock), 0, h->stream, d, (const unsigned long long *)nullptr, (uint64_t)1, (uint64_t)1, 0,
+			                   0, h->geom, h->store, h->table, h->d_ctr);
+		else
+			hipLaunchKernelGGL(k_merge_nodes, dim3(1), dim3(kBlock), 0, h->stream, d, (uint64_t)1, h->tref(), h->d_ctr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d);
+	if (e != hipSuccess) return hip_fail(e, "add_polyA", __LINE__);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_memcpy_d2d(dbgk_handle *h, void *d_dst, const void *d_src, size_t bytes)
+{
+	if (!h) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
 	return DBGK_OK;
 }
 

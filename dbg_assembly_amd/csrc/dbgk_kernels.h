@@ -570,7 +570,7 @@ __device__ __forceinline__ void link_classes(uint64_t links, int cutoff, unsigne
 }
 
 __global__ __launch_bounds__(kBlock) void k_link_stats(const Node *__restrict__ nodes, uint64_t size, int cutoff,
-                                                       uint64_t polyA_links, unsigned long long *__restrict__ out)
+                                                       uint64_t polyA_links, int with_polyA, unsigned long long *__restrict__ out)
 {
 	__shared__ unsigned int hist[256];
 	__shared__ unsigned long long red[kBlock / 64];
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_link_stats(const Node *__restrict__ 
 		const uint64_t key = ((uint64_t)v.y << 32) | v.x;
 		if (key != 0ull) link_classes(((uint64_t)v.w << 32) | v.z, cutoff, hist, cls);
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) link_classes(polyA_links, cutoff, hist, cls); // the key-0 node
+	if (with_polyA && blockIdx.x == 0 && threadIdx.x == 0) link_classes(polyA_links, cutoff, hist, cls); // the key-0 node
 	__syncthreads();
 	if (hist[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 #pragma unroll

@@ -69,13 +69,26 @@ struct PartGeom {
 	uint64_t cap1;       // records per level-1 bucket
 	uint64_t cap2;       // records per final bucket
 	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h)
+	// sharding (multi-GPU): `size` is the GLOBAL table; this handle owns the level-1 buckets
+	// [b_lo, b_lo + nb_own) = the contiguous slot range [slot_lo, slot_hi) and holds only that
+	// part of the table.  n_ranks == 1: b_lo = 0, nb_own = n1, the whole table.
+	uint32_t n_ranks, rank;
+	uint32_t B;          // level-1 buckets per rank = ceil(n1 / n_ranks); the level-1 store has n_ranks * B buckets
+	uint32_t b_lo, nb_own;
+	uint32_t n_regions_own;
+	uint64_t slot_lo, slot_hi;
 };
 
 struct PartStore {
-	uint64_t *l1;                 // [n1 * cap1]
-	uint64_t *l2;                 // [n_final_padded * cap2], final bucket f = slot >> 12
-	uint32_t *cnt1;               // [n1]       records appended (may exceed cap1: excess went to ovf)
-	uint32_t *cnt2;               // [n1 * n2]
+	uint64_t *l1;                 // [n_ranks * B][cap1]: what this rank extracted, by GLOBAL level-1 bucket
+	uint32_t *cnt1;               // [n_ranks * B] records appended (may exceed cap1: excess went to ovf)
+	const uint64_t *inbox;        // [n_ranks][B][cap1]: level-1 buckets of MY slot range from every rank
+	const uint32_t *inbox_cnt;    // [n_ranks * B]      (n_ranks == 1: inbox == l1, inbox_cnt == cnt1)
+	uint64_t *l2;                 // [nb_own * n2][cap2], local final bucket = (b1 - b_lo) * n2 + b2
+	uint32_t *cnt2;               // [nb_own * n2]
+	Node *outgoing;               // nodes that probed past the end of this shard: for the next rank
+	unsigned long long *outgoing_n;
+	uint64_t outgoing_cap;
 	Node *ovf;                    // overflow triples {key, lb | rb << 8}
 	Node *spill;                  // nodes that probed past the end of their region
 	unsigned long long *ovf_n;    // [0] = overflow triples, [1] = spill nodes
@@ -443,28 +456,42 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 }
 
 // ---- level 2: split every level-1 bucket into its n2 final buckets -----------------------------
-// k_plan_l2 (one workgroup): tile_prefix[b1] = number of 16384-record tiles in buckets < b1.
+// Inbox entry e = (source rank s = e / B, own bucket j = e % B): one level-1 bucket of this
+// shard's slot range as extracted by rank s.  k_plan_l2: tile_prefix[e] = number of 16384-record
+// tiles in entries < e (entries with j >= nb_own are empty).  One workgroup, entries strided.
+constexpr int kMaxInboxEntries = 8192; // n_ranks * B <= n1 + n_ranks
+
 __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P, uint32_t *__restrict__ tile_prefix)
 {
 	__shared__ uint32_t tot[kMaxBuckets / 64];
+	__shared__ uint32_t carry;
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	uint32_t v = 0;
-	if ((uint32_t)t < G.n1) {
-		const uint64_t filled = P.cnt1[t] < G.cap1 ? P.cnt1[t] : G.cap1;
-		v = (uint32_t)((filled + kTileRecords - 1) / kTileRecords);
-	}
-	uint32_t inc = v;
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t n = __shfl_up(inc, off, 64);
-		if (lane >= off) inc += n;
-	}
-	if (lane == 63) tot[wave] = inc;
+	const uint32_t n_entries = G.n_ranks * G.B;
+	if (t == 0) carry = 0;
 	__syncthreads();
-	uint32_t before = 0;
-	for (int w = 0; w < wave; w++) before += tot[w];
-	if ((uint32_t)t < G.n1) tile_prefix[t] = before + inc - v;
-	if ((uint32_t)t == G.n1 - 1) tile_prefix[G.n1] = before + inc;
+	for (uint32_t base = 0; base < n_entries; base += kMaxBuckets) {
+		const uint32_t e = base + (uint32_t)t;
+		uint32_t v = 0;
+		if (e < n_entries && (e % G.B) < G.nb_own) {
+			const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
+			v = (uint32_t)((filled + kTileRecords - 1) / kTileRecords);
+		}
+		uint32_t inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t n = __shfl_up(inc, off, 64);
+			if (lane >= off) inc += n;
+		}
+		if (lane == 63) tot[wave] = inc;
+		__syncthreads();
+		uint32_t before = carry;
+		for (int w = 0; w < wave; w++) before += tot[w];
+		if (e < n_entries) tile_prefix[e] = before + inc - v;
+		__syncthreads();
+		if (t == kMaxBuckets - 1) carry = before + inc;
+		__syncthreads();
+	}
+	if (t == 0) tile_prefix[n_entries] = carry;
 }
 
 // Persistent workgroups (one per CU) walk the flattened tile list; the records of tile i+1 are
@@ -477,16 +504,16 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 #pragma unroll
 	for (int u = 0; u < 16; u++) rec[u] = ~0ull;
 	if (g >= n_tiles) return;
-	uint32_t lo = 0, hi = G.n1; // last b1 with tile_prefix[b1] <= g
+	uint32_t lo = 0, hi = G.n_ranks * G.B; // last entry with tile_prefix[e] <= g (empty entries repeat the prefix: take the last)
 	while (hi - lo > 1) {
 		const uint32_t mid = (lo + hi) >> 1;
 		if (tile_prefix[mid] <= g) lo = mid; else hi = mid;
 	}
-	const uint32_t b1 = lo;
-	b1_out = b1;
-	const uint64_t filled = P.cnt1[b1] < G.cap1 ? P.cnt1[b1] : G.cap1;
-	const uint64_t first = (uint64_t)(g - tile_prefix[b1]) * kTileRecords;
-	const uint64_t *in = P.l1 + (uint64_t)b1 * G.cap1;
+	const uint32_t e = lo;
+	b1_out = e % G.B; // own bucket index j
+	const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
+	const uint64_t first = (uint64_t)(g - tile_prefix[e]) * kTileRecords;
+	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 #pragma unroll
 	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
 		const uint64_t i = first + (uint64_t)u * kTileThreads + threadIdx.x;
@@ -499,14 +526,14 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	ScatterLds &L = *reinterpret_cast<ScatterLds *>(lds_raw);
-	const uint32_t n_tiles = tile_prefix[G.n1];
+	const uint32_t n_tiles = tile_prefix[G.n_ranks * G.B];
 	uint64_t nxt[16];
-	uint32_t nxt_b1;
+	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
 	l2_load_tile(G, P, tile_prefix, blockIdx.x, n_tiles, nxt, nxt_b1);
 	for (uint32_t g = blockIdx.x; g < n_tiles; g += gridDim.x) {
 		uint64_t rec[16];
 		uint32_t bkt[16];
-		const uint32_t b1 = nxt_b1;
+		const uint32_t j = nxt_b1;
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
 			rec[u] = nxt[u];
@@ -514,7 +541,7 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
 		}
 		l2_load_tile(G, P, tile_prefix, g + gridDim.x, n_tiles, nxt, nxt_b1); // in flight during the scatter below
-		scatter_tile<16>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)b1 * G.n2, P.l2 + (uint64_t)b1 * G.n2 * G.cap2, G.cap2, b1, false, G, P, ctr);
+		scatter_tile<16>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
 	}
 }
 
@@ -535,10 +562,11 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	BuildLds &L = *reinterpret_cast<BuildLds *>(lds_raw);
-	const uint32_t f = blockIdx.x;                       // final bucket == region index == slot >> 12
-	const uint32_t b1 = f >> (G.r - kRegionBits);
-	const uint64_t region_base = (uint64_t)f << kRegionBits;
-	const uint32_t region_len = (uint32_t)((G.size - region_base < (uint64_t)kRegionSlots) ? G.size - region_base : kRegionSlots);
+	const uint32_t f = blockIdx.x;                       // LOCAL final bucket == local region index == (slot - slot_lo) >> 12
+	const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits));
+	const uint64_t region_base = (uint64_t)f << kRegionBits;   // index into this shard's table
+	const uint64_t region_slot0 = G.slot_lo + region_base;     // global slot of the region's first entry
+	const uint32_t region_len = (uint32_t)((G.size - region_slot0 < (uint64_t)kRegionSlots) ? G.size - region_slot0 : kRegionSlots);
 	const int t = threadIdx.x;
 	const uint64_t filled = P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2;
 	const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
@@ -690,6 +718,81 @@ __global__ __launch_bounds__(kBlock) void k_merge_spill(const Node *__restrict__
 		if (b) atomicAdd(&ctr->n_conflict, b);
 	}
 	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// ---- sharded tables (multi-GPU): probing confined to the shard's slot range -----------------------
+// Like find_or_claim (dbgk_kernels.h) but on the shard-local array and without wrap-around: returns
+// the local index, or ~0 when the probe reaches slot_hi (the node then belongs to the next shard).
+__device__ __forceinline__ uint64_t find_or_claim_range(Node *nodes, uint64_t slot_lo, uint64_t slot_hi, uint64_t key, uint64_t slot,
+                                                        uint64_t &links_guess, unsigned long long &n_new, unsigned long long &n_conf)
+{
+	for (; slot < slot_hi; slot++) {
+		const uint64_t idx = slot - slot_lo;
+		const uint4 v = *reinterpret_cast<const uint4 *>(&nodes[idx]);
+		uint64_t seen = ((uint64_t)v.y << 32) | v.x;
+		uint64_t links = ((uint64_t)v.w << 32) | v.z;
+		if (seen == 0ull) {
+			seen = atomicCAS(reinterpret_cast<unsigned long long *>(&nodes[idx].kmer), 0ull, (unsigned long long)key);
+			if (seen == 0ull) {
+				n_new++;
+				links_guess = 0ull;
+				return idx;
+			}
+			links = 0ull;
+		}
+		if (seen == key) {
+			links_guess = links;
+			return idx;
+		}
+		n_conf++;
+	}
+	return ~0ull;
+}
+
+// Merge nodes (is_triple == 0: {key, links}) or single observations (is_triple == 1: {key, lb | rb << 8})
+// into this shard.  A node whose home slot lies outside the shard is skipped unless start_foreign_at_lo
+// (nodes handed over by the previous shard continue their probe at this shard's first slot).  Nodes
+// whose probe runs off the end of the shard are appended to P.outgoing for the next rank.
+__global__ __launch_bounds__(kBlock) void k_merge_sharded(const Node *__restrict__ in, const unsigned long long *__restrict__ n_ptr,
+                                                          uint64_t n_direct, uint64_t cap, int is_triple, int start_foreign_at_lo,
+                                                          PartGeom G, PartStore P, Node *__restrict__ table, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	uint64_t n = n_ptr ? (uint64_t)*n_ptr : n_direct;
+	if (n > cap) n = cap;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+		const uint64_t key = in[i].kmer;
+		uint64_t add = in[i].links;
+		if (is_triple) add = links_observe(0ull, (uint32_t)add & 0xFFu, (uint32_t)(add >> 8) & 0xFFu);
+		if (key == 0ull) { // key-0 node of another shard: folded into this handle's side node
+			links_cas_merge(&ctr->polyA_links, 0ull, add);
+			continue;
+		}
+		const uint64_t home = fast_mod(hash_code(key), G.magic);
+		const bool mine = home >= G.slot_lo && home < G.slot_hi;
+		if (!mine && !start_foreign_at_lo) continue;
+		uint64_t guess;
+		const uint64_t idx = find_or_claim_range(table, G.slot_lo, G.slot_hi, key, mine ? home : G.slot_lo, guess, n_new, n_conf);
+		if (idx == ~0ull) {
+			const unsigned long long j = atomicAdd(P.outgoing_n, 1ull);
+			if (j < P.outgoing_cap) {
+				P.outgoing[j].kmer = key;
+				P.outgoing[j].links = add;
+			} else {
+				atomicOr(&ctr->error, 2u);
+			}
+			continue;
+		}
+		links_cas_merge(reinterpret_cast<unsigned long long *>(&table[idx].links), guess, add);
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
 }
 
 } // namespace dbgk

@@ -101,3 +101,112 @@ def exchange_and_merge(engine, group=None):
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]),
             "count": int(tot[3]) - (world - 1), "owned_count": int(owned.count),
             "sent_nodes": n_send, "recv_nodes": n_recv}
+
+
+# ==================================================================================================
+# Slot-range ownership (the scalable path; bench.py uses it for N > 1)
+# ==================================================================================================
+# exchange_and_merge above ships locally AGGREGATED nodes, which pays when every rank sees the whole
+# genome at high coverage.  With reads sharded by record, a rank's coverage is only 1/N of the job's,
+# local aggregation finds few duplicates and the per-rank table would have to hold nearly every
+# occurrence.  Here no local table exists at all: every rank level-1-partitions its k-mer records by
+# slot range of ONE global table (PARTITION engine), rank d owns the buckets [d*B, (d+1)*B), and
+#
+#   1. all-reduce (sum) of the per-bucket record counts  -> global bucket fills (capacity check),
+#   2. all-to-all of the bucket fill counts and of the level-1 bucket stores themselves: chunk d of
+#      every rank's store goes to rank d (zero-copy slices of the library's own buffers),
+#   3. each rank builds only its slot range (level-2 partition + LDS region build),
+#   4. hand-offs that are normally empty or tiny: nodes whose probe ran off the end of a shard go
+#      to the next rank (ring), bucket-overflow observations are offered to every rank,
+#   5. key-0 links gathered onto rank 0, scalar totals all-reduced.
+
+class _DevMem:
+    """zero-copy view of raw device memory for torch (CUDA array interface v2)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_memory(ptr, nbytes, device):
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+
+
+def sharded_finalize(g, device, group=None):
+    """g: a sharded capi.Graph (shard_count == world, shard_index == rank) that has received all its
+    pushes.  Performs steps 1-5 and returns the global totals; afterwards g's table holds this
+    rank's slot range of the global table."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    info = g.shard_info()
+    assert info.n_ranks == world and info.rank == rank, (info.n_ranks, info.rank, world, rank)
+    g.sync()
+    send = wrap_device_memory(info.d_send, world * info.chunk_bytes, device)
+    recv = wrap_device_memory(info.d_recv, world * info.chunk_bytes, device)
+    send_cnt = wrap_device_memory(info.d_send_cnt, world * info.cnt_chunk_bytes, device)
+    recv_cnt = wrap_device_memory(info.d_recv_cnt, world * info.cnt_chunk_bytes, device)
+
+    # 1. per-bucket k-mer counts of the whole job
+    bucket_counts = send_cnt.view(torch.int32).to(torch.int64)
+    dist.all_reduce(bucket_counts, op=dist.ReduceOp.SUM, group=group)
+    records_global = int(bucket_counts.sum().item())
+
+    # 2. the exchange
+    dist.all_to_all_single(recv_cnt, send_cnt, group=group)
+    dist.all_to_all_single(recv, send, group=group)
+    torch.cuda.current_stream().synchronize()
+    g.shard_mark_exchanged()
+
+    # 3. build this rank's slot range
+    st = g.finalize()
+    local = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers))
+
+    # 4. hand-offs
+    p_out, n_out = g.shard_outgoing()
+    p_ovf, n_ovf = g.shard_overflow()
+    sizes = torch.tensor([n_out, n_ovf], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    max_out, max_ovf = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    if max_ovf:
+        mine = torch.zeros(max_ovf * NODE_BYTES, dtype=torch.uint8, device=device)
+        if n_ovf:
+            mine[:n_ovf * NODE_BYTES] = wrap_device_memory(p_ovf, n_ovf * NODE_BYTES, device)
+        lists = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(lists, mine, group=group)
+        torch.cuda.current_stream().synchronize()
+        for src in range(world):
+            if all_sizes[src, 1]:
+                g.shard_merge(lists[src].data_ptr(), int(all_sizes[src, 1]), is_triple=True)
+        g.sync()
+    if max_out:
+        mine = torch.zeros(max_out * NODE_BYTES, dtype=torch.uint8, device=device)
+        if n_out:
+            mine[:n_out * NODE_BYTES] = wrap_device_memory(p_out, n_out * NODE_BYTES, device)
+        lists = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(lists, mine, group=group)
+        torch.cuda.current_stream().synchronize()
+        prev = (rank - 1) % world
+        if all_sizes[prev, 0]:
+            g.shard_merge(lists[prev].data_ptr(), int(all_sizes[prev, 0]), from_previous_shard=True)
+            g.sync()
+            _, n_again = g.shard_outgoing()
+            if n_again != n_out:
+                raise RuntimeError("a handed-over node left the next shard as well: shard (nearly) full")
+
+    # 5. key-0 node onto rank 0, totals
+    links = torch.tensor([int(st.polyA_l_link), int(st.polyA_r_link)], dtype=torch.int64, device=device)
+    all_links = [torch.zeros_like(links) for _ in range(world)]
+    dist.all_gather(all_links, links, group=group)
+    if rank == 0:
+        for src in range(1, world):
+            l, r = (int(x) for x in all_links[src].cpu().numpy())
+            if l or r:
+                g.add_polyA(l, r)
+    owned = g.refresh_stats()
+    tot = torch.tensor([local[0], local[1], local[2], int(owned.count)], dtype=torch.int64, device=device)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    tot = tot.cpu().numpy()
+    return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
+            "owned_count": int(owned.count), "records_global": records_global,
+            "handed_over_nodes": int(all_sizes[:, 0].sum()), "overflow_observations": int(all_sizes[:, 1].sum())}

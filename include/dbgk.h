@@ -63,9 +63,14 @@ typedef struct dbgk_config {
 	uint64_t max_batch_bases;  /* capacity of the internal staging buffers used by
 	                              dbgk_push_reads (host buffers); 0 = default (256 MiB)            */
 	uint64_t expected_kmers;   /* PARTITION engine: upper bound on k-mer occurrences that will be
-	                              pushed before finalize (sizes the record store); 0 = derive
-	                              from table_slots                                                */
-	uint64_t reserved[4];
+	                              pushed INTO THIS HANDLE before finalize (sizes the record store);
+	                              0 = derive from table_slots                                      */
+	uint32_t shard_count;      /* > 1: this handle is one of shard_count handles (one per GPU) that
+	                              together hold ONE table of table_slots slots, each a contiguous
+	                              slot range; 0 = unsharded (1 = a single shard that still follows
+	                              the exchange protocol, useful for testing it on one GPU)        */
+	uint32_t shard_index;      /* 0 .. shard_count-1                                               */
+	uint64_t reserved[3];
 } dbgk_config;
 
 /* totals after dbgk_finalize (the globals the reference prints, DBGgraph.cpp:410-411, and the
@@ -195,6 +200,42 @@ int dbgk_refresh_stats(dbgk_handle *h, dbgk_stats *out);
 /* single-process multi-GPU: copy n nodes from a device buffer of src's GPU into a device buffer
  * of dst's GPU (peer copy over xGMI), synchronous                                               */
 int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_handle *src, const dbgk_node *d_src, uint64_t n);
+
+/* ---- sharded table: reads shard by record, k-mers are owned by SLOT RANGE ---------------------
+ * With shard_count = N every handle extracts its own reads into level-1 buckets of the GLOBAL table
+ * (slot >> r); rank d owns the bucket range [d*B, (d+1)*B).  Between the pushes and dbgk_finalize
+ * the caller moves chunk d of every rank's send buffer to rank d (an all-to-all: RCCL
+ * ncclSend/ncclRecv, torch all_to_all_single, or peer copies), the bucket fill counts likewise,
+ * then calls dbgk_shard_mark_exchanged.  finalize builds only the handle's slot range; the few
+ * nodes whose probe runs off the end of a shard (dbgk_shard_outgoing) are handed to the next rank
+ * (dbgk_shard_merge(..., from_previous_shard = 1)), bucket-overflow records (dbgk_shard_overflow,
+ * normally none) are offered to every rank, which keeps its own.  Exact for the same reason the
+ * reference's per-thread ownership is (DBGgraph.cpp:148): a key has exactly one home slot.       */
+typedef struct dbgk_shard_info {
+	uint32_t n_ranks, rank;
+	uint64_t table_slots_global;
+	uint64_t slot_lo, slot_hi;     /* this handle's slot range                                     */
+	void    *d_send;               /* n_ranks chunks of chunk_bytes: chunk d goes to rank d        */
+	void    *d_recv;               /* n_ranks chunks of chunk_bytes: chunk s comes from rank s     */
+	uint64_t chunk_bytes;
+	void    *d_send_cnt;           /* n_ranks chunks of cnt_chunk_bytes (u32 fill counts)          */
+	void    *d_recv_cnt;
+	uint64_t cnt_chunk_bytes;
+} dbgk_shard_info;
+
+int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out);
+int dbgk_shard_mark_exchanged(dbgk_handle *h);
+/* after dbgk_finalize: device list of nodes that left this shard / of overflow observations
+ * {kmer, lb | rb << 8}; the lists stay valid until the next dbgk_reset                            */
+int dbgk_shard_outgoing(dbgk_handle *h, dbgk_node **d_nodes, uint64_t *n);
+int dbgk_shard_overflow(dbgk_handle *h, dbgk_node **d_triples, uint64_t *n);
+/* merge nodes (is_triple = 0) or observations (is_triple = 1) held in device memory of this GPU:
+ * entries whose home slot lies in another shard are ignored unless from_previous_shard is set,
+ * in which case they continue their probe at this shard's first slot                            */
+int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n, int is_triple, int from_previous_shard);
+/* fold another handle's key-0 node into this one (per-byte saturating add)                      */
+int dbgk_add_polyA(dbgk_handle *h, uint32_t l_link, uint32_t r_link);
+int dbgk_memcpy_d2d(dbgk_handle *h, void *d_dst, const void *d_src, size_t bytes);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
 

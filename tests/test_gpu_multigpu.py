@@ -52,3 +52,40 @@ def test_exchange_and_merge_single_rank_nccl(engine):
             d_off.free()
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_finalize_single_rank_nccl(oracle):
+    """slot-range ownership flow of bench.py (N > 1) with a one-rank shard: the all-to-all runs on
+    the library's own device buffers wrapped as torch tensors, the handed-over nodes wrap around to
+    the same shard; result == plain single-GPU build == oracle"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import sharded_finalize
+
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_reads, G = 100000, 500000
+        P, PO = capi.synth_params(G, 150, cfg=2), oracle.synth_params(G, 150, cfg=2)
+        bases, offsets = oracle.synth_reads(PO, 0, n_reads)
+        size = capi.find_next_prime_ref(70000000)
+        with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=n_reads * 150,
+                        shard_count=1, shard_index=0) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            for _ in range(2):  # two steps: the handle must be reusable (bench loop)
+                g.reset()
+                g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+                out = sharded_finalize(g, torch.device("cuda", 0))
+            nodes = g.export_sorted()
+            d_bases.free()
+            d_off.free()
+        ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.02)
+        assert (out["count"], out["total_kmers"], out["total_reads"]) == (ref.count, ref.total_kmers, ref.total_reads)
+        assert out["records_global"] == ref.total_kmers  # no key-0 k-mers in this input
+        assert np.array_equal(nodes, ref.nodes)
+    finally:
+        dist.destroy_process_group()

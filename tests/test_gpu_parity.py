@@ -336,3 +336,90 @@ def test_full_size_direct_vs_partition_digest(capi):
             d_bases.free()
             d_off.free()
     assert res[0] == res[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
+# device copies.  Validates slot-range ownership end to end on real hardware.
+# ------------------------------------------------------------------------------------------------
+def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slots=PART_SLOTS):
+    size = capi.find_next_prime_ref(slots)
+    graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected_per_shard,
+                         shard_count=n_shards, shard_index=i) for i in range(n_shards)]
+    try:
+        for i, g in enumerate(graphs):
+            g.push_reads(*oracle.pack_reads(reads[i::n_shards]))  # reads shard by record
+            g.sync()
+        infos = [g.shard_info() for g in graphs]
+        assert infos[0].slot_lo == 0 and infos[-1].slot_hi == size
+        for a, b in zip(infos[:-1], infos[1:]):
+            assert a.slot_hi == b.slot_lo
+        for s in range(n_shards):       # the all-to-all: chunk d of rank s -> slot s of rank d's inbox
+            for d in range(n_shards):
+                graphs[0].memcpy_d2d(infos[d].d_recv + s * infos[d].chunk_bytes, infos[s].d_send + d * infos[s].chunk_bytes,
+                                     infos[s].chunk_bytes)
+                graphs[0].memcpy_d2d(infos[d].d_recv_cnt + s * infos[d].cnt_chunk_bytes,
+                                     infos[s].d_send_cnt + d * infos[s].cnt_chunk_bytes, infos[s].cnt_chunk_bytes)
+        stats = []
+        for g in graphs:
+            g.shard_mark_exchanged()
+            stats.append(g.finalize())
+        ovf = [g.shard_overflow() for g in graphs]
+        out = [g.shard_outgoing() for g in graphs]
+        for (p, n) in ovf:              # overflow observations are offered to every shard, which keeps its own
+            for g in graphs:
+                if n:
+                    g.shard_merge(p, n, is_triple=True)
+        for s, (p, n) in enumerate(out):  # nodes that ran off the end of shard s continue in shard s+1
+            if n:
+                graphs[(s + 1) % n_shards].shard_merge(p, n, from_previous_shard=True)
+        for s in range(1, n_shards):    # key-0 node lives on shard 0
+            if stats[s].polyA_l_link or stats[s].polyA_r_link:
+                graphs[0].add_polyA(stats[s].polyA_l_link, stats[s].polyA_r_link)
+        final = [g.refresh_stats() for g in graphs]
+        for g, (p, n) in zip(graphs, out):
+            assert g.shard_outgoing()[1] == n  # nothing handed over twice
+        nodes = np.concatenate([g.export_sorted() for g in graphs])
+        tables = [g.export_host_table(g.stats.table_slots) for g in graphs]
+        return final, stats, nodes, infos, tables, (sum(n for _, n in ovf), sum(n for _, n in out)), size
+    finally:
+        for g in graphs:
+            g.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_sharded_table_equals_oracle(capi, oracle, n_shards):
+    rng = random.Random(31 + n_shards)
+    reads = rand_reads(rng, 4000, G=30000) + [b"A" * 150] * 300 + [b"T" * 99] * 50
+    rng.shuffle(reads)
+    final, stats, nodes, infos, tables, (n_ovf, n_out), size = _sharded_build(capi, oracle, reads, n_shards, 600000)
+    ref = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=31, init_hash_size=0.002)
+    assert sum(int(s.count) for s in final) == ref.count
+    assert sum(int(s.total_kmers) for s in stats) == ref.total_kmers
+    assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
+    # every shard holds exactly the keys whose home slot lies in its range (or was handed over from the shard before)
+    L = oracle.lib()
+    for info, (array, flags) in zip(infos, tables):
+        occ = np.flatnonzero(array["kmer"] != 0)
+        for i in occ[:300]:
+            home = L.orc_hash_code(int(array["kmer"][i])) % size
+            assert (info.slot_lo <= home < info.slot_hi and home <= info.slot_lo + i) or home >= infos[info.rank - 1].slot_lo
+    # concatenated shards form one valid linear-probing table of the global size (key-0 node aside)
+    whole = np.concatenate([t[0] for t in tables])
+    assert len(whole) == size
+    fl = np.packbits((whole["kmer"] != 0).astype(np.uint8))
+    fl = np.concatenate([fl, np.zeros(size // 8 + 1 - len(fl), np.uint8)])
+    assert oracle.check_host_table(whole, fl, size, ref.count - 1) == 0
+
+
+def test_sharded_table_with_overflow_and_heavy_repeats(capi, oracle):
+    """tiny bucket capacities force overflow observations; a heavily repeated read saturates counters
+    across shards"""
+    rng = random.Random(77)
+    reads = rand_reads(rng, 1500, G=6000) + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 2500
+    rng.shuffle(reads)
+    final, stats, nodes, infos, tables, (n_ovf, n_out), size = _sharded_build(capi, oracle, reads, 2, 1)
+    ref = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=31, init_hash_size=0.001)
+    assert n_ovf > 0
+    assert sum(int(s.count) for s in final) == ref.count
+    assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
