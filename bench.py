@@ -133,7 +133,7 @@ def main():
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
-                   expected_kmers=n_reads * 150 if args.engine == capi.ENGINE_PARTITION else 0,
+                   expected_kmers=n_reads * kpr if args.engine == capi.ENGINE_PARTITION else 0,  # exact for fixed-length reads
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     engine = HipEngine(g, device)

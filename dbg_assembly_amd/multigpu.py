@@ -131,10 +131,13 @@ def wrap_device_memory(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def sharded_finalize(g, device, group=None):
+def sharded_finalize(g, device, group=None, wrap=None):
     """g: a sharded capi.Graph (shard_count == world, shard_index == rank) that has received all its
     pushes.  Performs steps 1-5 and returns the global totals; afterwards g's table holds this
-    rank's slot range of the global table."""
+    rank's slot range of the global table.  `wrap(ptr, nbytes, device)` turns the library's buffers
+    into tensors (default: zero-copy CUDA array interface; the gloo CPU test passes a host wrapper)."""
+    wrap_device_memory = wrap or globals()["wrap_device_memory"]
+    on_gpu = torch.device(device).type == "cuda"
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     info = g.shard_info()
@@ -152,8 +155,9 @@ def sharded_finalize(g, device, group=None):
 
     # 2. the exchange
     dist.all_to_all_single(recv_cnt, send_cnt, group=group)
-    dist.all_to_all_single(recv, send, group=group)
-    torch.cuda.current_stream().synchronize()
+    dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=group)  # 8-byte records: counts stay < 2^31
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
     g.shard_mark_exchanged()
 
     # 3. build this rank's slot range
@@ -174,7 +178,8 @@ def sharded_finalize(g, device, group=None):
             mine[:n_ovf * NODE_BYTES] = wrap_device_memory(p_ovf, n_ovf * NODE_BYTES, device)
         lists = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(lists, mine, group=group)
-        torch.cuda.current_stream().synchronize()
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
         for src in range(world):
             if all_sizes[src, 1]:
                 g.shard_merge(lists[src].data_ptr(), int(all_sizes[src, 1]), is_triple=True)
@@ -185,7 +190,8 @@ def sharded_finalize(g, device, group=None):
             mine[:n_out * NODE_BYTES] = wrap_device_memory(p_out, n_out * NODE_BYTES, device)
         lists = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(lists, mine, group=group)
-        torch.cuda.current_stream().synchronize()
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
         prev = (rank - 1) % world
         if all_sizes[prev, 0]:
             g.shard_merge(lists[prev].data_ptr(), int(all_sizes[prev, 0]), from_previous_shard=True)

@@ -138,3 +138,166 @@ def test_exchange_and_merge_gloo(oracle, world):
         L = oracle.lib()
         for key in owned["kmer"][:200]:
             assert (0 if key == 0 else (L.orc_hash_code(int(key)) >> 32) % world) == rank
+
+
+# ------------------------------------------------------------------------------------------------
+# slot-range ownership flow (multigpu.sharded_finalize) with a host-memory stand-in for capi.Graph
+# ------------------------------------------------------------------------------------------------
+import ctypes as C
+
+
+class FakeShardGraph:
+    """capi.Graph look-alike on host memory: 'records' are 16-byte observations {kmer, lb | rb << 8}
+    bucketed by slot-range owner; finalize aggregates what arrived with numpy.  Only the interface
+    sharded_finalize uses is provided."""
+
+    CAP = 1 << 15  # records per destination chunk
+
+    def __init__(self, O, reads, k, world, rank, size):
+        self.O, self.world, self.rank, self.size = O, world, rank, size
+        L = O.lib()
+        span = -(-size // world)
+        self.slot_lo, self.slot_hi = rank * span, min(size, (rank + 1) * span)
+        self.send = np.zeros((world, self.CAP), NODE)
+        self.send_cnt = np.zeros((world, 1), np.uint32)
+        self.recv = np.zeros((world, self.CAP), NODE)
+        self.recv_cnt = np.zeros((world, 1), np.uint32)
+        self.polyA = np.zeros(8, np.int64)
+        self.total_reads, self.total_kmers = len(reads), 0
+        for seq in reads:
+            km, lb, rb = O.parse_read(seq, k)
+            self.total_kmers += len(km)
+            for key, l, r in zip(km.tolist(), lb.tolist(), rb.tolist()):
+                if key == 0:
+                    if l != 4:
+                        self.polyA[l] += 1
+                    if r != 4:
+                        self.polyA[4 + r] += 1
+                    continue
+                d = (L.orc_hash_code(key) % size) // span
+                i = int(self.send_cnt[d, 0])
+                self.send[d, i] = (key, l | (r << 8), 0)
+                self.send_cnt[d, 0] = i + 1
+        self.nodes = np.zeros(0, NODE)
+        self.extra = []
+
+    def shard_info(self):
+        class I:
+            pass
+        i = I()
+        i.n_ranks, i.rank = self.world, self.rank
+        i.chunk_bytes, i.cnt_chunk_bytes = self.CAP * 16, 4
+        i.d_send, i.d_recv = self.send.ctypes.data, self.recv.ctypes.data
+        i.d_send_cnt, i.d_recv_cnt = self.send_cnt.ctypes.data, self.recv_cnt.ctypes.data
+        return i
+
+    def sync(self):
+        pass
+
+    def shard_mark_exchanged(self):
+        self.exchanged = True
+
+    def _aggregate(self, triples):
+        if len(triples) == 0:
+            return np.zeros(0, NODE)
+        keys, inv = np.unique(triples["kmer"], return_inverse=True)
+        cnt = np.zeros((len(keys), 8), np.int64)
+        code = triples["l_link"]
+        lb, rb = code & 0xFF, (code >> 8) & 0xFF
+        for side, b in ((0, lb), (4, rb)):
+            ok = b != 4
+            np.add.at(cnt, (inv[ok], side + b[ok].astype(np.int64)), 1)
+        return keys, np.minimum(cnt, 255)
+
+    def finalize(self):
+        assert self.exchanged
+        got = np.concatenate([self.recv[s, :int(self.recv_cnt[s, 0])] for s in range(self.world)])
+        keys, cnt = self._aggregate(got)
+        self.keys, self.cnt = keys, cnt
+
+        class S:
+            pass
+        st = S()
+        st.total_reads, st.total_kmers, st.stored_kmers = self.total_reads, self.total_kmers, self.total_kmers
+        pa = np.minimum(self.polyA, 255)
+        st.polyA_l_link = int(pa[0] << 24 | pa[1] << 16 | pa[2] << 8 | pa[3])
+        st.polyA_r_link = int(pa[4] << 24 | pa[5] << 16 | pa[6] << 8 | pa[7])
+        self.pa_links = [st.polyA_l_link, st.polyA_r_link]
+        return st
+
+    def shard_outgoing(self):
+        return 0, 0
+
+    def shard_overflow(self):
+        return 0, 0
+
+    def add_polyA(self, l, r):
+        for j, v in enumerate((l, r)):
+            a = np.array([(self.pa_links[j] >> s) & 0xFF for s in (24, 16, 8, 0)]) + np.array([(v >> s) & 0xFF for s in (24, 16, 8, 0)])
+            a = np.minimum(a, 255)
+            self.pa_links[j] = int(a[0] << 24 | a[1] << 16 | a[2] << 8 | a[3])
+
+    def refresh_stats(self):
+        class S:
+            pass
+        s = S()
+        s.count = len(self.keys) + (1 if self.rank == 0 else 0)
+        return s
+
+    def result_nodes(self):
+        out = np.zeros(len(self.keys) + (1 if self.rank == 0 else 0), NODE)
+        z = 1 if self.rank == 0 else 0
+        if z:
+            out[0] = (0, self.pa_links[0], self.pa_links[1])
+        out["kmer"][z:] = self.keys
+        c = self.cnt
+        out["l_link"][z:] = c[:, 0] << 24 | c[:, 1] << 16 | c[:, 2] << 8 | c[:, 3]
+        out["r_link"][z:] = c[:, 4] << 24 | c[:, 5] << 16 | c[:, 6] << 8 | c[:, 7]
+        return out
+
+
+def _wrap_host(ptr, nbytes, device):
+    return torch.frombuffer((C.c_uint8 * int(nbytes)).from_address(int(ptr)), dtype=torch.uint8)
+
+
+def _shard_worker(rank, world, port, reads, k, size, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as O
+    from dbg_assembly_amd.multigpu import sharded_finalize
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FakeShardGraph(O, reads[rank::world], k, world, rank, size)
+    out = sharded_finalize(g, "cpu", wrap=_wrap_host)
+    q.put((rank, out, g.result_nodes().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_finalize_gloo(oracle, world):
+    rng = random.Random(9)
+    g = "".join(rng.choice("ACGT") for _ in range(2500))
+    reads = []
+    for _ in range(500):
+        s = rng.randint(0, 2500 - 90)
+        reads.append(g[s:s + 90].encode())
+    reads += [b"A" * 90] * 280 + [b"T" * 40] * 7
+    rng.shuffle(reads)
+    k, size = 21, 1000003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, reads, k, size, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=k, init_hash_size=0.001)
+    merged = np.sort(np.concatenate([np.frombuffer(b, dtype=NODE) for _, _, b in results]), order="kmer")
+    assert np.array_equal(merged, whole.nodes.astype(NODE))
+    for rank, out, _ in results:
+        assert (out["count"], out["total_reads"], out["total_kmers"]) == (whole.count, whole.total_reads, whole.total_kmers)
