@@ -30,6 +30,10 @@ constexpr int kTileRecords = kTileThreads * 16; // level 2: 16384 records staged
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
 constexpr int kBPT = kMaxBuckets / kTileThreads; // histogram entries owned by one thread
 constexpr int kL1Threads = kTileThreads;        // level-1 kernel: same tile geometry as level 2
+#ifndef DBGK_SCHED_WINDOW
+#define DBGK_SCHED_WINDOW 0
+#endif
+constexpr uint32_t kSchedWindow = DBGK_SCHED_WINDOW; // positions the scheduler may interleave in the extraction loop (0 = all 16)
 constexpr int kL1BPT = kMaxBuckets / kL1Threads;
 constexpr int kBuildThreads = 1024;            // 2 workgroups per CU (66 KiB LDS each) = 32 waves per CU, needs <= 64 VGPRs
 
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 				c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
 				// keep the scheduler from interleaving all 16 positions (register pressure: the
 				// workgroup has 1024 threads, so 128 VGPRs per lane is the ceiling)
-				if ((i & 3u) == 3u) __builtin_amdgcn_sched_barrier(0);
+				if (kSchedWindow && (i % (kSchedWindow ? kSchedWindow : 1)) == (kSchedWindow ? kSchedWindow : 1) - 1u) __builtin_amdgcn_sched_barrier(0);
 			}
 		}
 		if (zero_mask) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
