@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libdbgk.so")
 NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
 
 OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
-ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION = 0, 1, 2
+ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ = 0, 1, 2, 3
 
 
 class SynthParams(C.Structure):
@@ -87,6 +87,8 @@ SYMBOLS = [
     ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
+    ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
+    ("dbgk_kfreq_export_bits", _i, [_vp, C.c_uint32, _u64, _u64, _vp]),
     ("dbgk_extract_kmers", _i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("dbgk_partition_counts", _i, [_vp, C.c_uint32, _vp]),
     ("dbgk_partition_export", _i, [_vp, C.c_uint32, _vp, _u64]),
@@ -279,6 +281,19 @@ class Graph:
         _chk(lib().dbgk_refresh_stats(self._h, C.byref(st)), "dbgk_refresh_stats")
         self.stats = st
         return st
+
+    # ---- KFREQ engine
+    def kfreq_counts(self, first=0, n=None):
+        n = (4 ** self.k - first) if n is None else n
+        out = np.zeros(n, np.uint8)
+        _chk(lib().dbgk_kfreq_export_counts(self._h, first, n, out.ctypes.data), "dbgk_kfreq_export_counts")
+        return out
+
+    def kfreq_bits(self, cutoff, first_byte=0, n_bytes=None):
+        n_bytes = (4 ** self.k // 8 - first_byte) if n_bytes is None else n_bytes
+        out = np.zeros(n_bytes, np.uint8)
+        _chk(lib().dbgk_kfreq_export_bits(self._h, cutoff, first_byte, n_bytes, out.ctypes.data), "dbgk_kfreq_export_bits")
+        return out
 
     # ---- sharded table (slot-range ownership)
     def shard_info(self):

@@ -93,6 +93,12 @@ struct dbgk_handle {
 	bool finalized = false;
 	uint64_t total_reads = 0;
 
+	// KFREQ engine: counts[4^k] instead of a node table
+	bool kfreq = false;
+	uint8_t *counts = nullptr;
+	uint64_t n_counts = 0;
+	uint64_t kf_distinct = 0, kf_sum = 0;
+
 	// PARTITION engine
 	bool part = false;            // records are partitioned at push time, table built at finalize
 	bool part_built = false;      // finalize already turned the records into the table
@@ -223,6 +229,7 @@ static void free_handle(dbgk_handle *h)
 		if (h->store.outgoing_n) (void)hipFree(h->store.outgoing_n);
 	}
 	if (h->table) (void)hipFree(h->table);
+	if (h->counts) (void)hipFree(h->counts);
 	if (h->d_ctr) (void)hipFree(h->d_ctr);
 	if (h->h_ctr) (void)hipHostFree(h->h_ctr);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -238,7 +245,9 @@ static int zero_table_now(dbgk_handle *h)
 
 static int reset_state(dbgk_handle *h)
 {
-	if (h->part) {
+	if (h->kfreq) {
+		HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
+	} else if (h->part) {
 		// the region build of finalize overwrites every slot, so the 16 B/slot memset is only needed
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
@@ -369,8 +378,10 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	*out = nullptr;
 	if (cfg->kmer_size < 1 || cfg->kmer_size > 32) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100)
 	if (cfg->max_read_len < cfg->kmer_size) return DBGK_ERR_ARG;
-	if (cfg->table_slots < 3) return DBGK_ERR_ARG;
-	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION)
+	const bool kfreq = cfg->engine == DBGK_ENGINE_KFREQ;
+	if (kfreq && cfg->kmer_size > 18) return DBGK_ERR_ARG; // 4^18 bytes = 64 GiB
+	if (!kfreq && cfg->table_slots < 3) return DBGK_ERR_ARG;
+	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION && !kfreq)
 		return DBGK_ERR_ARG;
 
 	int n_dev = 0;
@@ -385,9 +396,11 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	if (!h) return DBGK_ERR_NOMEM;
 	h->cfg = *cfg;
 	h->device = cfg->device_id;
-	h->size = cfg->table_slots;
+	h->kfreq = kfreq;
+	h->size = kfreq ? 3 : cfg->table_slots;
 	h->magic = make_mod_magic(h->size);
-	{
+	h->tslots = h->size;
+	if (!kfreq) {
 		const int prc = plan_partition(h); // geometry first: a sharded handle holds only its slot range
 		if (prc != DBGK_OK) {
 			delete h;
@@ -410,7 +423,14 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->grid = h->n_cu * 8; // 8 x 256-thread blocks per CU = 32 waves/CU, the residency limit
 
 	if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DBGK_ERR_HIP);
-	if (hipMalloc(&h->table, h->tslots * sizeof(Node)) != hipSuccess) {
+	if (kfreq) {
+		h->n_counts = 1ull << (2 * cfg->kmer_size);
+		if (h->n_counts < 64) h->n_counts = 64; // whole dwords / 8-byte groups for the scan kernels (k < 3)
+		if (hipMalloc(&h->counts, h->n_counts) != hipSuccess) {
+			g_last_error = "hipMalloc of the 4^k count table failed";
+			return fail(DBGK_ERR_NOMEM);
+		}
+	} else if (hipMalloc(&h->table, h->tslots * sizeof(Node)) != hipSuccess) {
 		g_last_error = "hipMalloc of the k-mer table failed";
 		return fail(DBGK_ERR_NOMEM);
 	}
@@ -461,6 +481,7 @@ extern "C" void *dbgk_stream(dbgk_handle *h) { return h ? (void *)h->stream : nu
 
 extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || new_slots < 3) return DBGK_ERR_ARG;
 	int rc = use_device(h);
 	if (rc) return rc;
@@ -533,7 +554,12 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
-	if (h->part) {
+	if (h->kfreq) {
+		if (has_long)
+			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
+		else
+			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
+	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
@@ -703,10 +729,33 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 		rc = build_from_records(h);
 		if (rc) return rc;
 	}
+	if (h->kfreq) {
+		unsigned long long *d_sum = nullptr, res[2] = {0, 0};
+		if (hipMalloc(&d_sum, 16) != hipSuccess) return DBGK_ERR_NOMEM;
+		hipError_t e = hipMemsetAsync(d_sum, 0, 16, h->stream);
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_counts_summary, dim3(grid_for(h, h->n_counts >> 3)), dim3(kBlock), 0, h->stream, h->counts, h->n_counts, d_sum);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipMemcpyAsync(res, d_sum, 16, hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		(void)hipFree(d_sum);
+		if (e != hipSuccess) return hip_fail(e, "kfreq summary", __LINE__);
+		h->kf_distinct = res[0];
+		h->kf_sum = res[1];
+	}
 	rc = read_counters(h);
 	if (rc) return rc;
 	h->finalized = true;
 	if (out) fill_stats(h, out);
+	if (h->kfreq) {
+		if (out) {
+			out->count = h->kf_distinct;
+			out->count_conflict = 0;
+			out->table_slots = h->n_counts;
+		}
+		return DBGK_OK;
+	}
 	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
 	if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY; // PARTITION overflow stores exhausted (expected_kmers too small)
 	if (h->h_ctr->n_new + 1 > h->tslots) return DBGK_ERR_TABLE_FULL; // no free slot left for the key-0 node
@@ -746,6 +795,7 @@ __global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restri
 
 extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
@@ -799,6 +849,7 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 
 extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out || !n_out) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
@@ -859,6 +910,7 @@ extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capac
 
 extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !digest) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
@@ -881,6 +933,7 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 
 extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_stats *out)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
@@ -905,6 +958,43 @@ extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_
 	out->linear_nodes = (int64_t)res[258];
 	out->tip_nodes = (int64_t)res[259];
 	out->branch_nodes = (int64_t)res[260];
+	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KFREQ exports
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_kfreq_export_counts(dbgk_handle *h, uint64_t first_kmer, uint64_t n, uint8_t *host_out)
+{
+	if (!h || !host_out) return DBGK_ERR_ARG;
+	if (!h->kfreq || !h->finalized) return DBGK_ERR_STATE;
+	const uint64_t total = 1ull << (2 * h->cfg.kmer_size);
+	if (first_kmer > total || n > total - first_kmer) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n == 0) return DBGK_OK;
+	HIPCHK(hipMemcpyAsync(host_out, h->counts + first_kmer, n, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_kfreq_export_bits(dbgk_handle *h, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out)
+{
+	if (!h || !host_out) return DBGK_ERR_ARG;
+	if (!h->kfreq || !h->finalized) return DBGK_ERR_STATE;
+	const uint64_t total_bytes = h->n_counts >> 3;
+	if (first_byte > total_bytes || n_bytes > total_bytes - first_byte) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n_bytes == 0) return DBGK_OK;
+	uint8_t *d_bits = nullptr;
+	if (hipMalloc(&d_bits, n_bytes) != hipSuccess) return DBGK_ERR_NOMEM;
+	hipLaunchKernelGGL(k_counts_to_bits, dim3(grid_for(h, n_bytes)), dim3(kBlock), 0, h->stream, h->counts, first_byte, n_bytes, cutoff, d_bits);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(host_out, d_bits, n_bytes, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_bits);
+	if (e != hipSuccess) return hip_fail(e, "kfreq_export_bits", __LINE__);
 	return DBGK_OK;
 }
 
@@ -969,6 +1059,7 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE; // a sharded table is already owned by slot range
 	int rc = use_device(h);
@@ -999,6 +1090,7 @@ __global__ void k_write_polyA_node(Node *out, uint64_t index, const Counters *ct
 
 extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !d_nodes || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE;
 	std::vector<uint64_t> counts(n_parts);
@@ -1029,6 +1121,7 @@ extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node
 
 extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
 	if ((uintptr_t)d_nodes & 15u) return DBGK_ERR_ARG;
 	if (h->sharded) return DBGK_ERR_STATE; // use dbgk_shard_merge
@@ -1066,6 +1159,7 @@ extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_han
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 {
+	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out) return DBGK_ERR_ARG;
 	if (!h->part) return DBGK_ERR_STATE;
 	const PartGeom &G = h->geom;

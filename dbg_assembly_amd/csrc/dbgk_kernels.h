@@ -354,6 +354,76 @@ __global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRe
 }
 
 // ---------------------------------------------------------------------------------------------
+// KFREQ engine: the direct-addressed k-mer frequency table that the
+// reference's correct_error module loads (correct_error/main.cpp:161-220 8-bit format,
+// main_parallel_senior.cpp:334-408 1-bit format).  counts[v] = min(255, occurrences of the
+// canonical k-mer v), v < 4^k.  Same extraction as the graph path (N counts as A, tie -> forward).
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_DEAD>
+__global__ __launch_bounds__(kBlock) void k_extract_count(ReadBatch rb, uint32_t *__restrict__ count_words)
+{
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x; chunk < n_chunks; chunk += stride) {
+		LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+#pragma unroll 4
+		for (uint32_t i = 0; i < kPosPerLane; i++) {
+			const Triple t = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
+			if (!t.valid) continue;
+			uint32_t *word = count_words + (t.key >> 2);
+			const uint32_t sh = (uint32_t)(t.key & 3u) * 8u; // little-endian byte t.key of the table
+			uint32_t old = *word;
+			for (;;) { // saturating byte increment inside its dword
+				if (((old >> sh) & 0xFFu) == 0xFFu) break;
+				const uint32_t prev = atomicCAS(word, old, old + (1u << sh));
+				if (prev == old) break;
+				old = prev;
+			}
+		}
+	}
+}
+
+// bit table of the 1-bit format: bit (128 >> (v % 8)) of byte v / 8 is set when counts[v] > cutoff
+// (bitAll, correct_error/seqKmer.cpp:34); one thread per output byte
+__global__ __launch_bounds__(kBlock) void k_counts_to_bits(const uint8_t *__restrict__ counts, uint64_t first_byte, uint64_t n_bytes,
+                                                           uint32_t cutoff, uint8_t *__restrict__ bits)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_bytes; b += stride) {
+		const uint64_t c8 = *reinterpret_cast<const uint64_t *>(counts + (first_byte + b) * 8u);
+		uint32_t byte = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++)
+			if (((uint32_t)(c8 >> (8u * j)) & 0xFFu) > cutoff) byte |= 0x80u >> j;
+		bits[b] = (uint8_t)byte;
+	}
+}
+
+// out[0] = number of non-zero counters, out[1] = sum of counters (saturated values)
+__global__ __launch_bounds__(kBlock) void k_counts_summary(const uint8_t *__restrict__ counts, uint64_t n, unsigned long long *__restrict__ out)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long nz = 0, sum = 0;
+	const uint64_t n8 = n >> 3;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += stride) {
+		const uint64_t c8 = reinterpret_cast<const uint64_t *>(counts)[i];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++) {
+			const uint32_t c = (uint32_t)(c8 >> (8u * j)) & 0xFFu;
+			nz += c != 0u;
+			sum += c;
+		}
+	}
+	const unsigned long long a = block_sum(nz, red);
+	const unsigned long long b = block_sum(sum, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&out[0], a);
+		if (b) atomicAdd(&out[1], b);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_extract_store: phase A alone, position-indexed outputs (parity of the extraction)
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_DEAD>

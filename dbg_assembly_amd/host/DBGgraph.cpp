@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "dbgk.h"
+#include "reads_io.h"
 
 // ---- the reference's globals (DBGgraph.cpp:10-34), same names and defaults -------------------
 int KmerSize = 31;
@@ -150,53 +151,15 @@ void *thread_updatekmers(void *)
 	abort();
 }
 
-// One reads file -> batches on the GPU.  Record rules of DBGgraph.cpp:244-272: a line whose first
-// character is '@' (format 1) / '>' (otherwise) announces a record and the NEXT line is its
-// sequence; format 1 then skips two lines; any other line is ignored.  A header on the very last
-// line yields an empty read (it is still counted in Total_reads_num).
+// One reads file -> batches on the GPU (record rules: reads_io.h).
 void parse_one_reads_file(string &reads_file)
 {
 	if (!g_session) return;
 	Session &S = *g_session;
-	gzFile fp = gzopen(reads_file.c_str(), "rb");
-	if (!fp) {
+	if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); })) {
 		cerr << "fail to open reads file " << reads_file << endl;
 		return;
 	}
-	gzbuffer(fp, 1 << 20);
-	const char marker = (Input_file_format == 1) ? '@' : '>';
-	const size_t CHUNK = 8u << 20;
-	std::vector<char> buf(CHUNK + 1);
-	size_t have = 0;   // bytes of an unfinished line carried over
-	int state = 0;     // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
-	bool eof = false;
-	while (!eof) {
-		if (buf.size() < have + CHUNK) buf.resize(have + CHUNK);
-		const int got = gzread(fp, buf.data() + have, (unsigned)CHUNK);
-		if (got <= 0) eof = true;
-		const size_t end = have + (got > 0 ? (size_t)got : 0);
-		size_t pos = 0;
-		while (pos < end) {
-			const char *nl = static_cast<const char *>(memchr(buf.data() + pos, '\n', end - pos));
-			size_t line_end;
-			if (nl) line_end = (size_t)(nl - buf.data());
-			else if (eof) line_end = end;  // last line without a newline
-			else break;
-			const char *line = buf.data() + pos;
-			const size_t len = line_end - pos;
-			switch (state) {
-				case 0: if (len && line[0] == marker) state = 1; break;
-				case 1: add_read(S, line, len); state = (Input_file_format == 1) ? 2 : 0; break;
-				case 2: state = 3; break;
-				default: state = 0; break;
-			}
-			pos = line_end + 1;
-		}
-		have = pos < end ? end - pos : 0;
-		if (have) memmove(buf.data(), buf.data() + pos, have);
-	}
-	if (state == 1) add_read(S, "", 0);
-	gzclose(fp);
 	flush_batch(S);
 	cerr << "this block has reach the end of file " << endl;
 }

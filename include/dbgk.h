@@ -51,6 +51,9 @@ typedef struct dbgk_handle dbgk_handle;
 #define DBGK_ENGINE_AUTO       0
 #define DBGK_ENGINE_DIRECT     1  /* fused extract + 64-bit-atomic insert into the global table      */
 #define DBGK_ENGINE_PARTITION  2  /* extract -> radix-partitioned records -> LDS-built table regions */
+#define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
+                                     canonical k-mers (the correct_error module's frequency table);
+                                     table_slots is ignored, k <= 18                                */
 
 typedef struct dbgk_config {
 	int32_t  kmer_size;        /* KmerSize   (DBGgraph.cpp:10), 1..32                              */
@@ -169,6 +172,17 @@ int dbgk_digest(dbgk_handle *h, uint64_t *digest);
 
 /* calculate_kmer_links first pass (contig.cpp:119-181) on the device table                      */
 int dbgk_link_stats_device(dbgk_handle *h, int32_t kmer_freq_cutoff, dbgk_link_stats *out);
+
+/* ---- KFREQ engine: the k-mer frequency table of the correct_error module --------
+ * The reference only CONSUMES this table (its producer, `kmerfreq`, is not part of the repository):
+ * 8-bit format = 4^k saturating counts indexed by k-mer value, read by
+ * correct_error/main.cpp:161-220; 1-bit format = bitmap, bit 128 >> (v % 8) of byte v / 8, read by
+ * correct_error/main_parallel_senior.cpp:334-408 which mirrors bit v to its reverse complement only
+ * when v <= rc(v) -- so counts live on the canonical (smaller) k-mer.  push_reads / finalize work as
+ * for the graph engines; stats.count = number of distinct canonical k-mers.                       */
+int dbgk_kfreq_export_counts(dbgk_handle *h, uint64_t first_kmer, uint64_t n, uint8_t *host_out);
+/* n_bytes bytes of the bit table starting at byte first_byte: bit set when count > cutoff          */
+int dbgk_kfreq_export_bits(dbgk_handle *h, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out);
 
 /* ---- phase A alone (parity of the extraction kernel) ------------------------------------------ */
 

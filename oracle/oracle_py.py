@@ -275,3 +275,102 @@ def ref_build(lib_file, k=31, max_read_len=250, threads=1, init_hash_size=0.001,
     cmd.append(lib_file)
     out = subprocess.run(cmd, check=True, capture_output=True, timeout=timeout, text=True).stdout
     return json.loads(out.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# correct_error k-mer frequency table: restated LOADERS, expected counts
+# ------------------------------------------------------------------------------------------------
+KFREQ_BLOCK_KMERS = 8 * 1024 * 1024  # SrcBlockSize (correct_error/main.cpp:48, main_parallel_senior.cpp:71)
+
+
+def revcomp_values(v, k):
+    """vectorised get_rev_com_kbit (correct_error/seqKmer.cpp:88-97) on a uint64 array"""
+    x = ~np.asarray(v, dtype=np.uint64)
+    for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF),
+                  (16, 0x0000FFFF0000FFFF), (32, 0x00000000FFFFFFFF)):
+        m = np.uint64(m)
+        x = ((x & m) << np.uint64(sh)) | ((x & ~m) >> np.uint64(sh))
+    return x >> np.uint64(64 - 2 * k)
+
+
+def kfreq_expected_counts(files_mem, k, max_read_len=1000000):
+    """min(255, occurrences) of every canonical k-mer, indexed by k-mer value (4^k entries); the
+    extraction is the graph path's (orc_parse_read: N is A, canonical = min, tie forward)."""
+    acc = np.zeros(4 ** k, dtype=np.int64)
+    for bases, offsets in files_mem:
+        raw = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+        for i in range(len(offsets) - 1):
+            seq = raw[int(offsets[i]):int(offsets[i + 1])]
+            km, _, _ = parse_read(seq, k, max_read_len)
+            if len(km):
+                np.add.at(acc, km.astype(np.int64), 1)
+    return np.minimum(acc, 255).astype(np.uint8)
+
+
+def _read_cz_blocks(path):
+    import zlib
+    lens = [int(x) for x in open(path + ".len").read().split()]
+    data = open(path, "rb").read()
+    out, pos = [], 0
+    for n in lens:
+        out.append(zlib.decompress(data[pos:pos + n]))
+        pos += n
+    return out
+
+
+def kfreq_load_1bit(path, k):
+    """make_kmerFreq_1bit_table_from_1BitGz_pthread (correct_error/main_parallel_senior.cpp:334-408):
+    block b of the file is the bit table from byte b * 1 MiB; then every set bit i with
+    i <= rc(i) sets bit rc(i) (thread_setrevcompkmer :310-329).  Returns (bits uint8[4^k/8], hifreq)."""
+    total = 4 ** k
+    table = np.zeros(total // 8, dtype=np.uint8)
+    for b, blk in enumerate(_read_cz_blocks(path)):
+        start = b * (KFREQ_BLOCK_KMERS // 8)
+        table[start:start + len(blk)] = np.frombuffer(blk, dtype=np.uint8)
+    idx = np.flatnonzero(np.unpackbits(table)).astype(np.uint64)
+    rc = revcomp_values(idx, k)
+    keep = idx <= rc
+    bits = np.unpackbits(table)
+    bits[rc[keep].astype(np.int64)] = 1
+    return np.packbits(bits), int(keep.sum())
+
+
+def kfreq_load_8bit(path, k, low_freq_cutoff):
+    """make_kmerFreq_1bit_table_from_8BitGz (correct_error/main.cpp:161-220): counts > cutoff set the
+    bit of idx and of rc(idx).  Returns (bits, num_total_kmers, num_effect_kmers)."""
+    total = 4 ** k
+    counts = np.zeros(total, dtype=np.uint8)
+    for b, blk in enumerate(_read_cz_blocks(path)):
+        start = b * KFREQ_BLOCK_KMERS
+        counts[start:start + len(blk)] = np.frombuffer(blk, dtype=np.uint8)
+    hi = np.flatnonzero(counts > low_freq_cutoff).astype(np.uint64)
+    bits = np.zeros(total, dtype=np.uint8)
+    bits[hi.astype(np.int64)] = 1
+    bits[revcomp_values(hi, k).astype(np.int64)] = 1
+    return np.packbits(bits), int(counts.astype(np.int64).sum()), int((counts > 0).sum())
+
+
+def kfreq_write_cz(path, raw_bytes, block_bytes):
+    """test-side writer of the .cz / .cz.len container (blocks zlib-compressed independently)"""
+    import zlib
+    raw = bytes(raw_bytes)
+    with open(path, "wb") as fz, open(path + ".len", "w") as fl:
+        for pos in range(0, len(raw), block_bytes):
+            c = zlib.compress(raw[pos:pos + block_bytes])
+            fz.write(c)
+            fl.write("%d\n" % len(c))
+
+
+def have_ref_kfreq():
+    return all(os.access(os.path.join(HERE, "_ref", b), os.X_OK) for b in ("ref_kfreq1", "ref_kfreq8"))
+
+
+def ref_kfreq_load(path, k, one_bit=True, threads_or_cutoff=4, timeout=600):
+    """run the REAL reference loader on a .cz file -> (bits uint8[4^k/8], json stats)"""
+    import tempfile
+    exe = os.path.join(HERE, "_ref", "ref_kfreq1" if one_bit else "ref_kfreq8")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "bits.bin")
+        r = subprocess.run([exe, path, str(k), str(threads_or_cutoff), out], check=True, capture_output=True,
+                           text=True, timeout=timeout)
+        return np.fromfile(out, dtype=np.uint8), json.loads(r.stdout.strip().splitlines()[-1])
