@@ -293,6 +293,7 @@ static int plan_partition(dbgk_handle *h)
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
+	while (r > 20 && qbits + (int)r + 6 > 64 && ((h->size + (1ull << (r - 1)) - 1) >> (r - 1)) <= (uint64_t)kMaxBuckets) r--; // small tables: q needs the bits
 	const bool feasible = (r - kRegionBits) <= 10 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26) && h->size < (1ull << 32);
 	if (!feasible || (want_shard && want == DBGK_ENGINE_DIRECT)) {
 		if (want == DBGK_ENGINE_PARTITION || want_shard) {
