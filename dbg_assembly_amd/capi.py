@@ -16,6 +16,7 @@ NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
 
 OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ = 0, 1, 2, 3
+FLAG_TRACK_FIRST_SEEN = 1
 
 
 class SynthParams(C.Structure):
@@ -34,7 +35,7 @@ class Config(C.Structure):
     _fields_ = [("kmer_size", C.c_int32), ("max_read_len", C.c_int32), ("table_slots", C.c_uint64),
                 ("device_id", C.c_int32), ("engine", C.c_int32), ("max_batch_bases", C.c_uint64),
                 ("expected_kmers", C.c_uint64), ("shard_count", C.c_uint32), ("shard_index", C.c_uint32),
-                ("reserved", C.c_uint64 * 3)]
+                ("flags", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class ShardInfo(C.Structure):
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("dbgk_copy_nodes_peer", _i, [_vp, _vp, _vp, _vp, _u64]),
     ("dbgk_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_export_first_seen_order", _i, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -171,10 +173,10 @@ class Graph:
     """One GPU-resident k-mer graph under construction (thin wrapper over a dbgk_handle)."""
 
     def __init__(self, k, table_slots, max_read_len=250, device=0, engine=ENGINE_AUTO, max_batch_bases=0,
-                 expected_kmers=0, shard_count=0, shard_index=0):
+                 expected_kmers=0, shard_count=0, shard_index=0, flags=0):
         self._h = None
         cfg = Config(k, max_read_len, table_slots, device, engine, max_batch_bases, expected_kmers,
-                     shard_count, shard_index)
+                     shard_count, shard_index, flags)
         h = C.c_void_p()
         _chk(lib().dbgk_create(C.byref(cfg), C.byref(h)), "dbgk_create")
         self._h = h
@@ -240,6 +242,15 @@ class Graph:
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_export_host_table")
         return array, flags
+
+    def export_first_seen_order(self):
+        n = self.stats.count - 1
+        nodes = np.zeros(max(n, 1), dtype=NODE_DTYPE)
+        pos = np.zeros(max(n, 1), dtype=np.uint64)
+        got = C.c_uint64()
+        _chk(lib().dbgk_export_first_seen_order(self._h, nodes.ctypes.data, pos.ctypes.data, n, C.byref(got)),
+             "dbgk_export_first_seen_order")
+        return nodes[:got.value], pos[:got.value]
 
     def digest(self):
         d = C.c_uint64()

@@ -93,6 +93,11 @@ struct dbgk_handle {
 	bool finalized = false;
 	uint64_t total_reads = 0;
 
+	// first-seen tracking (DBGK_FLAG_TRACK_FIRST_SEEN, DIRECT engine)
+	bool track = false;
+	unsigned long long *first_pos = nullptr; // [tslots]
+	uint64_t pos_base = 0;                   // bases pushed so far
+
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
 	uint8_t *counts = nullptr;
@@ -230,6 +235,7 @@ static void free_handle(dbgk_handle *h)
 	}
 	if (h->table) (void)hipFree(h->table);
 	if (h->counts) (void)hipFree(h->counts);
+	if (h->first_pos) (void)hipFree(h->first_pos);
 	if (h->d_ctr) (void)hipFree(h->d_ctr);
 	if (h->h_ctr) (void)hipHostFree(h->h_ctr);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -261,6 +267,8 @@ static int reset_state(dbgk_handle *h)
 		int rc = zero_table_now(h);
 		if (rc) return rc;
 	}
+	if (h->track) HIPCHK(hipMemsetAsync(h->first_pos, 0xFF, h->tslots * 8, h->stream));
+	h->pos_base = 0;
 	HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
 	HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
 	h->finalized = false;
@@ -435,6 +443,14 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 		g_last_error = "hipMalloc of the k-mer table failed";
 		return fail(DBGK_ERR_NOMEM);
 	}
+	if (cfg->flags & DBGK_FLAG_TRACK_FIRST_SEEN) {
+		if (h->part || h->kfreq) {
+			g_last_error = "DBGK_FLAG_TRACK_FIRST_SEEN needs the DIRECT engine";
+			return fail(DBGK_ERR_ARG);
+		}
+		if (hipMalloc(&h->first_pos, h->tslots * 8) != hipSuccess) return fail(DBGK_ERR_NOMEM);
+		h->track = true;
+	}
 	if (hipMalloc(&h->d_ctr, sizeof(Counters)) != hipSuccess) return fail(DBGK_ERR_NOMEM);
 	if (hipHostMalloc(&h->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return fail(DBGK_ERR_NOMEM);
 	h->cap_bases = cfg->max_batch_bases ? cfg->max_batch_bases : (256ull << 20);
@@ -494,26 +510,45 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 		return DBGK_ERR_STATE;
 	}
 	Node *fresh = nullptr;
+	unsigned long long *fresh_first = nullptr;
 	if (hipMalloc(&fresh, new_slots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (h->track) {
+		if (hipMalloc(&fresh_first, new_slots * 8) != hipSuccess) {
+			(void)hipFree(fresh);
+			return DBGK_ERR_NOMEM;
+		}
+		if (hipMemsetAsync(fresh_first, 0xFF, new_slots * 8, h->stream) != hipSuccess) {
+			(void)hipFree(fresh);
+			(void)hipFree(fresh_first);
+			return DBGK_ERR_HIP;
+		}
+	}
 	TableRef dst{fresh, new_slots, make_mod_magic(new_slots)};
 	hipError_t e = hipMemsetAsync(fresh, 0, new_slots * sizeof(Node), h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, dst, h->d_ctr);
+		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, dst, h->d_ctr,
+		                   (const unsigned long long *)h->first_pos, fresh_first);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	if (e != hipSuccess) {
 		(void)hipFree(fresh);
+		if (fresh_first) (void)hipFree(fresh_first);
 		return hip_fail(e, "resize_table", __LINE__);
 	}
 	if (h->h_ctr->error & 1u) { // new table too small for the existing nodes: keep the old one
 		(void)hipFree(fresh);
+		if (fresh_first) (void)hipFree(fresh_first);
 		HIPCHK(hipMemsetAsync(&h->d_ctr->error, 0, sizeof(unsigned int), h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		return DBGK_ERR_TABLE_FULL;
 	}
 	(void)hipFree(h->table);
+	if (h->track) {
+		(void)hipFree(h->first_pos);
+		h->first_pos = fresh_first;
+	}
 	h->table = fresh;
 	h->size = new_slots;
 	h->tslots = new_slots;
@@ -572,10 +607,20 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else
 			hipLaunchKernelGGL(k_extract_scatter<false>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+	} else if (h->track) {
+		if (has_long)
+			hipLaunchKernelGGL((k_extract_insert<true, true>), dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr,
+			                   h->first_pos, h->pos_base);
+		else
+			hipLaunchKernelGGL((k_extract_insert<false, true>), dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr,
+			                   h->first_pos, h->pos_base);
+		h->pos_base += n_bases;
 	} else if (has_long) {
-		hipLaunchKernelGGL(k_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
+		hipLaunchKernelGGL((k_extract_insert<true, false>), dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr,
+		                   (unsigned long long *)nullptr, (uint64_t)0);
 	} else {
-		hipLaunchKernelGGL(k_extract_insert<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr);
+		hipLaunchKernelGGL((k_extract_insert<false, false>), dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr,
+		                   (unsigned long long *)nullptr, (uint64_t)0);
 	}
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp);
@@ -906,6 +951,48 @@ extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capac
 		out[i + z].l_link = (uint32_t)(hl[i] & 0xFFFFFFFFu);
 		out[i + z].r_link = (uint32_t)(hl[i] >> 32);
 	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_export_first_seen_order(dbgk_handle *h, dbgk_node *out, uint64_t *first_pos, uint64_t capacity, uint64_t *n_out)
+{
+	if (!h || !out || !first_pos || !n_out) return DBGK_ERR_ARG;
+	if (!h->finalized || !h->track) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t n = h->h_ctr->n_new;
+	*n_out = n;
+	if (capacity < n) return DBGK_ERR_CAPACITY;
+	if (n == 0) return DBGK_OK;
+	uint64_t *d_pos = nullptr, *d_slot = nullptr;
+	unsigned long long *d_cursor = nullptr;
+	Node *d_nodes = nullptr;
+	auto cleanup = [&]() {
+		for (void *p : {(void *)d_pos, (void *)d_slot, (void *)d_cursor, (void *)d_nodes})
+			if (p) (void)hipFree(p);
+	};
+	if (hipMalloc(&d_pos, n * 8) != hipSuccess || hipMalloc(&d_slot, n * 8) != hipSuccess || hipMalloc(&d_cursor, 8) != hipSuccess ||
+	    hipMalloc(&d_nodes, n * sizeof(Node)) != hipSuccess) {
+		cleanup();
+		return DBGK_ERR_NOMEM;
+	}
+	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_compact_order, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->first_pos, h->tslots, d_pos,
+		                   d_slot, d_cursor, n);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) { cleanup(); return hip_fail(e, "export_first_seen_order/compact", __LINE__); }
+	rc = dbgk_internal_sort_pairs(d_pos, d_slot, n, h->stream); // positions are unique per key: a total order
+	if (rc != DBGK_OK) { cleanup(); return rc; }
+	hipLaunchKernelGGL(k_gather_nodes, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, h->table, d_slot, n, d_nodes);
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(out, d_nodes, n * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(first_pos, d_pos, n * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	cleanup();
+	if (e != hipSuccess) return hip_fail(e, "export_first_seen_order", __LINE__);
 	return DBGK_OK;
 }
 

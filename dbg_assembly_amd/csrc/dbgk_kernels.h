@@ -300,8 +300,12 @@ __device__ __forceinline__ uint64_t find_or_claim(const TableRef &T, uint64_t ke
 // ---------------------------------------------------------------------------------------------
 // k_extract_insert: DIRECT engine -- fused thread_parseBlock + thread_updatekmers
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_DEAD>
-__global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRef T, Counters *__restrict__ ctr)
+// TRACK: additionally keep, per slot, the smallest global base position at which the slot's key was
+// seen (first_pos[slot], atomicMin).  Distinct keys replayed in that order through the reference's
+// sequential insert reproduce its `-t 1` slot layout.
+template <bool HAS_DEAD, bool TRACK = false>
+__global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRef T, Counters *__restrict__ ctr,
+                                                           unsigned long long *__restrict__ first_pos = nullptr, uint64_t pos_base = 0)
 {
 	__shared__ unsigned long long red[kBlock / 64];
 	unsigned long long n_new = 0, n_conf = 0;
@@ -341,6 +345,10 @@ __global__ __launch_bounds__(kBlock) void k_extract_insert(ReadBatch rb, TableRe
 				const uint64_t s = find_or_claim(T, t[u].key, slot[u], first[u], guess, n_new, n_conf);
 				if (s == ~0ull) { full = true; continue; }
 				links_cas_observe(reinterpret_cast<unsigned long long *>(&T.nodes[s].links), guess, t[u].lb, t[u].rb);
+				if (TRACK) {
+					const unsigned long long pos = pos_base + chunk * 16u + g + (uint32_t)u;
+					if (first_pos[s] > pos) atomicMin(&first_pos[s], pos); // plain read first: positions mostly arrive in rising order
+				}
 			}
 		}
 	}
@@ -490,7 +498,8 @@ __global__ __launch_bounds__(kBlock) void k_merge_nodes(const Node *__restrict__
 // re-seat every node of `src` into `dst` (different size): keys are unique, so the claim is the
 // only atomic needed (device counterpart of enlarge_kmerset_parallel, kmerSet.cpp:132-189)
 __global__ __launch_bounds__(kBlock) void k_rehash(const Node *__restrict__ src, uint64_t src_size, TableRef dst,
-                                                   Counters *__restrict__ ctr)
+                                                   Counters *__restrict__ ctr, const unsigned long long *__restrict__ src_first = nullptr,
+                                                   unsigned long long *__restrict__ dst_first = nullptr)
 {
 	bool full = false;
 	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -506,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_rehash(const Node *__restrict__ src,
 			    atomicCAS(reinterpret_cast<unsigned long long *>(&dst.nodes[slot].kmer), 0ull, (unsigned long long)key);
 			if (seen == 0ull) {
 				dst.nodes[slot].links = links;
+				if (src_first) dst_first[slot] = src_first[i]; // first-seen position travels with the node
 				placed = true;
 				break;
 			}
@@ -591,6 +601,39 @@ __global__ __launch_bounds__(kBlock) void k_compact(const Node *__restrict__ nod
 			}
 		}
 	}
+}
+
+// compact occupied slots as (first_pos, slot index) pairs for the ordered export
+__global__ __launch_bounds__(kBlock) void k_compact_order(const Node *__restrict__ nodes, const unsigned long long *__restrict__ first_pos,
+                                                          uint64_t size, uint64_t *__restrict__ keys_pos, uint64_t *__restrict__ vals_slot,
+                                                          unsigned long long *__restrict__ cursor, uint64_t capacity)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	const uint64_t n_iter = (size + stride - 1) / stride;
+	for (uint64_t it = 0; it < n_iter; it++) {
+		const uint64_t i = it * stride + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+		const bool occ = i < size && nodes[i].kmer != 0ull;
+		const unsigned long long ballot = __ballot(occ);
+		const int lane = threadIdx.x & 63;
+		unsigned long long base = 0;
+		if (lane == 0 && ballot) base = atomicAdd(cursor, (unsigned long long)__popcll(ballot));
+		base = __shfl(base, 0, 64);
+		if (occ) {
+			const uint64_t dst = base + (uint64_t)__popcll(ballot & ((1ull << lane) - 1ull));
+			if (dst < capacity) {
+				keys_pos[dst] = first_pos[i];
+				vals_slot[dst] = i;
+			}
+		}
+	}
+}
+
+// out[i] = {node at slot vals_slot[i]} , pos_out[i] = keys_pos[i]   (after the pairs were sorted by position)
+__global__ __launch_bounds__(kBlock) void k_gather_nodes(const Node *__restrict__ nodes, const uint64_t *__restrict__ vals_slot, uint64_t n,
+                                                         Node *__restrict__ out)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = nodes[vals_slot[i]];
 }
 
 // order-independent digest + occupied count

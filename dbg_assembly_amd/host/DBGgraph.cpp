@@ -58,6 +58,11 @@ struct Session {
 	uint64_t device_slots = 0;
 	uint64_t next_progress = 0;
 	int status = DBGK_OK;
+	// DBGK_LAYOUT=ref: reproduce the reference's -t 1 slot layout (first-seen order replay)
+	bool ref_layout = false;
+	uint64_t pos = 0;                      // bases handed to the device so far (+ pending batch)
+	uint64_t reads_in_block = 0;           // reads since the last full block of the current file
+	std::vector<uint64_t> full_block_ends; // position right after every FULL block of BufferNum reads
 };
 
 Session *g_session = nullptr;
@@ -115,6 +120,13 @@ inline void add_read(Session &S, const char *seq, size_t len)
 {
 	S.bases.insert(S.bases.end(), seq, seq + len);
 	S.offsets.push_back(S.bases.size());
+	if (S.ref_layout) {
+		S.pos += len;
+		if (++S.reads_in_block == (uint64_t)std::max(BufferNum, 1)) { // the reference checks count > max here (DBGgraph.cpp:337)
+			S.full_block_ends.push_back(S.pos);
+			S.reads_in_block = 0;
+		}
+	}
 	if (S.bases.size() >= S.batch_limit) flush_batch(S);
 }
 
@@ -161,7 +173,56 @@ void parse_one_reads_file(string &reads_file)
 		return;
 	}
 	flush_batch(S);
+	S.reads_in_block = 0; // a file's last, short block is never followed by an enlarge check (DBGgraph.cpp:329-331)
 	cerr << "this block has reach the end of file " << endl;
+}
+
+// DBGK_LAYOUT=ref: rebuild the host table exactly as the reference's single-threaded path lays it
+// out.  At -t 1 the reference inserts k-mers in (file, read, position) order (DBGgraph.cpp:139-205),
+// a new key goes to the first slot with kmer == 0 on its probe chain, and after every FULL block of
+// BufferNum reads the table is enlarged in place when count > max (:337-343, kmerSet.cpp:132-189).
+// The slot layout therefore depends only on the ORDER in which distinct keys first appear and on
+// where the block boundaries fall between them -- both known here: the device returns the nodes
+// sorted by first-seen position, the parser recorded the position after every full block.
+static KmerSet *replay_reference_layout(Session &S, const std::vector<dbgk_node> &nodes, const std::vector<uint64_t> &first_pos,
+                                        uint64_t initial_size, uint32_t polyA_l, uint32_t polyA_r)
+{
+	KmerSet *ks = init_kmerset_parallel(initial_size, hashLoadFactor, std::max(threadNum, 1));
+	if (!ks) return NULL;
+	size_t i = 0;
+	bool alerted = false;
+	auto insert_until = [&](uint64_t limit) {
+		for (; i < nodes.size() && first_pos[i] < limit; i++) {
+			uint64_t hc = hash_code(nodes[i].kmer) % ks->size;
+			while (ks->array[hc].kmer != 0) {
+				ks->count_conflict++;
+				hc = (hc + 1 == ks->size) ? 0 : hc + 1;
+			}
+			ks->array[hc].kmer = nodes[i].kmer;
+			ks->array[hc].l_link = nodes[i].l_link;
+			ks->array[hc].r_link = nodes[i].r_link;
+			set_entity_fill(ks->nul_flag, hc);
+			ks->count++;
+		}
+	};
+	for (uint64_t end : S.full_block_ends) {
+		insert_until(end);
+		if (ks->count > ks->max) {
+			if (doubleHashTimes >= maxDoubleHashTimes && !alerted) {
+				// the reference drops the rest of the file here (DBGgraph.cpp:346-350); every read is kept
+				cerr << "\nAlert message: Memory reach the maximum allowed by -e " << maxDoubleHashTimes << "; all reads were kept" << endl;
+				alerted = true;
+			}
+			enlarge_kmerset_parallel(ks, 1, std::max(threadNum, 1));
+			doubleHashTimes++;
+			cerr << "Enlarge hash array size to be: " << ks->size << endl;
+			cerr << "The expanded memory used now:  " << (double)ks->size / 1000000000 * 16 << " G" << endl;
+		}
+	}
+	insert_until(~0ull);
+	KmerNode zero = {0, polyA_l, polyA_r};
+	add_node_to_kmerset(ks, &zero);  // DBGgraph.cpp:418
+	return ks;
 }
 
 static void release_session()
@@ -195,6 +256,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 	if (const char *mb = getenv("DBGK_BATCH_MB")) S->batch_limit = std::max<uint64_t>(1, strtoull(mb, NULL, 10)) << 20;
 	S->bases.reserve(S->batch_limit + (1u << 16));
 
+	S->ref_layout = getenv("DBGK_LAYOUT") && string(getenv("DBGK_LAYOUT")) == "ref";
 	dbgk_config cfg;
 	memset(&cfg, 0, sizeof cfg);
 	cfg.kmer_size = KmerSize;
@@ -202,6 +264,10 @@ void build_debruijn_graph(vector<string> &reads_files)
 	cfg.table_slots = initial_size;
 	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
 	cfg.engine = getenv("DBGK_ENGINE") ? atoi(getenv("DBGK_ENGINE")) : DBGK_ENGINE_AUTO;
+	if (S->ref_layout) {
+		cfg.engine = DBGK_ENGINE_DIRECT;
+		cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
+	}
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
 	int rc = dbgk_create(&cfg, &S->h);
 	if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
@@ -231,7 +297,21 @@ void build_debruijn_graph(vector<string> &reads_files)
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
 	}
 	KmerSet *result = NULL;
-	if (S->status == DBGK_OK) {
+	if (S->status == DBGK_OK && S->ref_layout) {
+		Kmer_total_num = st.total_kmers;
+		std::vector<dbgk_node> nodes(st.count ? st.count : 1);
+		std::vector<uint64_t> first_pos(st.count ? st.count : 1);
+		uint64_t n = 0;
+		rc = dbgk_export_first_seen_order(S->h, nodes.data(), first_pos.data(), nodes.size(), &n);
+		if (rc != DBGK_OK) {
+			fail(*S, rc, "dbgk_export_first_seen_order");
+		} else {
+			nodes.resize(n);
+			first_pos.resize(n);
+			result = replay_reference_layout(*S, nodes, first_pos, wanted, st.polyA_l_link, st.polyA_r_link);
+			if (!result) fail(*S, DBGK_ERR_NOMEM, "host table allocation");
+		}
+	} else if (S->status == DBGK_OK) {
 		Kmer_total_num = st.total_kmers;
 		bool capped = false;
 		const uint64_t host_size = final_host_size(initial_size, st.count - 1, hashLoadFactor, doubleHashTimes, capped);
@@ -296,6 +376,20 @@ int write_kmer_freq_file(const string &path, int kmer_freq_cutoff)
 	cerr << "Used branching kmer nodes:  " << ls.branch_nodes << "\t" << (double)ls.branch_nodes / ls.total_nodes << endl;
 	out << "Kmer_depth\tAppear_times\n";
 	for (int i = 1; i <= 255; i++) out << i << "\t" << ls.depth_stat[i] << endl;
+	return DBGK_OK;
+}
+
+int write_table_image(const string &path)
+{
+	// raw image of the host KmerSet: size, count, the node array, the nul_flag bytes (layout tests)
+	if (!kset) return DBGK_ERR_STATE;
+	FILE *fp = fopen(path.c_str(), "wb");
+	if (!fp) return DBGK_ERR_ARG;
+	const uint64_t hdr[2] = {kset->size, kset->count};
+	fwrite(hdr, 8, 2, fp);
+	fwrite(kset->array, sizeof(KmerNode), kset->size, fp);
+	fwrite(kset->nul_flag, 1, kset->size / 8 + 1, fp);
+	fclose(fp);
 	return DBGK_OK;
 }
 

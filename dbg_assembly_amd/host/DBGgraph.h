@@ -65,5 +65,7 @@ extern int DbgkLastStatus;
 int write_kmer_freq_file(const string &path, int kmer_freq_cutoff);
 // canonical dump (every node sorted by k-mer) of the current kset, the parity artefact
 int write_sorted_dump(const string &path);
+// raw image (size, count, node array, nul_flag) of the current kset
+int write_table_image(const string &path);
 
 #endif

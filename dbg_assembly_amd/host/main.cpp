@@ -64,6 +64,7 @@ static void usage()
 	print_options(cout, true);
 	cout << "   -h         get the help information" << endl << endl
 	     << "   environment: DBGK_DEVICE=<gpu ordinal>  DBGK_BATCH_MB=<host batch size>  DBGK_DUMP=<file: sorted node dump>" << endl
+	     << "                DBGK_LAYOUT=ref  lay the hash table out slot for slot like `debruijn_contig -t 1` of the reference" << endl
 	     << "\nExample: \ndebruijn_contig  -k 31 -r 250  -t 10  -i 0.1  -M 125 -o Ecoli reads_files.lib   2> reads_files.debruijn_contig.log \n" << endl;
 	exit(0);
 }
@@ -114,6 +115,7 @@ int main(int argc, char *argv[])
 		return 1;
 	}
 	if (const char *dump = getenv("DBGK_DUMP")) write_sorted_dump(dump);
+	if (const char *img = getenv("DBGK_DUMP_TABLE")) write_table_image(img);
 
 	if (build_contig_sequence) {
 		build_contig_sequence();

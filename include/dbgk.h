@@ -73,8 +73,15 @@ typedef struct dbgk_config {
 	                              slot range; 0 = unsharded (1 = a single shard that still follows
 	                              the exchange protocol, useful for testing it on one GPU)        */
 	uint32_t shard_index;      /* 0 .. shard_count-1                                               */
-	uint64_t reserved[3];
+	uint64_t flags;            /* DBGK_FLAG_*                                                      */
+	uint64_t reserved[2];
 } dbgk_config;
+
+/* DIRECT engine only: remember for every key the position (in pushed bases, over all pushes) of its
+ * first occurrence, so that dbgk_export_first_seen_order can list the nodes in the order in which
+ * the reference's single-threaded path first inserts them (DBGgraph.cpp:139-205 at -t 1).  Costs one
+ * extra 64-bit atomic per k-mer and 8 bytes per slot.                                            */
+#define DBGK_FLAG_TRACK_FIRST_SEEN 1ull
 
 /* totals after dbgk_finalize (the globals the reference prints, DBGgraph.cpp:410-411, and the
  * KmerSet counters of kmerSet.cpp:331-338) */
@@ -165,6 +172,12 @@ int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array,
 /* canonical dump: all nodes sorted by kmer (the parity artefact of SURVEY.md section 8(a)).
  * `capacity` = number of nodes `out` can hold (>= stats.count).                                  */
 int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out);
+
+/* all non-zero-key nodes sorted by the position of their first occurrence (needs
+ * DBGK_FLAG_TRACK_FIRST_SEEN): out[i] and first_pos[i] (index into the concatenation of everything
+ * pushed) for i < *n_out.  Replaying out[] through the reference's sequential insert and enlarge
+ * schedule reproduces its -t 1 slot layout (host side: DBGK_LAYOUT=ref).   */
+int dbgk_export_first_seen_order(dbgk_handle *h, dbgk_node *out, uint64_t *first_pos, uint64_t capacity, uint64_t *n_out);
 
 /* order-independent digest of the node multiset: sum over nodes of
  * mix64(kmer ^ mix64((l_link << 32) | r_link)) mod 2^64, mix64 = splitmix64 finaliser             */

@@ -264,14 +264,26 @@ def write_dump(path, nodes, total_reads, total_kmers, count):
             fh.write("%d\t%08x\t%08x\n" % (int(r["kmer"]), int(r["l_link"]), int(r["r_link"])))
 
 
+def read_table_image(path):
+    """raw table image written by ref_driver.cpp -T / DBGK_DUMP_TABLE: (size, count, array, nul_flag)"""
+    raw = open(path, "rb").read()
+    size, count = np.frombuffer(raw[:16], dtype=np.uint64)
+    size, count = int(size), int(count)
+    array = np.frombuffer(raw[16:16 + size * 16], dtype=NODE_DTYPE)
+    flags = np.frombuffer(raw[16 + size * 16:16 + size * 16 + size // 8 + 1], dtype=np.uint8)
+    return size, count, array, flags
+
+
 def ref_build(lib_file, k=31, max_read_len=250, threads=1, init_hash_size=0.001, load_factor=0.7,
-              max_double=10, buffer_num=10000, fmt=2, dump=None, timeout=600):
+              max_double=10, buffer_num=10000, fmt=2, dump=None, timeout=600, image=None):
     """Run the real reference (oracle/_ref/ref_dbg build ...).  Returns its JSON summary."""
     cmd = [REF_BIN, "build", "-k", str(k), "-r", str(max_read_len), "-f", str(fmt), "-t", str(threads),
            "-i", repr(float(init_hash_size)), "-l", repr(float(load_factor)), "-e", str(max_double),
            "-b", str(buffer_num), "-q"]
     if dump:
         cmd += ["-d", dump]
+    if image:
+        cmd += ["-T", image]
     cmd.append(lib_file)
     out = subprocess.run(cmd, check=True, capture_output=True, timeout=timeout, text=True).stdout
     return json.loads(out.strip().splitlines()[-1])

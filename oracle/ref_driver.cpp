@@ -11,7 +11,8 @@
 // parity artefact: every non-null slot's (kmer, l_link, r_link), sorted by kmer.
 //
 // Sub-commands
-//   ref_dbg build [-k -r -f -t -i -l -e -b as in main.cpp:166] [-d dump.txt] [-q] <reads.lib>
+//   ref_dbg build [-k -r -f -t -i -l -e -b as in main.cpp:166] [-d dump.txt] [-T table.img] [-q] <reads.lib>
+//                 -T writes the raw table image (size, count, node array, nul_flag): the slot LAYOUT
 //   ref_dbg kat                        known-answer values of the codec / hash helpers
 //   ref_dbg prime <n> [<n> ...]        find_next_prime(n)
 #include "DBGgraph.h"
@@ -24,11 +25,11 @@
 
 static int cmd_build(int argc, char **argv)
 {
-	std::string dump_path;
+	std::string dump_path, image_path;
 	int quiet = 0;
 	int c;
 	optind = 1;
-	while ((c = getopt(argc, argv, "k:r:f:t:i:l:e:b:d:q")) != -1) {
+	while ((c = getopt(argc, argv, "k:r:f:t:i:l:e:b:d:T:q")) != -1) {
 		switch (c) {
 			case 'k': KmerSize = atoi(optarg); break;
 			case 'r': maxReadLen = atoi(optarg); break;
@@ -39,6 +40,7 @@ static int cmd_build(int argc, char **argv)
 			case 'e': maxDoubleHashTimes = atoi(optarg); break;
 			case 'b': BufferNum = atoi(optarg); break;
 			case 'd': dump_path = optarg; break;
+			case 'T': image_path = optarg; break;
 			case 'q': quiet = 1; break;
 			default: return 2;
 		}
@@ -63,6 +65,15 @@ static int cmd_build(int argc, char **argv)
 	       (unsigned long long)kset->max, (unsigned long long)kset->count_conflict,
 	       threadNum, wall);
 
+	if (!image_path.empty()) {
+		FILE *fp = fopen(image_path.c_str(), "wb");
+		if (!fp) { perror("image"); return 4; }
+		const uint64_t hdr[2] = {kset->size, kset->count};
+		fwrite(hdr, 8, 2, fp);
+		fwrite(kset->array, sizeof(KmerNode), kset->size, fp);
+		fwrite(kset->nul_flag, 1, kset->size / 8 + 1, fp);
+		fclose(fp);
+	}
 	if (!dump_path.empty()) {
 		std::vector<KmerNode> nodes;
 		nodes.reserve(kset->count);

@@ -68,3 +68,27 @@ def test_cli_small_batches_and_device_resize(tmp_path):
     r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_MB": "1"})
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert "Enlarge device hash array size" in r.stderr
+
+
+LAYOUT_CASES = [c for c in FILE_CASES if c["name"] in ("mixed150_k31", "enlarge_b50", "block_b7", "polyA_k31", "fastq_gz_k31",
+                                                        "lengths_k31_r100", "even_k32", "saturate_k31")]
+
+
+@pytest.mark.parametrize("case", LAYOUT_CASES, ids=[c["name"] for c in LAYOUT_CASES])
+def test_cli_reference_layout_mode(tmp_path, oracle, case):
+    """DBGK_LAYOUT=ref: the host KmerSet is slot-for-slot the table the reference builds at -t 1
+    (same size after the same enlarges, every node in the same slot, same nul_flag) -- checked
+    against the oracle's sequential path, which tests/test_oracle_vs_ref_live.py pins to the real
+    reference's layout."""
+    p = case["params"]
+    img = tmp_path / "table.img"
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_LAYOUT": "ref", "DBGK_DUMP_TABLE": str(img), "DBGK_BATCH_MB": "1"})
+    assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
+    size, count, array, flags = oracle.read_table_image(str(img))
+    res = oracle.build_graph(files=case_files(case), k=p["k"], max_read_len=p["max_read_len"], threads=1,
+                             init_hash_size=p["init_hash_size"], load_factor=p["load_factor"], max_double=p["max_double"],
+                             buffer_num=p["buffer_num"], fmt=p["fmt"], want_table=True)
+    assert (size, count) == (res.size, res.count)
+    import numpy as np
+    assert np.array_equal(array, res.table)
+    assert np.array_equal(flags, res.nul_flag)

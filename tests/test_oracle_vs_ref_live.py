@@ -59,3 +59,24 @@ def test_oracle_equals_reference(oracle, tmp_path, k, b, i, t, r, fmt):
         one = oracle.build_graph(files=[f1, f2], k=k, max_read_len=r, threads=1, init_hash_size=i,
                                  buffer_num=b, fmt=fmt)
         assert one.conflict == js["conflict"]  # same insertion order => same probe count
+
+
+@pytest.mark.parametrize("k,b,i", [(31, 200, 0.0001), (21, 60, 0.00001), (17, 37, 0.00001)])
+def test_oracle_t1_layout_equals_reference_t1_layout(oracle, tmp_path, k, b, i):
+    """slot-for-slot: the oracle's sequential path reproduces the layout of the reference at -t 1,
+    enlarges included (what DBGK_LAYOUT=ref is checked against on the GPU box)"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/ref_dbg not built (no /root/reference here)")
+    rng = random.Random(k * b)
+    reads = _reads(rng, 900)
+    f1, f2 = str(tmp_path / "a.fa"), str(tmp_path / "b.fa")
+    oracle.write_reads_file(f1, reads[:500])
+    oracle.write_reads_file(f2, reads[500:])
+    libf = str(tmp_path / "reads.lib")
+    open(libf, "w").write(f1 + "\n" + f2 + "\n")
+    img = str(tmp_path / "table.img")
+    oracle.ref_build(libf, k=k, threads=1, init_hash_size=i, buffer_num=b, fmt=2, image=img, timeout=120)
+    size, count, array, flags = oracle.read_table_image(img)
+    res = oracle.build_graph(files=[f1, f2], k=k, threads=1, init_hash_size=i, buffer_num=b, fmt=2, want_table=True)
+    assert (res.size, res.count) == (size, count) and res.double_times >= (1 if i < 0.0001 else 0)
+    assert np.array_equal(res.table, array) and np.array_equal(res.nul_flag, flags)
