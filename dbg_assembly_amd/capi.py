@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libdbgk.so")
 NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
 
 OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
-ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ, ENGINE_SEEDIDX = 0, 1, 2, 3, 4
 FLAG_TRACK_FIRST_SEEN = 1
 
 
@@ -89,6 +89,8 @@ SYMBOLS = [
     ("dbgk_export_first_seen_order", _i, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
+    ("dbgk_seed_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_seed_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
     ("dbgk_kfreq_export_bits", _i, [_vp, C.c_uint32, _u64, _u64, _vp]),
     ("dbgk_extract_kmers", _i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
@@ -292,6 +294,22 @@ class Graph:
         _chk(lib().dbgk_refresh_stats(self._h, C.byref(st)), "dbgk_refresh_stats")
         self.stats = st
         return st
+
+    # ---- SEEDIDX engine
+    SEED_DTYPE = np.dtype([("kmer", "<u8"), ("payload", "<u8")])  # payload = {id:32, pos:30, freq:1, direct:1}
+
+    def seed_export_sorted(self):
+        n = int(self.stats.count)
+        out = np.zeros(max(n, 1), dtype=self.SEED_DTYPE)
+        got = C.c_uint64()
+        _chk(lib().dbgk_seed_export_sorted(self._h, out.ctypes.data, n, C.byref(got)), "dbgk_seed_export_sorted")
+        return out[:got.value]
+
+    def seed_export_host_table(self, host_size):
+        array = np.zeros(host_size, dtype=self.SEED_DTYPE)
+        flags = np.zeros(host_size // 8 + 1, dtype=np.uint8)
+        _chk(lib().dbgk_seed_export_host_table(self._h, host_size, array.ctypes.data, flags.ctypes.data), "dbgk_seed_export_host_table")
+        return array, flags
 
     # ---- KFREQ engine
     def kfreq_counts(self, first=0, n=None):

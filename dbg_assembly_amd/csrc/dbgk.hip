@@ -98,6 +98,7 @@ struct dbgk_handle {
 	unsigned long long *first_pos = nullptr; // [tslots]
 	uint64_t pos_base = 0;                   // bases pushed so far
 
+	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
 	uint8_t *counts = nullptr;
@@ -288,7 +289,7 @@ static int plan_partition(dbgk_handle *h)
 	memset(&h->geom, 0, sizeof h->geom);
 	h->tslots = h->size;
 	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
-	const int want = h->cfg.engine;
+	const int want = h->cfg.engine == DBGK_ENGINE_SEEDIDX ? DBGK_ENGINE_DIRECT : h->cfg.engine; // the seed index uses the plain table
 	const bool want_shard = h->cfg.shard_count >= 1; // shard_count == 1: one-rank sharded handle (same protocol, for testing)
 	if (want_shard && h->cfg.shard_index >= n_ranks) return DBGK_ERR_ARG;
 	if (!want_shard) {
@@ -390,8 +391,10 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	const bool kfreq = cfg->engine == DBGK_ENGINE_KFREQ;
 	if (kfreq && cfg->kmer_size > 18) return DBGK_ERR_ARG; // 4^18 bytes = 64 GiB
 	if (!kfreq && cfg->table_slots < 3) return DBGK_ERR_ARG;
-	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION && !kfreq)
+	const bool seed = cfg->engine == DBGK_ENGINE_SEEDIDX;
+	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION && !kfreq && !seed)
 		return DBGK_ERR_ARG;
+	if (seed && (cfg->shard_count || (cfg->flags & DBGK_FLAG_TRACK_FIRST_SEEN))) return DBGK_ERR_ARG;
 
 	int n_dev = 0;
 	hipError_t e = hipGetDeviceCount(&n_dev);
@@ -406,6 +409,8 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->cfg = *cfg;
 	h->device = cfg->device_id;
 	h->kfreq = kfreq;
+	h->seed = seed;
+	if (seed) h->cfg.max_read_len = 0x7FFFFFFF; // contigs are never trimmed (the pos field bounds them, see push)
 	h->size = kfreq ? 3 : cfg->table_slots;
 	h->magic = make_mod_magic(h->size);
 	h->tslots = h->size;
@@ -566,6 +571,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */)
 {
 	if (n_reads == 0) return DBGK_OK;
+	if (h->seed) has_long = 1; // the dead bitmap carries the 'N' positions
 	const uint64_t words = bitmap_words(n_bases);
 	TimedSpan sp;
 	int rc = span_begin(h, PH_MARK, sp);
@@ -575,6 +581,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, sizeof(unsigned int), h->stream));
 	hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
 	                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr);
+	if (h->seed && n_bases)
+		hipLaunchKernelGGL(k_mark_n, dim3(grid_for(h, (n_bases + 31) >> 5)), dim3(kBlock), 0, h->stream, d_bases, n_bases, d_dead);
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
@@ -583,6 +591,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		HIPCHK(hipStreamSynchronize(h->stream));
 		has_long = h->h_ctr->any_dead ? 1 : 0;
 	}
+	const uint64_t id_base = h->total_reads; // contig index of the batch's first sequence (SEEDIDX)
 	h->total_reads += n_reads;
 	if (n_bases == 0) return DBGK_OK;
 
@@ -590,7 +599,9 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
-	if (h->kfreq) {
+	if (h->seed) {
+		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
+	} else if (h->kfreq) {
 		if (has_long)
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
@@ -644,6 +655,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 {
 	if (!h || !offsets || (n_reads && !bases && offsets[n_reads] != offsets[0])) return DBGK_ERR_ARG;
 	if (h->finalized) return DBGK_ERR_STATE;
+	if (h->seed && h->total_reads + n_reads > 0xFFFFFFFFull) return DBGK_ERR_ARG; // id is a 32-bit field
 	int rc = use_device(h);
 	if (rc) return rc;
 	uint64_t r0 = 0;
@@ -667,6 +679,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
 			s.h_offsets[i] = offsets[r0 + i] - base0;
 			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
+			if (h->seed && i && s.h_offsets[i] - s.h_offsets[i - 1] >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
 		}
 		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
@@ -718,6 +731,7 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 	out->stored_kmers = c.stored_kmers;
 	// + the key-0 node, always present (DBGgraph.cpp:418); of a sharded table only shard 0 reports it
 	out->count = c.n_new + ((h->sharded && h->geom.rank != 0) ? 0 : 1);
+	if (h->seed) out->count = c.n_new + (c.polyA_links ? 1 : 0); // key 0 is an ordinary key of the seed index
 	out->count_conflict = c.n_conflict;
 	out->table_slots = h->tslots;
 	out->polyA_l_link = (uint32_t)(c.polyA_links & 0xFFFFFFFFu);
@@ -841,6 +855,7 @@ __global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restri
 
 extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -895,6 +910,7 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 
 extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out || !n_out) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -998,6 +1014,7 @@ extern "C" int dbgk_export_first_seen_order(dbgk_handle *h, dbgk_node *out, uint
 
 extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !digest) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -1021,6 +1038,7 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 
 extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_stats *out)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -1047,6 +1065,95 @@ extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_
 	out->tip_nodes = (int64_t)res[259];
 	out->branch_nodes = (int64_t)res[260];
 	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEEDIDX exports
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_seed_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)
+{
+	if (!h || !out || !n_out) return DBGK_ERR_ARG;
+	if (!h->seed || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t n = h->h_ctr->n_new;
+	const uint64_t z = h->h_ctr->polyA_links ? 1 : 0;
+	*n_out = n + z;
+	if (capacity < n + z) return DBGK_ERR_CAPACITY;
+	if (z) {
+		const uint64_t w = seed_payload_out(h->h_ctr->polyA_links);
+		out[0].kmer = 0;
+		out[0].l_link = (uint32_t)w;
+		out[0].r_link = (uint32_t)(w >> 32);
+	}
+	if (n == 0) return DBGK_OK;
+	uint64_t *d_keys = nullptr, *d_links = nullptr;
+	unsigned long long *d_cursor = nullptr;
+	auto cleanup = [&]() {
+		for (void *p : {(void *)d_keys, (void *)d_links, (void *)d_cursor})
+			if (p) (void)hipFree(p);
+	};
+	if (hipMalloc(&d_keys, n * 8) != hipSuccess || hipMalloc(&d_links, n * 8) != hipSuccess || hipMalloc(&d_cursor, 8) != hipSuccess) {
+		cleanup();
+		return DBGK_ERR_NOMEM;
+	}
+	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_compact, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_keys, d_links, d_cursor, n);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) { cleanup(); return hip_fail(e, "seed_export_sorted/compact", __LINE__); }
+	rc = dbgk_internal_sort_pairs(d_keys, d_links, n, h->stream);
+	if (rc != DBGK_OK) { cleanup(); return rc; }
+	std::vector<uint64_t> hk(n), hl(n);
+	e = hipMemcpyAsync(hk.data(), d_keys, n * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(hl.data(), d_links, n * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	cleanup();
+	if (e != hipSuccess) return hip_fail(e, "seed_export_sorted/copy", __LINE__);
+	for (uint64_t i = 0; i < n; i++) {
+		const uint64_t w = seed_payload_out(hl[i]);
+		out[i + z].kmer = hk[i];
+		out[i + z].l_link = (uint32_t)w;
+		out[i + z].r_link = (uint32_t)(w >> 32);
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_seed_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
+{
+	if (!h || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
+	if (!h->seed || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
+	Node *tmp = nullptr;
+	uint8_t *d_flags = nullptr;
+	if (hipMalloc(&tmp, host_size * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&d_flags, host_size / 8 + 1) != hipSuccess) {
+		(void)hipFree(tmp);
+		return DBGK_ERR_NOMEM;
+	}
+	TableRef T{tmp, host_size, make_mod_magic(host_size)};
+	hipError_t e = hipMemsetAsync(tmp, 0, host_size * sizeof(Node), h->stream);
+	if (e == hipSuccess) {
+		// always through a copy: the payload words are converted in place to the reference's bit-field
+		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, T, h->d_ctr,
+		                   (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
+		hipLaunchKernelGGL(k_seed_convert, dim3(grid_for(h, host_size)), dim3(kBlock), 0, h->stream, tmp, host_size);
+		hipLaunchKernelGGL(k_seed_place_key0, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
+		hipLaunchKernelGGL(k_build_flags_ctr, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, tmp, host_size, h->d_ctr, d_flags);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(array, tmp, host_size * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(tmp);
+	(void)hipFree(d_flags);
+	if (e != hipSuccess) return hip_fail(e, "seed_export_host_table", __LINE__);
+	return (h->h_ctr->error & 1u) ? DBGK_ERR_TABLE_FULL : DBGK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1147,6 +1254,7 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE; // a sharded table is already owned by slot range
@@ -1178,6 +1286,7 @@ __global__ void k_write_polyA_node(Node *out, uint64_t index, const Counters *ct
 
 extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !d_nodes || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE;
@@ -1209,6 +1318,7 @@ extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node
 
 extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n)
 {
+	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
 	if ((uintptr_t)d_nodes & 15u) return DBGK_ERR_ARG;

@@ -195,6 +195,7 @@ struct Triple {
 	uint64_t key;
 	uint32_t lb, rb;
 	bool valid;
+	bool strict_fwd; // forward k-mer strictly smaller than its reverse complement
 };
 
 // k-mer starting at the window's current first base, then slide by one base
@@ -217,6 +218,7 @@ __device__ __forceinline__ Triple next_triple(LaneWindow &w, uint32_t i, int k, 
 		has_right = has_right && !((w.D >> k) & 1ull);
 	}
 	const uint64_t rc = revcomp_kbit(kbit, k);
+	t.strict_fwd = kbit < rc;
 	if (kbit <= rc) {
 		t.key = kbit;
 		t.lb = has_left ? left : 4u;
@@ -429,6 +431,134 @@ __global__ __launch_bounds__(kBlock) void k_counts_summary(const uint8_t *__rest
 		if (a) atomicAdd(&out[0], a);
 		if (b) atomicAdd(&out[1], b);
 	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEEDIDX engine: the seed index of the link_scaffold module,
+// chop_contig_to_kmerset (link_scaffold/map_func.cpp:119-173) over add_kmerset
+// (link_scaffold/kmerSet.cpp:168-210).  Every k-mer of every contig, windows never span an
+// upper-case 'N' (scaffold_to_contig :303-324; 'n' counts as A like every other use of alphabet[]);
+// canonical by STRICT '<' (:160: a palindrome is stored with direct = 0); payload of a key = contig
+// index, position and strand of its FIRST occurrence in (contig, position) order, freq = 1 only
+// while the key has been seen once.  "First" is made order-free by keeping the minimum
+// (contig, position): payload word while building = id << 32 | (pos + 1) << 2 | direct << 1 | dup,
+// 0 = never written.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t seed_merge(uint64_t old, uint64_t mine)
+{
+	if (old == 0ull) return mine;
+	return (((old >> 2) <= (mine >> 2)) ? old : mine) | 1ull; // earlier occurrence wins, key no longer unique
+}
+
+__device__ __forceinline__ void seed_cas_merge(unsigned long long *addr, uint64_t guess, uint64_t mine)
+{
+	uint64_t old = guess;
+	for (;;) {
+		const uint64_t upd = seed_merge(old, mine);
+		if (upd == old) return;
+		const uint64_t prev = atomicCAS(addr, (unsigned long long)old, (unsigned long long)upd);
+		if (prev == old) return;
+		old = prev;
+	}
+}
+
+// dead bit on every upper-case 'N' (one thread per 32 positions)
+__global__ __launch_bounds__(kBlock) void k_mark_n(const char *__restrict__ bases, uint64_t n_bases, uint32_t *__restrict__ dead_bits)
+{
+	const uint64_t n_words = (n_bases + 31u) >> 5;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < n_words; w += stride) {
+		uint32_t mask = 0;
+		for (uint32_t j = 0; j < 32u; j++) {
+			const uint64_t p = w * 32u + j;
+			if (p < n_bases && bases[p] == 'N') mask |= 1u << j;
+		}
+		if (mask) atomicOr(&dead_bits[w], mask);
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void k_seed_insert(ReadBatch rb, const uint64_t *__restrict__ offsets, uint64_t n_contigs,
+                                                        uint64_t id_base, TableRef T, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x; chunk < n_chunks; chunk += stride) {
+		LaneWindow w = load_lane_window<true>(rb, chunk);
+		const uint64_t p0 = chunk * 16u;
+		uint64_t lo = 0, hi = n_contigs; // offsets[lo] <= p0 < offsets[hi]; ties (empty contigs) resolve to the last one
+		while (hi - lo > 1) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (offsets[mid] <= p0) lo = mid; else hi = mid;
+		}
+		uint64_t cid = lo, cur_off = offsets[lo], next_off = offsets[lo + 1];
+		for (uint32_t i = 0; i < kPosPerLane; i++) {
+			const Triple t = next_triple<true>(w, i, rb.k, rb.n_bases);
+			const uint64_t p = p0 + i;
+			while (p >= next_off && cid + 1 < n_contigs) {
+				cid++;
+				cur_off = next_off;
+				next_off = offsets[cid + 1];
+			}
+			if (!t.valid) continue;
+			const uint64_t mine = ((id_base + cid) << 32) | ((p - cur_off + 1ull) << 2) | (t.strict_fwd ? 2ull : 0ull);
+			if (t.key == 0ull) {
+				seed_cas_merge(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links), mine);
+				continue;
+			}
+			const uint64_t slot = fast_mod(hash_code(t.key), T.magic);
+			const uint4 v = *reinterpret_cast<const uint4 *>(&T.nodes[slot]);
+			Node first;
+			first.kmer = ((uint64_t)v.y << 32) | v.x;
+			first.links = ((uint64_t)v.w << 32) | v.z;
+			uint64_t guess;
+			const uint64_t s = find_or_claim(T, t.key, slot, first, guess, n_new, n_conf);
+			if (s == ~0ull) { full = true; continue; }
+			seed_cas_merge(reinterpret_cast<unsigned long long *>(&T.nodes[s].links), guess, mine);
+		}
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// build-time payload -> the reference's bit-field word {id:32, pos:30, freq:1, direct:1}
+// (link_scaffold/kmerSet.h:54-61, first field in the low bits)
+__host__ __device__ __forceinline__ uint64_t seed_payload_out(uint64_t w)
+{
+	if (w == 0ull) return 0ull;
+	const uint64_t id = w >> 32, pos = ((w >> 2) & 0x3FFFFFFFull) - 1ull, direct = (w >> 1) & 1ull, dup = w & 1ull;
+	return id | (pos << 32) | ((dup ^ 1ull) << 62) | (direct << 63);
+}
+
+__global__ __launch_bounds__(kBlock) void k_seed_convert(Node *__restrict__ nodes, uint64_t size)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < size; i += stride) nodes[i].links = seed_payload_out(nodes[i].links);
+}
+
+// place the key-0 node (only if key 0 was seen) on its probe chain; the slot keeps kmer == 0
+__global__ void k_seed_place_key0(TableRef T, Counters *ctr)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	ctr->polyA_slot = ~0ull;
+	if (ctr->polyA_links == 0ull) return;
+	uint64_t slot = fast_mod(hash_code(0ull), T.magic);
+	for (uint64_t steps = 0; steps < T.size; steps++) {
+		if (T.nodes[slot].kmer == 0ull) {
+			T.nodes[slot].links = seed_payload_out(ctr->polyA_links);
+			ctr->polyA_slot = slot;
+			return;
+		}
+		slot = (slot + 1 == T.size) ? 0 : slot + 1;
+	}
+	atomicOr(&ctr->error, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------

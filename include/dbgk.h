@@ -51,6 +51,8 @@ typedef struct dbgk_handle dbgk_handle;
 #define DBGK_ENGINE_AUTO       0
 #define DBGK_ENGINE_DIRECT     1  /* fused extract + 64-bit-atomic insert into the global table      */
 #define DBGK_ENGINE_PARTITION  2  /* extract -> radix-partitioned records -> LDS-built table regions */
+#define DBGK_ENGINE_SEEDIDX    4  /* link_scaffold's seed index: every k-mer of the pushed CONTIGS -> (contig
+                                     index, position, strand) of its first occurrence + uniqueness flag   */
 #define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
                                      canonical k-mers (the correct_error module's frequency table);
                                      table_slots is ignored, k <= 18                                */
@@ -196,6 +198,19 @@ int dbgk_link_stats_device(dbgk_handle *h, int32_t kmer_freq_cutoff, dbgk_link_s
 int dbgk_kfreq_export_counts(dbgk_handle *h, uint64_t first_kmer, uint64_t n, uint8_t *host_out);
 /* n_bytes bytes of the bit table starting at byte first_byte: bit set when count > cutoff          */
 int dbgk_kfreq_export_bits(dbgk_handle *h, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out);
+
+/* ---- SEEDIDX engine: the contig k-mer index of the link_scaffold module ----------
+ * chop_contig_to_kmerset (link_scaffold/map_func.cpp:119-173): push the contig sequences with
+ * dbgk_push_reads (contig index = order of pushing; windows never span an upper-case 'N'), finalize,
+ * export.  Nodes come out as the reference's 16-byte KmerNode of THAT module
+ * (link_scaffold/kmerSet.h:54-61): kmer, then one 64-bit word {id:32, pos:30, freq:1, direct:1}
+ * (low bits first) -- held in dbgk_node as l_link = low dword, r_link = high dword.  Key 0 is an
+ * ordinary key here (the reference tests emptiness with nul_flag, not kmer == 0).
+ * dbgk_seed_export_host_table fills a table every key of which is reachable from
+ * hash_code(key) % host_size without crossing a clear nul_flag bit (exist_kmerset,
+ * link_scaffold/kmerSet.cpp:216-238).                                                              */
+int dbgk_seed_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out);
+int dbgk_seed_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
 
 /* ---- phase A alone (parity of the extraction kernel) ------------------------------------------ */
 

@@ -386,3 +386,103 @@ def ref_kfreq_load(path, k, one_bit=True, threads_or_cutoff=4, timeout=600):
         r = subprocess.run([exe, path, str(k), str(threads_or_cutoff), out], check=True, capture_output=True,
                            text=True, timeout=timeout)
         return np.fromfile(out, dtype=np.uint8), json.loads(r.stdout.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# link_scaffold seed index: restatement of chop_contig_to_kmerset
+# (link_scaffold/map_func.cpp:119-173) over add_kmerset (link_scaffold/kmerSet.cpp:168-210).
+# Pinned against the real code through oracle/_ref/ref_seed (tests/test_seedidx.py).
+# ------------------------------------------------------------------------------------------------
+REF_SEED = os.path.join(HERE, "_ref", "ref_seed")
+SEED_DTYPE = np.dtype([("kmer", "<u8"), ("id", "<u4"), ("pos", "<u4"), ("freq", "u1"), ("direct", "u1")])
+_CODE = np.zeros(256, dtype=np.uint64)  # alphabet[] (link_scaffold/seqKmer.cpp:8-24): A a N n -> 0, C c 1, G g 2, T t 3
+for _ch, _v in (("C", 1), ("c", 1), ("G", 2), ("g", 2), ("T", 3), ("t", 3)):
+    _CODE[ord(_ch)] = _v
+
+
+def seed_index(contigs, k):
+    """Every k-mer of every contig; windows never span an upper-case 'N' (scaffold_to_contig,
+    map_func.cpp:303-324); canonical by strict '<' (map_func.cpp:160-166); a key keeps the
+    (id, pos, direct) of its first occurrence in (contig, position) order and freq = 1 only while it
+    was added once (kmerSet.cpp:179-201).  Blocks shorter than k hold no k-mer (the reference reads
+    out of bounds for blocks shorter than k - 1; not exercised).  Returns nodes sorted by kmer."""
+    keys, ids, poss, dirs = [], [], [], []
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    for cid, seq in enumerate(contigs):
+        raw = np.frombuffer(seq.encode() if isinstance(seq, str) else seq, dtype=np.uint8)
+        n = raw.size - k + 1
+        if n <= 0:
+            continue
+        code = _CODE[raw]
+        is_n = (raw == ord("N")).astype(np.int64)
+        csum = np.concatenate([[0], np.cumsum(is_n)])
+        ok = (csum[k:] - csum[:-k]) == 0  # no 'N' inside the window
+        fwd = np.zeros(n, dtype=np.uint64)
+        rc = np.zeros(n, dtype=np.uint64)
+        for j in range(k):
+            c = code[j:j + n]
+            fwd = (fwd << np.uint64(2)) | c
+            rc |= (np.uint64(3) - c) << np.uint64(2 * j)
+        fwd &= mask
+        direct = fwd < rc
+        key = np.where(direct, fwd, rc)
+        pos = np.nonzero(ok)[0]
+        keys.append(key[pos]); ids.append(np.full(pos.size, cid, dtype=np.uint32))
+        poss.append(pos.astype(np.uint32)); dirs.append(direct[pos].astype(np.uint8))
+    if not keys:
+        return np.zeros(0, dtype=SEED_DTYPE)
+    key = np.concatenate(keys); cid = np.concatenate(ids); pos = np.concatenate(poss); direct = np.concatenate(dirs)
+    uniq, first, counts = np.unique(key, return_index=True, return_counts=True)  # first = first occurrence in input order
+    out = np.zeros(uniq.size, dtype=SEED_DTYPE)
+    out["kmer"] = uniq
+    out["id"] = cid[first]
+    out["pos"] = pos[first]
+    out["direct"] = direct[first]
+    out["freq"] = (counts == 1).astype(np.uint8)
+    return out
+
+
+def seed_payload(nodes):
+    """the reference's bit-field word {id:32, pos:30, freq:1, direct:1} (link_scaffold/kmerSet.h:54-61)"""
+    return (nodes["id"].astype(np.uint64) | (nodes["pos"].astype(np.uint64) << np.uint64(32))
+            | (nodes["freq"].astype(np.uint64) << np.uint64(62)) | (nodes["direct"].astype(np.uint64) << np.uint64(63)))
+
+
+def seed_unpack(kmer, payload):
+    out = np.zeros(len(kmer), dtype=SEED_DTYPE)
+    payload = np.asarray(payload, dtype=np.uint64)
+    out["kmer"] = kmer
+    out["id"] = (payload & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    out["pos"] = ((payload >> np.uint64(32)) & np.uint64(0x3FFFFFFF)).astype(np.uint32)
+    out["freq"] = ((payload >> np.uint64(62)) & np.uint64(1)).astype(np.uint8)
+    out["direct"] = (payload >> np.uint64(63)).astype(np.uint8)
+    return out
+
+
+def write_contig_fasta(path, contigs, width=0):
+    with open(path, "w") as f:
+        for i, s in enumerate(contigs):
+            f.write(">ctg%d len=%d\n" % (i, len(s)))
+            if width:
+                for j in range(0, len(s), width):
+                    f.write(s[j:j + width] + "\n")
+            else:
+                f.write(s + "\n")
+
+
+def parse_seed_dump(path):
+    with open(path) as f:
+        head = f.readline().split()
+        meta = {"contigs": int(head[1]), "size": int(head[3]), "count": int(head[5])}
+        rows = [tuple(int(x) for x in line.split()) for line in f]
+    return meta, np.array(rows, dtype=SEED_DTYPE) if rows else np.zeros(0, dtype=SEED_DTYPE)
+
+
+def have_ref_seed():
+    return os.path.exists(REF_SEED)
+
+
+def ref_seed(fasta, k, dump, hash_size=0, load_factor=0.5, timeout=600):
+    subprocess.run([REF_SEED, fasta, str(k), str(hash_size), str(load_factor), dump], check=True, timeout=timeout,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return parse_seed_dump(dump)
