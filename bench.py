@@ -139,15 +139,20 @@ def main():
     engine = HipEngine(g, device)
 
     debug_mode = int(os.environ.get("DBGK_DEBUG_MODE", "0"))  # kernel timing experiments: results are wrong
+    debug_l2 = int(os.environ.get("DBGK_DEBUG_L2", "0")) or int(os.environ.get("DBGK_DEBUG_BUILD", "0"))
 
     def step():
         g.reset()
         g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
-        if debug_mode:
+        if debug_mode:  # level-1 timing experiments leave garbage records: never run the later phases on them
+            g.sync()
+            return {"stored_kmers": n_reads * kpr, "count": 0}
+        if debug_l2:    # level-2 timing experiment: the library refuses to build regions afterwards
             try:
-                st = g.finalize()
+                g.finalize()
             except capi.DbgkError:
-                st = g.refresh_stats() if False else capi.Stats()
+                pass
+            g.sync()
             return {"stored_kmers": n_reads * kpr, "count": 0}
         if sharded:
             return sharded_finalize(g, device)

@@ -371,14 +371,24 @@ static int setup_partition(dbgk_handle *h)
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		return DBGK_ERR_NOMEM;
 	}
+	h->geom.stagger = getenv("DBGK_STAGGER") ? (uint32_t)atoi(getenv("DBGK_STAGGER")) : 0u;
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	return DBGK_OK;
 }
 
@@ -610,10 +620,17 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-		if (dbg_mode == 1)
+		const bool wide_d = h->geom.size >= (1ull << 31); // divisor needs the 2-by-1 division steps
+		if (wide_d && has_long)
+			hipLaunchKernelGGL((k_extract_scatter<true, 0, true>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (wide_d)
+			hipLaunchKernelGGL((k_extract_scatter<false, 0, true>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (dbg_mode == 1)
 			hipLaunchKernelGGL((k_extract_scatter<false, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode == 2)
 			hipLaunchKernelGGL((k_extract_scatter<false, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (dbg_mode == 3)
+			hipLaunchKernelGGL((k_extract_scatter<false, 3>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (has_long)
 			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else
@@ -746,16 +763,40 @@ static int build_from_records(dbgk_handle *h)
 	int rc = span_begin(h, PH_PARTITION, sp);
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, G, h->store, h->tile_prefix);
-	hipLaunchKernelGGL(k_scatter_l2, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
+	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0; // timing experiments, results are wrong
+	if (dbg_l2 == 1)
+		hipLaunchKernelGGL(k_scatter_l2<1>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
+	else if (dbg_l2 == 2)
+		hipLaunchKernelGGL(k_scatter_l2<2>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
+	else if (dbg_l2 == 3)
+		hipLaunchKernelGGL(k_scatter_l2<3>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
+	else
+		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
+	if (dbg_l2) { // never build regions from the garbage a timing experiment leaves behind
+		g_last_error = "DBGK_DEBUG_L2 set: level-2 timing experiment, no table was built";
+		return DBGK_ERR_STATE;
+	}
 	rc = span_begin(h, PH_BUILD, sp);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_build_regions, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0; // timing experiments, results are wrong
+	if (dbg_build == 1)
+		hipLaunchKernelGGL(k_build_regions<1>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	else if (dbg_build == 2)
+		hipLaunchKernelGGL(k_build_regions<2>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	else if (dbg_build == 3)
+		hipLaunchKernelGGL(k_build_regions<3>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
+	else
+		hipLaunchKernelGGL(k_build_regions<0>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
+	if (dbg_build) {
+		g_last_error = "DBGK_DEBUG_BUILD set: build timing experiment, the table is garbage";
+		return DBGK_ERR_STATE;
+	}
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;

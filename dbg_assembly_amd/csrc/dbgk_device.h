@@ -103,6 +103,24 @@ __device__ __forceinline__ uint32_t divmod_u64_u32(uint64_t h, const Div32Magic 
 	return r2 >> g.s;
 }
 
+// h = q * d + r for d < 2^31 with m = floor(2^64 / d) (ModMagic): mulhi(h, m) is q or q - 1, so the
+// estimate's remainder is < 2d < 2^32 and 32-bit wrap-around arithmetic gives it exactly.  Integer
+// multiplies issue at full rate on gfx950 (profiles/ubench/alu_rate.hip), which makes this ~13
+// instructions against ~35 for the two 2-by-1 steps above.
+__device__ __forceinline__ uint32_t divmod_magic_small(uint64_t h, uint64_t m, uint32_t d, uint64_t &q_out)
+{
+	const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32), m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+	const uint64_t t1 = (uint64_t)h1 * m0 + __umulhi(h0, m0);
+	const uint64_t t2 = (uint64_t)h0 * m1 + (uint32_t)t1;
+	uint64_t q = (uint64_t)h1 * m1 + (t1 >> 32) + (t2 >> 32);
+	uint32_t r = h0 - (uint32_t)q * d;
+	const bool fix = r >= d;
+	r = fix ? r - d : r;
+	q += fix ? 1u : 0u;
+	q_out = q;
+	return r;
+}
+
 // ---- hash_code (kmerSet.h:105-116) and its inverse ------------------------------------------
 __host__ __device__ __forceinline__ uint64_t hash_code(uint64_t k)
 {
@@ -110,7 +128,11 @@ __host__ __device__ __forceinline__ uint64_t hash_code(uint64_t k)
 	k ^= (k >> 22);
 	k += ~(k << 13);
 	k ^= (k >> 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(k) : "v"(k)); // k += k << 3 in one instruction (the compiler emits a 64-bit multiply by 9)
+#else
 	k += (k << 3);
+#endif
 	k ^= (k >> 15);
 	k += ~(k << 27);
 	k ^= (k >> 31);

@@ -81,7 +81,18 @@ struct PartGeom {
 	uint32_t b_lo, nb_own;
 	uint32_t n_regions_own;
 	uint64_t slot_lo, slot_hi;
+	uint32_t stagger;    // persistent scatter kernels: start delay spread over the workgroups, in s_sleep(16) units (0 = none)
 };
+
+// Identical workgroups started together run their phases in lockstep, so every CU issues its
+// copy-out stores at the same moment and the whole chip queues on the write path while it idles
+// during the extraction / ranking phases.  A start delay that differs per workgroup spreads the phases.
+__device__ __forceinline__ void stagger_start(uint32_t units)
+{
+	if (units == 0u) return;
+	const uint32_t mine = (uint32_t)(((uint64_t)((blockIdx.x * 0x9E3779B9u) >> 8) * units) >> 24); // low-discrepancy spread over [0, units)
+	for (uint32_t i = 0; i < mine; i++) __builtin_amdgcn_s_sleep(16);
+}
 
 struct PartStore {
 	uint64_t *l1;                 // [n_ranks * B][cap1]: what this rank extracted, by GLOBAL level-1 bucket
@@ -131,19 +142,30 @@ __device__ __forceinline__ void lds_barrier()
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// threadIdx.x as a value the optimiser cannot hoist: the persistent tile loops otherwise keep dozens of
+// loop-invariant per-thread addresses alive across the whole iteration, which pushes these
+// 1024-thread kernels (128-VGPR ceiling) into scratch spills -- and a scratch reload queues behind
+// the tile's global stores (one in-order vmcnt).  Recomputing an address costs an instruction or two.
+__device__ __forceinline__ uint32_t fresh_tid()
+{
+	uint32_t t = threadIdx.x;
+	asm volatile("" : "+v"(t));
+	return t;
+}
+
 // ---- workgroup-wide bucket scatter of up to 16 records per thread ------------------------------
 struct ScatterLds {
 	uint64_t stage[kTileRecords];
-	uint32_t hist[kMaxBuckets];
+	uint32_t hist[kMaxBuckets + 64]; // + one dummy bin per lane (level 1: positions that yield no record)
 	uint32_t lbase[kMaxBuckets];
-	uint32_t gbase[kMaxBuckets];
+	uint64_t desc[kMaxBuckets];      // copy-out descriptor per bucket (scatter_stage_copy)
 	uint32_t wave_tot[kTileThreads / 64];
 };
 
 // exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries kBPT*t .. kBPT*t+kBPT-1
 __device__ __forceinline__ void scan_hist(ScatterLds &L)
 {
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int t = (int)fresh_tid(), lane = t & 63, wave = t >> 6;
 	uint32_t v[kBPT], sum = 0;
 #pragma unroll
 	for (int j = 0; j < kBPT; j++) { v[j] = L.hist[kBPT * t + j]; sum += v[j]; }
@@ -156,18 +178,19 @@ __device__ __forceinline__ void scan_hist(ScatterLds &L)
 	if (lane == 63) L.wave_tot[wave] = inc;
 	lds_barrier();
 	uint32_t run = inc - sum;
-	for (int w = 0; w < wave; w++) run += L.wave_tot[w];
+#pragma unroll
+	for (int w = 0; w < kTileThreads / 64; w++) run += (w < wave) ? L.wave_tot[w] : 0u; // branch-free: a rolled loop gets vectorised into a register hog
 #pragma unroll
 	for (int j = 0; j < kBPT; j++) { L.lbase[kBPT * t + j] = run; run += v[j]; }
 }
 
 // Phases of the workgroup-wide bucket scatter of one tile (<= 16 records per thread).
-//   br[u] = (bucket << 16) | rank-within-bucket, bucket 0xFFFF = no record
+//   br[u] = (bucket << 16) | rank-within-bucket, bucket >= kMaxBuckets = no record
 
 // after every record has been ranked (hist complete): reserve global space, scan
 __device__ __forceinline__ void scatter_reserve_scan(ScatterLds &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[kBPT])
 {
-	const int t = threadIdx.x;
+	const int t = (int)fresh_tid();
 	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
 	// round trip overlaps the scan and the staging writes
 #pragma unroll
@@ -187,28 +210,50 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                                    const PartStore &P, Counters *ctr)
 {
-	const int t = threadIdx.x;
+	const int t = (int)fresh_tid();
 #pragma unroll
-	for (int u = 0; u < PER_THREAD; u++)
-		if ((br[u] >> 16) != 0xFFFFu) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
+	for (int u = 0; u < PER_THREAD; u++) {
+		if ((br[u] >> 16) < (uint32_t)kMaxBuckets) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
+		if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four lbase reads in flight are enough; more costs VGPRs the callers do not have
+	}
+	// one descriptor per bucket for the copy-out: global offset | records in this tile | first staged index
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) L.gbase[kBPT * t + j] = my_gbase[j];
+	for (int j = 0; j < kBPT; j++) {
+		const uint32_t b = kBPT * t + j;
+		L.desc[b] = ((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b];
+	}
 	lds_barrier();
-	// copy-out: each wave takes buckets wave, wave+16, ...; a run is written with contiguous 8-byte lanes
-	const int lane = t & 63, wave = t >> 6;
-	for (uint32_t b = wave; b < (DBG == 2 ? 0u : n_buckets); b += kTileThreads / 64) {
-		const uint32_t n = L.hist[b];
+	// copy-out: wave w takes buckets w, w+16, ...  Lane l fetches the descriptor of the wave's l-th
+	// bucket in ONE LDS read; the loop then broadcasts descriptor k with readlane, so every per-bucket
+	// quantity is scalar and an iteration is an LDS read of the staged run plus one coalesced store.
+	const uint32_t lane = t & 63, wave = t >> 6;
+	constexpr uint32_t kWaves = kTileThreads / 64;
+	const uint32_t per_wave = (DBG == 2) ? 0u : (n_buckets + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * k < n_buckets
+	const uint32_t mine = wave + kWaves * lane;
+	const uint64_t d = (lane < per_wave) ? L.desc[mine] : 0ull; // per_wave <= kMaxBuckets / kWaves = 64
+	const uint32_t d_lo = (uint32_t)d, d_hi = (uint32_t)(d >> 32);
+	// (Unrolling this loop by four so that the staged runs are read back to back was measured slower:
+	// 7.2 / 6.9 ms against 7.1 / 6.4 ms for level 1 / level 2.)
+	for (uint32_t kk = 0; kk < per_wave; kk++) {
+		const uint32_t k = __builtin_amdgcn_readfirstlane(kk);
+		const uint32_t lo = __builtin_amdgcn_readlane(d_lo, k), dst = __builtin_amdgcn_readlane(d_hi, k);
+		const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
 		if (n == 0) continue;
-		const uint32_t src = L.lbase[b];
-		const uint64_t dst = L.gbase[b];
-		uint64_t *o = out + (uint64_t)b * cap;
-		for (uint32_t i = lane; i < n; i += 64) {
-			const uint64_t rcd = L.stage[src + i];
-			if (dst + i < cap) {
-				o[dst + i] = rcd;
-			} else {
-				const uint32_t b1 = bucket_is_b1 ? b : b1_of_bucket0;
-				push_overflow(P, record_key(rcd, b1, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+		const uint32_t b = wave + kWaves * k;
+		uint64_t *o = out + (uint64_t)b * cap + dst;
+		if (DBG == 3) { // timing experiment: same instruction stream, stores land in a 32 KiB window per workgroup (no HBM write traffic)
+			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + dst + i) & 4095ull)] = L.stage[src + i];
+		} else if ((uint64_t)dst + n <= cap) {
+			for (uint32_t i = lane; i < n; i += 64) o[i] = L.stage[src + i];
+		} else { // the bucket is full: records beyond its capacity go to the overflow list
+			for (uint32_t i = lane; i < n; i += 64) {
+				const uint64_t rcd = L.stage[src + i];
+				if ((uint64_t)dst + i < cap) {
+					o[i] = rcd;
+				} else {
+					const uint32_t b1 = bucket_is_b1 ? b : b1_of_bucket0;
+					push_overflow(P, record_key(rcd, b1, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+				}
 			}
 		}
 	}
@@ -222,13 +267,20 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
                                              uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                              const PartStore &P, Counters *ctr)
 {
-	const int t = threadIdx.x;
+	const int t = (int)fresh_tid();
 #pragma unroll
 	for (int j = 0; j < kBPT; j++) L.hist[kBPT * t + j] = 0;
 	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) bkt[u] = (bkt[u] << 16) | ((bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u);
 	lds_barrier();
+	if (DBG == 1) { // timing experiment: loads + ranking only
+		uint64_t x = 0;
+#pragma unroll
+		for (int u = 0; u < PER_THREAD; u++) x ^= rec[u] + bkt[u];
+		if (x == 0x1234567u) out[threadIdx.x] = x;
+		return;
+	}
 	uint32_t my_gbase[kBPT];
 	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
 	scatter_stage_copy<PER_THREAD, DBG>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
@@ -291,7 +343,7 @@ template <bool HAS_DEAD, bool GUARDED>
 __device__ __forceinline__ RawChunk load_raw(const ReadBatch &rb, uint64_t chunk, uint64_t n_chunks)
 {
 	RawChunk r;
-	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t lane = fresh_tid() & 63u;
 	const uint64_t halo_chunk = chunk - lane + 64u + lane; // == chunk + 64 for lanes 0,1
 	r.a0 = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
 	r.halo = r.a0;
@@ -331,7 +383,7 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 {
 	Chunk16 c;
 	const uint32_t k = (uint32_t)rb.k;
-	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t lane = fresh_tid() & 63u;
 	const uint64_t p0 = chunk * 16u;
 	const uint32_t w0 = pack16_ascii(raw.a0);
 	const uint32_t hw = pack16_ascii(raw.halo);
@@ -376,8 +428,8 @@ __device__ __forceinline__ uint32_t comp_code(uint32_t x) { return (0x4053u >> (
 // bucket ranges -- was measured at 24.5 ms against 10.4 ms for the staged form: uncoalesced 8-byte
 // stores are the wrong trade on this chip even though the L2 merges them into lines.)
 // DBG != 0 are timing experiments selected with DBGK_DEBUG_MODE (results are wrong): 1 = extraction
-// only, 2 = no copy-out
-template <bool HAS_DEAD, int DBG = 0>
+// only, 2 = no copy-out, 3 = copy-out into a small window
+template <bool HAS_DEAD, int DBG = 0, bool WIDE_D = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -387,42 +439,64 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 	const uint32_t k = (uint32_t)rb.k;
 	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;  // KmerHeadMaskVal, DBGgraph.cpp:371
 	const uint32_t rc_shift = 2u * k - 2u;                                      // KmerRCOrVal[b] = (3-b) << (2k-2), :373-376
+	const uint32_t rel_mask = (1u << G.r) - 1u, q_shift = G.r + 6u;             // record = q << (r+6) | slot_rel << 6 | lb << 3 | rb
 
 	// a tile is INTERIOR when every chunk it touches (incl. the two halo chunks past its end) is a
 	// full 16 bytes inside the buffer: its loads need no guards and are issued back to back
 	auto interior = [&](uint64_t tile) { return ((tile + 1u) * kL1Threads + 2u) * 16u <= rb.n_bases; };
 	auto fetch = [&](uint64_t tile) {
-		const uint64_t ch = tile * kL1Threads + threadIdx.x;
+		const uint64_t ch = tile * kL1Threads + fresh_tid();
 		if (tile >= n_tiles) return RawChunk{};
 		return interior(tile) ? load_raw<HAS_DEAD, false>(rb, ch, n_chunks) : load_raw<HAS_DEAD, true>(rb, ch, n_chunks);
 	};
+	// The loads of tile i+1 are issued when the extraction of tile i is done and are complete (they
+	// precede the reservation atomics, whose results staging waits for) before tile i's copy-out
+	// stores are issued: nothing ever waits for those stores, they drain during the next extraction.
+	stagger_start(G.stagger);
+	RawChunk raw = fetch(blockIdx.x);
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const RawChunk raw = fetch(tile); // all loads of the tile issued back to back, one round trip
-		const uint64_t chunk = tile * kL1Threads + threadIdx.x;
+		const uint32_t tid = fresh_tid();
+		const uint64_t chunk = tile * kL1Threads + tid;
 		uint32_t bkt[16]; // (bucket << 16) | rank once the position has been processed
-		L.hist[threadIdx.x] = 0;
+		L.hist[tid] = 0;
 		lds_barrier();
-		uint32_t zero_mask = 0; // valid positions whose canonical k-mer is 0 (poly-A / poly-T): rare, handled below
+		uint32_t zero_mask = 0; // this lane saw a canonical k-mer 0 (poly-A / poly-T): rare, handled below
 		{
 			Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
 			if (chunk >= n_chunks) c.valid = 0u;
+			// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
+			// first / last window are patched afterwards (rare per lane, so the loop stays lean).
+			// Complemented neighbour codes (3 - x == x ^ 3) for all 16 positions at once:
+			const uint32_t lwc = ~c.lw, nbc = ~c.nb;
+			uint32_t rev_mask = 0, key_min = ~0u;
 #pragma unroll
 			for (uint32_t i = 0; i < 16; i++) {
-				const uint32_t left = (c.lw >> (30u - 2u * i)) & 3u, right = (c.nb >> (30u - 2u * i)) & 3u;
-				const bool fwd = c.kbit <= c.rc;                        // tie -> forward (DBGgraph.cpp:80)
-				const uint64_t key = fwd ? c.kbit : c.rc;
-				const uint32_t lc = ((c.has_l >> i) & 1u) ? left : 4u, rcd = ((c.has_r >> i) & 1u) ? right : 4u;
-				const uint32_t lb = fwd ? lc : comp_code(rcd), rbb = fwd ? rcd : comp_code(lc);
-				const bool valid = (c.valid >> i) & 1u;
+				const uint32_t sh = 30u - 2u * i;
+				const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+				const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
+				const uint64_t key = rev ? c.rc : c.kbit;
+				// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
+				uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
+				asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
+				const uint32_t links = rev ? lr : lf;
+				uint32_t rev_bit = rev ? 1u : 0u;
+				asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
+				rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit 15 - i
+				key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 				uint64_t q;
-				const uint32_t slot = divmod_u64_u32(hash_code(key), G.div, q);
+				const uint32_t slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q)
+				                             : divmod_magic_small(hash_code(key), G.magic.m, (uint32_t)G.magic.d, q);
 				// park the record in the (still unused) stage buffer, column i of this thread, and rank it
 				// right away: only one packed register per position stays live across the tile
-				L.stage[i * kL1Threads + threadIdx.x] = (q << (G.r + 6u)) | ((uint64_t)(slot & ((1u << G.r) - 1u)) << 6) | (uint64_t)((lb << 3) | rbb);
+				const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+				const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
+				const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
+				L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
+				const bool valid = (c.valid >> i) & 1u;
 				const bool zero = key == 0ull;
-				const uint32_t b = (valid && !zero) ? (slot >> G.r) : 0xFFFFu;
-				bkt[i] = (b << 16) | ((b != 0xFFFFu) ? atomicAdd(&L.hist[b], 1u) : 0u);
-				zero_mask |= (valid && zero) ? (1u << i) : 0u;
+				// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
+				const uint32_t b = (valid && !zero) ? (slot >> G.r) : (uint32_t)kMaxBuckets + (tid & 63u);
+				bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 				// roll to the next position (DBGgraph.cpp:71-73)
 				c.kbit = ((c.kbit << 2) | right) & head_mask;
 				c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
@@ -430,6 +504,18 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 				// workgroup has 1024 threads, so 128 VGPRs per lane is the ceiling)
 				if (kSchedWindow && (i % (kSchedWindow ? kSchedWindow : 1)) == (kSchedWindow ? kSchedWindow : 1) - 1u) __builtin_amdgcn_sched_barrier(0);
 			}
+			// windows without a left / right neighbour: that side's code becomes 4 = none
+			const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
+			for (uint32_t fix = (no_l | no_r) & c.valid; fix; fix &= fix - 1u) {
+				const uint32_t i = (uint32_t)__builtin_ctz(fix);
+				const bool fwd = !((rev_mask >> (15u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+				uint64_t rec = L.stage[i * kL1Threads + tid];
+				uint32_t lb = ((uint32_t)rec >> 3) & 7u, rbb = (uint32_t)rec & 7u;
+				if (fwd ? nl : nr) lb = 4u;
+				if (fwd ? nr : nl) rbb = 4u;
+				L.stage[i * kL1Threads + tid] = (rec & ~63ull) | (lb << 3) | rbb;
+			}
+			zero_mask = key_min == 0u; // rare: the plain path below finds which (valid) positions it was
 		}
 		if (zero_mask) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
 			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
@@ -443,19 +529,22 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 		if (DBG == 1) {
 			uint64_t x = 0;
 #pragma unroll
-			for (int u = 0; u < 16; u++) x ^= L.stage[u * kL1Threads + threadIdx.x] + bkt[u];
+			for (int u = 0; u < 16; u++) x ^= L.stage[u * kL1Threads + tid] + bkt[u];
 			if (x == 0x1234567u) P.l1[threadIdx.x] = x;
 			lds_barrier();
+			raw = fetch(tile + gridDim.x);
 			continue;
 		}
+		const RawChunk nxt = fetch(tile + gridDim.x);
 		lds_barrier(); // hist complete
 		uint32_t my_gbase[kBPT];
 		scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
 		uint64_t rec[16];
 #pragma unroll
-		for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + threadIdx.x];
+		for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 		lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
 		scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1, G.cap1, 0u, true, G, P, ctr);
+		raw = nxt;
 	}
 }
 
@@ -469,7 +558,7 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 {
 	__shared__ uint32_t tot[kMaxBuckets / 64];
 	__shared__ uint32_t carry;
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int t = (int)fresh_tid(), lane = t & 63, wave = t >> 6;
 	const uint32_t n_entries = G.n_ranks * G.B;
 	if (t == 0) carry = 0;
 	__syncthreads();
@@ -518,13 +607,15 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
 	const uint64_t first = (uint64_t)(g - tile_prefix[e]) * kTileRecords;
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
+	const uint32_t tid = fresh_tid();
 #pragma unroll
 	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
-		const uint64_t i = first + (uint64_t)u * kTileThreads + threadIdx.x;
+		const uint64_t i = first + (uint64_t)u * kTileThreads + tid;
 		if (i < filled) rec[u] = __builtin_nontemporal_load(in + i);
 	}
 }
 
+template <int DBG = 0>
 __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
                                                              Counters *__restrict__ ctr)
 {
@@ -533,6 +624,7 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 	const uint32_t n_tiles = tile_prefix[G.n_ranks * G.B];
 	uint64_t nxt[16];
 	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
+	stagger_start(G.stagger);
 	l2_load_tile(G, P, tile_prefix, blockIdx.x, n_tiles, nxt, nxt_b1);
 	for (uint32_t g = blockIdx.x; g < n_tiles; g += gridDim.x) {
 		uint64_t rec[16];
@@ -545,7 +637,7 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
 		}
 		l2_load_tile(G, P, tile_prefix, g + gridDim.x, n_tiles, nxt, nxt_b1); // in flight during the scatter below
-		scatter_tile<16>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
+		scatter_tile<16, DBG>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
 	}
 }
 
@@ -561,6 +653,9 @@ struct BuildLds {
 	unsigned long long red[kBuildThreads / 64];
 };
 
+// DBG (DBGK_DEBUG_BUILD, timing experiments, results are wrong): 1 = clear + load only, 2 = no emit,
+// 3 = emit without recomputing the keys
+template <int DBG = 0>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
                                                                   Counters *__restrict__ ctr)
 {
@@ -571,7 +666,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	const uint64_t region_base = (uint64_t)f << kRegionBits;   // index into this shard's table
 	const uint64_t region_slot0 = G.slot_lo + region_base;     // global slot of the region's first entry
 	const uint32_t region_len = (uint32_t)((G.size - region_slot0 < (uint64_t)kRegionSlots) ? G.size - region_slot0 : kRegionSlots);
-	const int t = threadIdx.x;
+	const int t = (int)fresh_tid();
 	const uint64_t filled = P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2;
 	const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
 
@@ -581,7 +676,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	}
 	lds_barrier();
 
-	unsigned long long n_new = 0, n_conf = 0;
+	uint32_t n_new = 0, n_conf = 0; // per thread and region: far below 2^32
 	constexpr int kBatch = 8; // records per thread loaded together before any LDS work
 	for (uint64_t base = 0; base < filled; base += (uint64_t)kBatch * kBuildThreads) {
 		uint64_t recs[kBatch];
@@ -590,43 +685,59 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			const uint64_t i = base + (uint64_t)u * kBuildThreads + t;
 			recs[u] = (i < filled) ? __builtin_nontemporal_load(in + i) : ~0ull;
 		}
+		if (DBG == 1) {
+			uint64_t x = 0;
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) x ^= recs[u];
+			if (x == 0x1234567ull) table[t].kmer = x;
+			continue;
+		}
 #pragma unroll
 		for (int u = 0; u < kBatch; u++) {
+			// The loops below have ONE exit condition each and no breaks: the structurizer turns every
+			// extra exit of a divergent loop into a dozen scalar mask instructions per iteration, and this
+			// kernel is bound by instruction issue (profiles/dbg_modes_build.sh).
 			const uint64_t rec = recs[u];
-			if (rec == ~0ull) continue;
+			const bool live = rec != ~0ull;
 			const unsigned long long id = (rec >> 6) + 1ull;
 			const uint32_t lb = (uint32_t)(rec >> 3) & 7u, rb = (uint32_t)rec & 7u;
-			uint32_t idx = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
-			bool placed = false;
-			while (idx < (uint32_t)(kRegionSlots + kSpillSlots)) {
+			const uint32_t home = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
+			uint32_t idx = home;
+			unsigned long long old = L.links[home]; // usually the key sits in its home slot: fetch its counters together with the first probe
+			bool probing = live, lost = false;
+			while (probing) {
 				unsigned long long cur = L.ident[idx];
 				if (cur == 0ull) {
-					cur = atomicCAS(&L.ident[idx], 0ull, id);
-					if (cur == 0ull) {
-						if (idx < region_len) n_new++; // spilled nodes are counted when they are merged
-						placed = true;
-						break;
-					}
+					const unsigned long long prev = atomicCAS(&L.ident[idx], 0ull, id);
+					cur = prev == 0ull ? id : prev;
+					n_new += (prev == 0ull && idx < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
 				}
-				if (cur == id) { placed = true; break; }
-				n_conf++;
-				idx++;
+				const bool hit = cur == id;
+				idx += hit ? 0u : 1u;
+				n_conf += hit ? 0u : 1u;
+				lost = idx >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full
+				probing = !hit && !lost;
 			}
-			if (placed) {
-				unsigned long long old = L.links[idx];
-				for (;;) {
-					const unsigned long long upd = links_observe(old, lb, rb);
-					if (upd == old) break;
-					const unsigned long long prev = atomicCAS(&L.links[idx], old, upd);
-					if (prev == old) break;
-					old = prev;
-				}
-			} else {
-				push_overflow(P, record_key(rec, b1, G), lb, rb, ctr); // region + spill area completely full
+			// saturating +1 on the observed neighbour bytes (add_node_to_kmerset's "if (< 255) ++", kmerSet.cpp:253-273):
+			// both dwords at once, bytes that are already 255 masked out of the increment
+			const uint32_t dl = (lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
+			bool pending = live && !lost;
+			if (pending && idx != home) old = L.links[idx];
+			while (pending) {
+				const uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
+				const uint32_t sat_l = (((lo & 0x7F7F7F7Fu) + 0x01010101u) & lo & 0x80808080u) >> 7; // 0x01 in every byte that is 0xFF
+				const uint32_t sat_r = (((hi & 0x7F7F7F7Fu) + 0x01010101u) & hi & 0x80808080u) >> 7;
+				const unsigned long long upd = ((unsigned long long)(hi + (dr & ~sat_r)) << 32) | (lo + (dl & ~sat_l));
+				unsigned long long prev = old;
+				if (upd != old) prev = atomicCAS(&L.links[idx], old, upd);
+				pending = prev != old;
+				old = prev;
 			}
+			if (live && lost) push_overflow(P, record_key(rec, b1, G), lb, rb, ctr);
 		}
 	}
 	lds_barrier();
+	if (DBG == 1 || DBG == 2) return;
 
 	// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot))
 	for (uint32_t i = t; i < region_len; i += kBuildThreads) {
@@ -635,7 +746,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		if (id) {
 			const uint64_t v = id - 1ull;
 			const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
-			key = hash_code_inverse((v >> G.r) * G.size + slot);
+			key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
 			links = L.links[i];
 		}
 		*reinterpret_cast<uint4 *>(&table[region_base + i]) =

@@ -1,0 +1,8 @@
+#!/bin/bash
+# timing experiments for the level-2 kernel: DBGK_DEBUG_L2 0 = production, 1 = loads + ranking only, 2 = no copy-out,
+# 3 = copy-out into a 32 KiB window (no HBM write traffic)
+for m in 0 1 2 3; do
+  DBGK_DEBUG_L2=$m timeout -k 10 200 python bench.py --steps 2 --warmup 1 --engine 2 --no-cpu-baseline > gpurun_out/dbgl2_$m.json 2> gpurun_out/dbgl2_$m.err || exit 1
+  python -c "
+import json;d=json.load(open('gpurun_out/dbgl2_$m.json'));print($m, d['roofline']['all_kernels_ms'])"
+done
