@@ -371,7 +371,6 @@ static int setup_partition(dbgk_handle *h)
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		return DBGK_ERR_NOMEM;
 	}
-	h->geom.stagger = getenv("DBGK_STAGGER") ? (uint32_t)atoi(getenv("DBGK_STAGGER")) : 0u;
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));

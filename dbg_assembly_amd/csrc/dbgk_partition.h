@@ -81,18 +81,7 @@ struct PartGeom {
 	uint32_t b_lo, nb_own;
 	uint32_t n_regions_own;
 	uint64_t slot_lo, slot_hi;
-	uint32_t stagger;    // persistent scatter kernels: start delay spread over the workgroups, in s_sleep(16) units (0 = none)
 };
-
-// Identical workgroups started together run their phases in lockstep, so every CU issues its
-// copy-out stores at the same moment and the whole chip queues on the write path while it idles
-// during the extraction / ranking phases.  A start delay that differs per workgroup spreads the phases.
-__device__ __forceinline__ void stagger_start(uint32_t units)
-{
-	if (units == 0u) return;
-	const uint32_t mine = (uint32_t)(((uint64_t)((blockIdx.x * 0x9E3779B9u) >> 8) * units) >> 24); // low-discrepancy spread over [0, units)
-	for (uint32_t i = 0; i < mine; i++) __builtin_amdgcn_s_sleep(16);
-}
 
 struct PartStore {
 	uint64_t *l1;                 // [n_ranks * B][cap1]: what this rank extracted, by GLOBAL level-1 bucket
@@ -204,7 +193,13 @@ __device__ __forceinline__ void scatter_reserve_scan(ScatterLds &L, uint32_t n_b
 
 // bucket-sorted staging of the records, then the coalesced copy-out.  Records beyond a bucket's
 // capacity are decoded and pushed to the overflow list.
-template <int PER_THREAD, int DBG = 0>
+// FLAT (level 2): the bucket of a staged record can be recomputed from the record itself
+// ((rec >> 18) & (n_buckets - 1)), so the copy-out walks the sorted stage linearly, one record per
+// lane and every lane busy: 256 store instructions per tile instead of one (half-empty) store per
+// bucket and wave.  The vector-memory pipe costs ~27 clocks per store instruction per CU whatever
+// the number of active lanes (profiles/dbg_modes_l2.sh), which makes the instruction count the cost:
+// level 2 went from 6.3 to 5.3 ms.
+template <int PER_THREAD, int DBG = 0, bool FLAT = false>
 __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[kBPT], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
@@ -223,6 +218,30 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 		L.desc[b] = ((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b];
 	}
 	lds_barrier();
+	if (FLAT) {
+		if (DBG != 2) {
+			const uint32_t total = L.lbase[n_buckets - 1u] + L.hist[n_buckets - 1u];
+#pragma unroll
+			for (int u = 0; u < PER_THREAD; u++) {
+				const uint32_t p = (uint32_t)u * kTileThreads + (uint32_t)t;
+				if (p >= total) continue;
+				const uint64_t rcd = L.stage[p];
+				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits)) & (n_buckets - 1u);
+				const uint64_t d = L.desc[b];
+				const uint64_t off = (d >> 32) + (p - ((uint32_t)d & 0xFFFFu));
+				if (DBG == 3) {
+					out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + off) & 4095ull)] = rcd;
+				} else if (off < cap) {
+					out[(uint64_t)b * cap + off] = rcd;
+				} else { // the bucket is full: records beyond its capacity go to the overflow list
+					const uint32_t b1 = bucket_is_b1 ? b : b1_of_bucket0;
+					push_overflow(P, record_key(rcd, b1, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+				}
+			}
+		}
+		lds_barrier(); // stage / hist are reused by the next tile; the global stores keep draining
+		return;
+	}
 	// copy-out: wave w takes buckets w, w+16, ...  Lane l fetches the descriptor of the wave's l-th
 	// bucket in ONE LDS read; the loop then broadcasts descriptor k with readlane, so every per-bucket
 	// quantity is scalar and an iteration is an LDS read of the staged run plus one coalesced store.
@@ -261,7 +280,7 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 }
 
 // whole scatter for records held in registers (level 2)
-template <int PER_THREAD, int DBG = 0>
+template <int PER_THREAD, int DBG = 0, bool FLAT = false>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], uint32_t (&bkt)[PER_THREAD],
                                              uint32_t n_buckets, uint32_t *__restrict__ cnt, uint64_t *__restrict__ out,
                                              uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
@@ -283,7 +302,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
 	}
 	uint32_t my_gbase[kBPT];
 	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
-	scatter_stage_copy<PER_THREAD, DBG>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
+	scatter_stage_copy<PER_THREAD, DBG, FLAT>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
 }
 
 // ---- lean extraction for the partition path -----------------------------------------------------
@@ -452,7 +471,6 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 	// The loads of tile i+1 are issued when the extraction of tile i is done and are complete (they
 	// precede the reservation atomics, whose results staging waits for) before tile i's copy-out
 	// stores are issued: nothing ever waits for those stores, they drain during the next extraction.
-	stagger_start(G.stagger);
 	RawChunk raw = fetch(blockIdx.x);
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t tid = fresh_tid();
@@ -624,7 +642,6 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 	const uint32_t n_tiles = tile_prefix[G.n_ranks * G.B];
 	uint64_t nxt[16];
 	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
-	stagger_start(G.stagger);
 	l2_load_tile(G, P, tile_prefix, blockIdx.x, n_tiles, nxt, nxt_b1);
 	for (uint32_t g = blockIdx.x; g < n_tiles; g += gridDim.x) {
 		uint64_t rec[16];
@@ -637,7 +654,7 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
 		}
 		l2_load_tile(G, P, tile_prefix, g + gridDim.x, n_tiles, nxt, nxt_b1); // in flight during the scatter below
-		scatter_tile<16, DBG>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
+		scatter_tile<16, DBG, true>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
 	}
 }
 
@@ -739,7 +756,9 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	lds_barrier();
 	if (DBG == 1 || DBG == 2) return;
 
-	// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot))
+	// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot)).
+	// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
+	// written back into ident[], was measured: no change, 6.78 against 6.69-6.79 ms.)
 	for (uint32_t i = t; i < region_len; i += kBuildThreads) {
 		const unsigned long long id = L.ident[i];
 		uint64_t key = 0ull, links = 0ull;
