@@ -23,7 +23,7 @@ import csv, sys
 for row in csv.DictReader(open(sys.argv[1])):
     k = row["Kernel_Name"]
     if "dbgk" not in k: continue
-    k = k.split("(")[0].replace("void ", "")
+    k = k.split("(")[0].replace("void ", "").replace(", ", ";")  # template arguments would break the CSV
     print("%s,%s,%s,%.4f" % (k, row["Counter_Name"], row["Counter_Value"], (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
 PY
   done
