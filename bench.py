@@ -53,17 +53,19 @@ def parse_args():
 
 
 def measured_traffic(args, size, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_r*.json), only
-    when this run is the workload those passes were taken on; else None."""
+    """HBM bytes per launch of `kernel` (None = sum over all kernels of the step) from the committed PMC
+    passes (profiles/traffic_r*.json), only when this run is the workload those passes were taken on;
+    else None."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
         with open(path) as fh:
             t = json.load(fh)
         w = t.get("workload", {})
+        per = t.get("bytes_per_launch", {})
         if (w.get("reads_per_gpu"), w.get("kmer"), w.get("table_slots"), w.get("engine")) == \
-                (args.reads_per_gpu, args.kmer, size, args.engine) and kernel in t.get("bytes_per_launch", {}):
-            best = t["bytes_per_launch"][kernel]
+                (args.reads_per_gpu, args.kmer, size, args.engine) and (kernel is None or kernel in per):
+            best = sum(per.values()) if kernel is None else per[kernel]
     return best
 
 
@@ -215,6 +217,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, dom_kernel),
+                         "traffic_all_kernels": measured_traffic(args, size, None),
                          "kernel_ms": kern_ms, "bytes_per_kmer": B_ALG,
                          "kmers_per_launch": kmers_per_launch,
                          "all_kernels_ms": phase_kernels,

@@ -342,7 +342,7 @@ def test_full_size_direct_vs_partition_digest(capi):
 # sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
 # device copies.  Validates slot-range ownership end to end on real hardware.
 # ------------------------------------------------------------------------------------------------
-def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slots=PART_SLOTS):
+def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slots=PART_SLOTS, want_tables=True):
     size = capi.find_next_prime_ref(slots)
     graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected_per_shard,
                          shard_count=n_shards, shard_index=i) for i in range(n_shards)]
@@ -380,7 +380,7 @@ def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slot
         for g, (p, n) in zip(graphs, out):
             assert g.shard_outgoing()[1] == n  # nothing handed over twice
         nodes = np.concatenate([g.export_sorted() for g in graphs])
-        tables = [g.export_host_table(g.stats.table_slots) for g in graphs]
+        tables = [g.export_host_table(g.stats.table_slots) for g in graphs] if want_tables else None
         return final, stats, nodes, infos, tables, (sum(n for _, n in ovf), sum(n for _, n in out)), size
     finally:
         for g in graphs:
@@ -410,6 +410,25 @@ def test_sharded_table_equals_oracle(capi, oracle, n_shards):
     fl = np.packbits((whole["kmer"] != 0).astype(np.uint8))
     fl = np.concatenate([fl, np.zeros(size // 8 + 1 - len(fl), np.uint8)])
     assert oracle.check_host_table(whole, fl, size, ref.count - 1) == 0
+
+
+def test_tables_of_2_31_slots_and_more_use_the_wide_divisor_path(capi, oracle):
+    """the 8-GPU bench builds ONE table of ~2^32 slots: above 2^31 slots the level-1 kernel divides with the
+    two-step 2-by-1 form instead of the multiply-high shortcut; single handle and two shards"""
+    rng = random.Random(2031)
+    reads = rand_reads(rng, 6000, G=40000) + [b"A" * 150] * 100
+    ref = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=31, init_hash_size=0.002)
+    size = capi.find_next_prime_ref(2_200_000_000)
+    assert size >= 1 << 31
+    with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=1_000_000) as g:
+        g.push_reads(*oracle.pack_reads(reads))
+        st = g.finalize()
+        assert st.count == ref.count and st.total_kmers == ref.total_kmers
+        assert np.array_equal(g.export_sorted(), ref.nodes)
+    final, stats, nodes, infos, _, _, size2 = _sharded_build(capi, oracle, reads, 2, 600000, slots=2_200_000_000, want_tables=False)
+    assert size2 == size and infos[1].slot_hi == size
+    assert sum(int(s.count) for s in final) == ref.count
+    assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
 
 
 def test_sharded_table_with_overflow_and_heavy_repeats(capi, oracle):
