@@ -46,7 +46,7 @@ static int hip_fail(hipError_t e, const char *what, int line)
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-enum Phase { PH_MARK = 0, PH_INSERT, PH_PARTITION, PH_BUILD, PH_FIXUP, PH_FINALIZE, PH_COUNT };
+enum Phase { PH_MARK = 0, PH_INSERT, PH_PARTITION, PH_BUILD, PH_FIXUP, PH_FINALIZE, PH_L2_BUILD_WALL, PH_COUNT };
 
 struct TimedSpan {
 	hipEvent_t a, b;
@@ -112,6 +112,9 @@ struct dbgk_handle {
 	PartGeom geom;
 	PartStore store;
 	uint32_t *tile_prefix = nullptr; // [n_ranks * B + 1] level-2 tile plan
+	hipStream_t stream2 = nullptr;   // finalize: region build of bucket chunk c runs here while level 2 of chunk c+1 runs on `stream`
+	std::vector<hipEvent_t> chunk_ev; // level 2 of chunk c finished
+	hipEvent_t join_ev = nullptr;
 	// sharding: the handle owns slots [geom.slot_lo, geom.slot_hi) of a GLOBAL table of `size` slots
 	bool sharded = false;         // shard_count > 1
 	bool exchanged = false;       // the caller has filled the inbox (all-to-all) for this step
@@ -121,6 +124,7 @@ struct dbgk_handle {
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
 	uint64_t insert_launches = 0;
+	uint32_t partition_launches = 0;
 
 	TableRef tref() const { return TableRef{table, size, magic}; }
 };
@@ -131,7 +135,7 @@ static int use_device(dbgk_handle *h)
 	return DBGK_OK;
 }
 
-static int span_begin(dbgk_handle *h, int phase, TimedSpan &s)
+static int span_begin(dbgk_handle *h, int phase, TimedSpan &s, hipStream_t stream = nullptr)
 {
 	if (!h->free_spans.empty()) {
 		s = h->free_spans.back();
@@ -141,13 +145,13 @@ static int span_begin(dbgk_handle *h, int phase, TimedSpan &s)
 		HIPCHK(hipEventCreate(&s.b));
 	}
 	s.phase = phase;
-	HIPCHK(hipEventRecord(s.a, h->stream));
+	HIPCHK(hipEventRecord(s.a, stream ? stream : h->stream));
 	return DBGK_OK;
 }
 
-static int span_end(dbgk_handle *h, TimedSpan &s)
+static int span_end(dbgk_handle *h, TimedSpan &s, hipStream_t stream = nullptr)
 {
-	HIPCHK(hipEventRecord(s.b, h->stream));
+	HIPCHK(hipEventRecord(s.b, stream ? stream : h->stream));
 	h->spans.push_back(s);
 	return DBGK_OK;
 }
@@ -160,6 +164,7 @@ static int collect_spans(dbgk_handle *h)
 		HIPCHK(hipEventElapsedTime(&ms, s.a, s.b));
 		h->phase_ms[s.phase] += ms;
 		if (s.phase == PH_INSERT) h->insert_launches++;
+		if (s.phase == PH_PARTITION) h->partition_launches++;
 		h->free_spans.push_back(s);
 	}
 	h->spans.clear();
@@ -229,6 +234,9 @@ static void free_handle(dbgk_handle *h)
 		                (void *)h->store.spill, (void *)h->store.ovf_n})
 			if (p) (void)hipFree(p);
 		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
+		for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
+		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
+		if (h->stream2) (void)hipStreamDestroy(h->stream2);
 		if (h->inbox) (void)hipFree(h->inbox);
 		if (h->inbox_cnt) (void)hipFree(h->inbox_cnt);
 		if (h->store.outgoing) (void)hipFree(h->store.outgoing);
@@ -259,7 +267,7 @@ static int reset_state(dbgk_handle *h)
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
 		h->part_built = false;
-		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * 4, h->stream));
+		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
@@ -328,19 +336,20 @@ static int plan_partition(dbgk_handle *h)
 	G.n_ranks = n_ranks;
 	G.rank = want_shard ? h->cfg.shard_index : 0;
 	G.B = (G.n1 + n_ranks - 1) / n_ranks;
+	G.n_sub = kSubStores;
 	G.b_lo = std::min(G.rank * G.B, G.n1);
 	G.nb_own = std::min(G.B, G.n1 - G.b_lo);
 	G.slot_lo = (uint64_t)G.b_lo << r;
 	G.slot_hi = std::min<uint64_t>(h->size, ((uint64_t)G.b_lo + G.nb_own) << r);
 	G.n_regions_own = (uint32_t)((G.slot_hi - G.slot_lo + kRegionSlots - 1) >> kRegionBits);
-	if (G.nb_own == 0 || (uint64_t)n_ranks * G.B > (uint64_t)kMaxInboxEntries) {
+	if (G.nb_own == 0 || (uint64_t)n_ranks * G.B * G.n_sub > (uint64_t)kMaxInboxEntries) {
 		g_last_error = "shard_count too large for this table size";
 		return DBGK_ERR_ARG;
 	}
 	// expected_kmers = occurrences THIS handle extracts; a region receives the global density
 	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2 / n_ranks;
 	const double per_slot = (double)expected / (double)h->size;
-	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05) + 65536;
+	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05 / (double)G.n_sub) + 65536 / G.n_sub + (G.n_sub > 1 ? 8192 : 0); // per sub-store
 	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
 	h->tslots = G.slot_hi - G.slot_lo;
 	h->sharded = want_shard;
@@ -358,7 +367,7 @@ static int setup_partition(dbgk_handle *h)
 	P.ovf_cap = expected / 64 + (1ull << 20);
 	P.spill_cap = (uint64_t)G.n_regions_own * 8 + (1ull << 16);
 	P.outgoing_cap = 1ull << 16;
-	const size_t n_entries = (size_t)G.n_ranks * G.B;
+	const size_t n_entries = (size_t)G.n_ranks * G.B * G.n_sub;
 	const size_t l1_bytes = n_entries * G.cap1 * 8, l2_bytes = (size_t)G.nb_own * G.n2 * G.cap2 * 8;
 	bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
 	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
@@ -380,10 +389,10 @@ static int setup_partition(dbgk_handle *h)
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
@@ -755,47 +764,98 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 }
 
 // PARTITION engine: records -> final buckets -> table regions, then the stragglers
+template <int DBG>
+static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
+{
+	hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+}
+
+template <int DBG>
+static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions)
+{
+	hipLaunchKernelGGL(k_build_regions<DBG>, dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr, first_region);
+}
+
+// Level 2 is bound by the memory system (8 waves per CU and 72 KiB of LDS reach the same time as a
+// full CU), the region build by instruction issue: they run CONCURRENTLY.  The own level-1 buckets
+// are cut into chunks; level 2 of chunk c+1 runs on `stream` while the regions of chunk c are built
+// on `stream2` (one 512-thread level-2 workgroup and one 1024-thread build workgroup fit a CU together).
 static int build_from_records(dbgk_handle *h)
 {
 	const PartGeom &G = h->geom;
-	TimedSpan sp;
-	int rc = span_begin(h, PH_PARTITION, sp);
-	if (rc) return rc;
+	static const int l2_wg_per_cu = getenv("DBGK_L2_WG_PER_CU") ? atoi(getenv("DBGK_L2_WG_PER_CU")) : 1;
+	const int l2_grid = h->n_cu * (l2_wg_per_cu > 0 ? l2_wg_per_cu : 1);
+	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;       // timing experiments, results are wrong
+	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
+	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 8; // 1 = level 2, then build
+	uint32_t n_chunks = (dbg_l2 || dbg_build || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
+	if (n_chunks > G.nb_own) n_chunks = G.nb_own ? G.nb_own : 1u;
+	if (n_chunks > 1 && !h->stream2) {
+		HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+	}
+	while (h->chunk_ev.size() < n_chunks) {
+		hipEvent_t e;
+		HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		h->chunk_ev.push_back(e);
+	}
+	hipStream_t bstream = n_chunks > 1 ? h->stream2 : h->stream;
 	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, G, h->store, h->tile_prefix);
-	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0; // timing experiments, results are wrong
-	if (dbg_l2 == 1)
-		hipLaunchKernelGGL(k_scatter_l2<1>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
-	else if (dbg_l2 == 2)
-		hipLaunchKernelGGL(k_scatter_l2<2>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
-	else if (dbg_l2 == 3)
-		hipLaunchKernelGGL(k_scatter_l2<3>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
-	else
-		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(h->n_cu), dim3(kTileThreads), sizeof(ScatterLds), h->stream, G, h->store, h->tile_prefix, h->d_ctr);
 	HIPCHK(hipGetLastError());
-	rc = span_end(h, sp);
-	if (rc) return rc;
-	if (dbg_l2) { // never build regions from the garbage a timing experiment leaves behind
-		g_last_error = "DBGK_DEBUG_L2 set: level-2 timing experiment, no table was built";
+	TimedSpan wall;
+	{
+		const int rc0 = span_begin(h, PH_L2_BUILD_WALL, wall);
+		if (rc0) return rc0;
+	}
+	const uint32_t per = (G.nb_own + n_chunks - 1) / n_chunks;
+	for (uint32_t c = 0; c < n_chunks; c++) {
+		const uint32_t j0 = std::min(c * per, G.nb_own), j1 = std::min(j0 + per, G.nb_own);
+		if (j0 == j1) continue;
+		TimedSpan sp;
+		int rc = span_begin(h, PH_PARTITION, sp);
+		if (rc) return rc;
+		switch (dbg_l2) {
+			case 1: launch_l2<1>(h, l2_grid, j0, j1); break;
+			case 2: launch_l2<2>(h, l2_grid, j0, j1); break;
+			case 3: launch_l2<3>(h, l2_grid, j0, j1); break;
+			default: launch_l2<0>(h, l2_grid, j0, j1); break;
+		}
+		HIPCHK(hipGetLastError());
+		rc = span_end(h, sp);
+		if (rc) return rc;
+		if (dbg_l2) continue; // never build regions from the garbage a timing experiment leaves behind
+		if (n_chunks > 1) {
+			HIPCHK(hipEventRecord(h->chunk_ev[c], h->stream));
+			HIPCHK(hipStreamWaitEvent(bstream, h->chunk_ev[c], 0));
+		}
+		const uint32_t r0 = j0 * G.n2, r1 = std::min(j1 * G.n2, G.n_regions_own);
+		if (r1 <= r0) continue;
+		rc = span_begin(h, PH_BUILD, sp, bstream);
+		if (rc) return rc;
+		switch (dbg_build) {
+			case 1: launch_build<1>(h, bstream, r0, r1 - r0); break;
+			case 2: launch_build<2>(h, bstream, r0, r1 - r0); break;
+			case 3: launch_build<3>(h, bstream, r0, r1 - r0); break;
+			default: launch_build<0>(h, bstream, r0, r1 - r0); break;
+		}
+		HIPCHK(hipGetLastError());
+		rc = span_end(h, sp, bstream);
+		if (rc) return rc;
+	}
+	if (n_chunks > 1) { // everything after this point is ordered behind the last build on `stream` again
+		HIPCHK(hipEventRecord(h->join_ev, h->stream2));
+		HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
+	}
+	{
+		const int rc0 = span_end(h, wall);
+		if (rc0) return rc0;
+	}
+	if (dbg_l2 || dbg_build) {
+		g_last_error = "DBGK_DEBUG_L2 / DBGK_DEBUG_BUILD set: timing experiment, no valid table was built";
 		return DBGK_ERR_STATE;
 	}
-	rc = span_begin(h, PH_BUILD, sp);
-	if (rc) return rc;
-	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0; // timing experiments, results are wrong
-	if (dbg_build == 1)
-		hipLaunchKernelGGL(k_build_regions<1>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
-	else if (dbg_build == 2)
-		hipLaunchKernelGGL(k_build_regions<2>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
-	else if (dbg_build == 3)
-		hipLaunchKernelGGL(k_build_regions<3>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
-	else
-		hipLaunchKernelGGL(k_build_regions<0>, dim3(G.n_regions_own), dim3(kBuildThreads), sizeof(BuildLds), h->stream, G, h->store, h->table, h->d_ctr);
-	HIPCHK(hipGetLastError());
-	rc = span_end(h, sp);
-	if (rc) return rc;
-	if (dbg_build) {
-		g_last_error = "DBGK_DEBUG_BUILD set: build timing experiment, the table is garbage";
-		return DBGK_ERR_STATE;
-	}
+	TimedSpan sp;
+	int rc;
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
@@ -1407,8 +1467,8 @@ extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 	out->slot_lo = G.slot_lo;
 	out->slot_hi = G.slot_hi;
 	out->table_slots_global = h->size;
-	out->chunk_bytes = (uint64_t)G.B * G.cap1 * 8;
-	out->cnt_chunk_bytes = (uint64_t)G.B * 4;
+	out->chunk_bytes = (uint64_t)G.B * G.n_sub * G.cap1 * 8;
+	out->cnt_chunk_bytes = (uint64_t)G.B * G.n_sub * 4;
 	out->d_send = h->store.l1;
 	out->d_send_cnt = h->store.cnt1;
 	out->d_recv = h->sharded ? (void *)h->inbox : (void *)h->store.l1;
@@ -1573,6 +1633,8 @@ extern "C" int dbgk_get_timings(dbgk_handle *h, dbgk_timings *out)
 	out->fixup_ms = h->phase_ms[PH_FIXUP];
 	out->finalize_ms = h->phase_ms[PH_FINALIZE];
 	out->insert_launches = h->insert_launches;
+	out->l2_build_wall_ms = h->phase_ms[PH_L2_BUILD_WALL];
+	out->partition_launches = h->partition_launches;
 	return DBGK_OK;
 }
 
@@ -1581,6 +1643,7 @@ extern "C" int dbgk_reset_timings(dbgk_handle *h)
 	if (!h) return DBGK_ERR_ARG;
 	for (auto &v : h->phase_ms) v = 0.f;
 	h->insert_launches = 0;
+	h->partition_launches = 0;
 	return DBGK_OK;
 }
 

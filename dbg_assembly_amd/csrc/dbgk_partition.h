@@ -28,6 +28,7 @@ constexpr int kSpillSlots = 128;                // LDS slots past the region end
 constexpr int kTileThreads = 1024;              // scatter kernels: 16 waves
 constexpr int kTileRecords = kTileThreads * 16; // level 2: 16384 records staged in LDS (128 KiB), one workgroup per CU
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
+constexpr int kSubStores = 1;                   // level-1 sub-stores per bucket (8 = one per XCD was measured: 7.04 ms against 7.07, so off)
 constexpr int kBPT = kMaxBuckets / kTileThreads; // histogram entries owned by one thread
 constexpr int kL1Threads = kTileThreads;        // level-1 kernel: same tile geometry as level 2
 #ifndef DBGK_SCHED_WINDOW
@@ -78,16 +79,18 @@ struct PartGeom {
 	// part of the table.  n_ranks == 1: b_lo = 0, nb_own = n1, the whole table.
 	uint32_t n_ranks, rank;
 	uint32_t B;          // level-1 buckets per rank = ceil(n1 / n_ranks); the level-1 store has n_ranks * B buckets
+	uint32_t n_sub;      // sub-stores per level-1 bucket (kSubStores): workgroup w appends to sub-store w % n_sub, i.e.
+	                     // (round-robin dispatch) all appends to one sub-store come through ONE XCD's L2 and merge there
 	uint32_t b_lo, nb_own;
 	uint32_t n_regions_own;
 	uint64_t slot_lo, slot_hi;
 };
 
 struct PartStore {
-	uint64_t *l1;                 // [n_ranks * B][cap1]: what this rank extracted, by GLOBAL level-1 bucket
-	uint32_t *cnt1;               // [n_ranks * B] records appended (may exceed cap1: excess went to ovf)
-	const uint64_t *inbox;        // [n_ranks][B][cap1]: level-1 buckets of MY slot range from every rank
-	const uint32_t *inbox_cnt;    // [n_ranks * B]      (n_ranks == 1: inbox == l1, inbox_cnt == cnt1)
+	uint64_t *l1;                 // [n_ranks * B][n_sub][cap1]: what this rank extracted, by GLOBAL level-1 bucket and sub-store
+	uint32_t *cnt1;               // [n_ranks * B][n_sub] records appended (may exceed cap1: excess went to ovf)
+	const uint64_t *inbox;        // [n_ranks][B][n_sub][cap1]: level-1 buckets of MY slot range from every rank
+	const uint32_t *inbox_cnt;    // [n_ranks * B * n_sub]   (n_ranks == 1: inbox == l1, inbox_cnt == cnt1)
 	uint64_t *l2;                 // [nb_own * n2][cap2], local final bucket = (b1 - b_lo) * n2 + b2
 	uint32_t *cnt2;               // [nb_own * n2]
 	Node *outgoing;               // nodes that probed past the end of this shard: for the next rank
@@ -143,21 +146,33 @@ __device__ __forceinline__ uint32_t fresh_tid()
 }
 
 // ---- workgroup-wide bucket scatter of up to 16 records per thread ------------------------------
-struct ScatterLds {
-	uint64_t stage[kTileRecords];
+template <int THREADS>
+struct ScatterLdsT {
+	static constexpr int kThreads = THREADS;           // workgroup size
+	static constexpr int kRecords = THREADS * 16;      // records staged per tile
+	static constexpr int kBpt = kMaxBuckets / THREADS; // histogram entries owned by one thread
+	uint64_t stage[kRecords];
 	uint32_t hist[kMaxBuckets + 64]; // + one dummy bin per lane (level 1: positions that yield no record)
 	uint32_t lbase[kMaxBuckets];
 	uint64_t desc[kMaxBuckets];      // copy-out descriptor per bucket (scatter_stage_copy)
-	uint32_t wave_tot[kTileThreads / 64];
+	uint32_t wave_tot[THREADS / 64];
 };
+using ScatterLds = ScatterLdsT<kTileThreads>;   // level 1: 16384-record tiles, one workgroup per CU
+#ifndef DBGK_L2_THREADS
+#define DBGK_L2_THREADS 512
+#endif
+constexpr int kL2Threads = DBGK_L2_THREADS;
+using ScatterLdsL2 = ScatterLdsT<kL2Threads>;
 
-// exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries kBPT*t .. kBPT*t+kBPT-1
-__device__ __forceinline__ void scan_hist(ScatterLds &L)
+// exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries LDS::kBpt*t .. LDS::kBpt*t+LDS::kBpt-1
+template <class LDS>
+__device__ __forceinline__ void scan_hist(LDS &L)
 {
 	const int t = (int)fresh_tid(), lane = t & 63, wave = t >> 6;
-	uint32_t v[kBPT], sum = 0;
+	constexpr int kBpt = LDS::kBpt;
+	uint32_t v[kBpt], sum = 0;
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) { v[j] = L.hist[kBPT * t + j]; sum += v[j]; }
+	for (int j = 0; j < LDS::kBpt; j++) { v[j] = L.hist[LDS::kBpt * t + j]; sum += v[j]; }
 	uint32_t inc = sum;
 #pragma unroll
 	for (int off = 1; off < 64; off <<= 1) {
@@ -168,24 +183,26 @@ __device__ __forceinline__ void scan_hist(ScatterLds &L)
 	lds_barrier();
 	uint32_t run = inc - sum;
 #pragma unroll
-	for (int w = 0; w < kTileThreads / 64; w++) run += (w < wave) ? L.wave_tot[w] : 0u; // branch-free: a rolled loop gets vectorised into a register hog
+	for (int w = 0; w < LDS::kThreads / 64; w++) run += (w < wave) ? L.wave_tot[w] : 0u; // branch-free: a rolled loop gets vectorised into a register hog
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) { L.lbase[kBPT * t + j] = run; run += v[j]; }
+	for (int j = 0; j < LDS::kBpt; j++) { L.lbase[LDS::kBpt * t + j] = run; run += v[j]; }
 }
 
 // Phases of the workgroup-wide bucket scatter of one tile (<= 16 records per thread).
 //   br[u] = (bucket << 16) | rank-within-bucket, bucket >= kMaxBuckets = no record
 
 // after every record has been ranked (hist complete): reserve global space, scan
-__device__ __forceinline__ void scatter_reserve_scan(ScatterLds &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[kBPT])
+template <class LDS>
+__device__ __forceinline__ void scatter_reserve_scan(LDS &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[LDS::kBpt],
+                                                     uint32_t stride = 1u) // bucket b counts in cnt[b * stride]
 {
 	const int t = (int)fresh_tid();
 	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
 	// round trip overlaps the scan and the staging writes
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) {
-		const uint32_t b = kBPT * t + j, c = L.hist[b];
-		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b], c) : 0u;
+	for (int j = 0; j < LDS::kBpt; j++) {
+		const uint32_t b = LDS::kBpt * t + j, c = L.hist[b];
+		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], c) : 0u;
 	}
 	scan_hist(L);
 	lds_barrier();
@@ -199,11 +216,11 @@ __device__ __forceinline__ void scatter_reserve_scan(ScatterLds &L, uint32_t n_b
 // bucket and wave.  The vector-memory pipe costs ~27 clocks per store instruction per CU whatever
 // the number of active lanes (profiles/dbg_modes_l2.sh), which makes the instruction count the cost:
 // level 2 went from 6.3 to 5.3 ms.
-template <int PER_THREAD, int DBG = 0, bool FLAT = false>
-__device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
-                                                   const uint32_t (&my_gbase)[kBPT], uint32_t n_buckets, uint64_t *__restrict__ out,
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, class LDS>
+__device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
+                                                   const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
-                                                   const PartStore &P, Counters *ctr)
+                                                   const PartStore &P, Counters *ctr, uint32_t stride = 1u) // bucket b lives at out + b * stride * cap
 {
 	const int t = (int)fresh_tid();
 #pragma unroll
@@ -213,8 +230,8 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 	}
 	// one descriptor per bucket for the copy-out: global offset | records in this tile | first staged index
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) {
-		const uint32_t b = kBPT * t + j;
+	for (int j = 0; j < LDS::kBpt; j++) {
+		const uint32_t b = LDS::kBpt * t + j;
 		L.desc[b] = ((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b];
 	}
 	lds_barrier();
@@ -223,7 +240,7 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 			const uint32_t total = L.lbase[n_buckets - 1u] + L.hist[n_buckets - 1u];
 #pragma unroll
 			for (int u = 0; u < PER_THREAD; u++) {
-				const uint32_t p = (uint32_t)u * kTileThreads + (uint32_t)t;
+				const uint32_t p = (uint32_t)u * LDS::kThreads + (uint32_t)t;
 				if (p >= total) continue;
 				const uint64_t rcd = L.stage[p];
 				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits)) & (n_buckets - 1u);
@@ -246,7 +263,7 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 	// bucket in ONE LDS read; the loop then broadcasts descriptor k with readlane, so every per-bucket
 	// quantity is scalar and an iteration is an LDS read of the staged run plus one coalesced store.
 	const uint32_t lane = t & 63, wave = t >> 6;
-	constexpr uint32_t kWaves = kTileThreads / 64;
+	constexpr uint32_t kWaves = LDS::kThreads / 64;
 	const uint32_t per_wave = (DBG == 2) ? 0u : (n_buckets + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * k < n_buckets
 	const uint32_t mine = wave + kWaves * lane;
 	const uint64_t d = (lane < per_wave) ? L.desc[mine] : 0ull; // per_wave <= kMaxBuckets / kWaves = 64
@@ -259,9 +276,9 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 		const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
 		if (n == 0) continue;
 		const uint32_t b = wave + kWaves * k;
-		uint64_t *o = out + (uint64_t)b * cap + dst;
+		uint64_t *o = out + (uint64_t)b * stride * cap + dst;
 		if (DBG == 3) { // timing experiment: same instruction stream, stores land in a 32 KiB window per workgroup (no HBM write traffic)
-			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + dst + i) & 4095ull)] = L.stage[src + i];
+			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * stride * cap + dst + i) & 4095ull)] = L.stage[src + i];
 		} else if ((uint64_t)dst + n <= cap) {
 			for (uint32_t i = lane; i < n; i += 64) o[i] = L.stage[src + i];
 		} else { // the bucket is full: records beyond its capacity go to the overflow list
@@ -280,15 +297,15 @@ __device__ __forceinline__ void scatter_stage_copy(ScatterLds &L, const uint64_t
 }
 
 // whole scatter for records held in registers (level 2)
-template <int PER_THREAD, int DBG = 0, bool FLAT = false>
-__device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec)[PER_THREAD], uint32_t (&bkt)[PER_THREAD],
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, class LDS>
+__device__ __forceinline__ void scatter_tile(LDS &L, const uint64_t (&rec)[PER_THREAD], uint32_t (&bkt)[PER_THREAD],
                                              uint32_t n_buckets, uint32_t *__restrict__ cnt, uint64_t *__restrict__ out,
                                              uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                              const PartStore &P, Counters *ctr)
 {
 	const int t = (int)fresh_tid();
 #pragma unroll
-	for (int j = 0; j < kBPT; j++) L.hist[kBPT * t + j] = 0;
+	for (int j = 0; j < LDS::kBpt; j++) L.hist[LDS::kBpt * t + j] = 0;
 	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) bkt[u] = (bkt[u] << 16) | ((bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u);
@@ -300,7 +317,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const uint64_t (&rec
 		if (x == 0x1234567u) out[threadIdx.x] = x;
 		return;
 	}
-	uint32_t my_gbase[kBPT];
+	uint32_t my_gbase[LDS::kBpt];
 	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
 	scatter_stage_copy<PER_THREAD, DBG, FLAT>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
 }
@@ -555,37 +572,49 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 		}
 		const RawChunk nxt = fetch(tile + gridDim.x);
 		lds_barrier(); // hist complete
-		uint32_t my_gbase[kBPT];
-		scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
+		uint32_t my_gbase[ScatterLds::kBpt];
+		const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
+		scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 		uint64_t rec[16];
 #pragma unroll
 		for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 		lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
-		scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1, G.cap1, 0u, true, G, P, ctr);
+		scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 		raw = nxt;
 	}
 }
 
 // ---- level 2: split every level-1 bucket into its n2 final buckets -----------------------------
-// Inbox entry e = (source rank s = e / B, own bucket j = e % B): one level-1 bucket of this
-// shard's slot range as extracted by rank s.  k_plan_l2: tile_prefix[e] = number of 16384-record
-// tiles in entries < e (entries with j >= nb_own are empty).  One workgroup, entries strided.
-constexpr int kMaxInboxEntries = 8192; // n_ranks * B <= n1 + n_ranks
+// Inbox entry e = (s * B + j) * n_sub + x: sub-store x of level-1 bucket j of this shard's slot range
+// as extracted by rank s.  The tile list is flattened OWN-BUCKET-MAJOR, f = (j * n_ranks + s) * n_sub + x,
+// so that a range of own buckets [j0, j1) is a contiguous range of tiles (the finalize runs level 2 and the build in chunks of
+// buckets on two streams).  k_plan_l2: tile_prefix[f] = number of tiles in flat entries < f
+// (entries with j >= nb_own are empty).  One workgroup, entries strided.
+constexpr int kMaxInboxEntries = 16384; // n_ranks * B * n_sub <= (n1 + n_ranks) * n_sub
+
+__device__ __forceinline__ uint32_t flat_to_entry(const PartGeom &G, uint32_t f, uint32_t &j_out)
+{
+	const uint32_t per_j = G.n_ranks * G.n_sub;
+	const uint32_t j = f / per_j, rem = f - j * per_j, src = rem / G.n_sub, x = rem - src * G.n_sub;
+	j_out = j;
+	return (src * G.B + j) * G.n_sub + x;
+}
 
 __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P, uint32_t *__restrict__ tile_prefix)
 {
 	__shared__ uint32_t tot[kMaxBuckets / 64];
 	__shared__ uint32_t carry;
 	const int t = (int)fresh_tid(), lane = t & 63, wave = t >> 6;
-	const uint32_t n_entries = G.n_ranks * G.B;
+	const uint32_t n_entries = G.n_ranks * G.B * G.n_sub;
 	if (t == 0) carry = 0;
 	__syncthreads();
 	for (uint32_t base = 0; base < n_entries; base += kMaxBuckets) {
-		const uint32_t e = base + (uint32_t)t;
-		uint32_t v = 0;
-		if (e < n_entries && (e % G.B) < G.nb_own) {
-			const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
-			v = (uint32_t)((filled + kTileRecords - 1) / kTileRecords);
+		const uint32_t e = base + (uint32_t)t; // flat index f
+		uint32_t v = 0, own_j = 0;
+		const uint32_t entry = e < n_entries ? flat_to_entry(G, e, own_j) : 0u;
+		if (e < n_entries && own_j < G.nb_own) {
+			const uint64_t filled = P.inbox_cnt[entry] < G.cap1 ? P.inbox_cnt[entry] : G.cap1;
+			v = (uint32_t)((filled + ScatterLdsL2::kRecords - 1) / ScatterLdsL2::kRecords);
 		}
 		uint32_t inc = v;
 #pragma unroll
@@ -615,35 +644,43 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 #pragma unroll
 	for (int u = 0; u < 16; u++) rec[u] = ~0ull;
 	if (g >= n_tiles) return;
-	uint32_t lo = 0, hi = G.n_ranks * G.B; // last entry with tile_prefix[e] <= g (empty entries repeat the prefix: take the last)
+	uint32_t lo = 0, hi = G.n_ranks * G.B * G.n_sub; // last flat entry with tile_prefix[f] <= g (empty entries repeat the prefix: take the last)
 	while (hi - lo > 1) {
 		const uint32_t mid = (lo + hi) >> 1;
 		if (tile_prefix[mid] <= g) lo = mid; else hi = mid;
 	}
-	const uint32_t e = lo;
-	b1_out = e % G.B; // own bucket index j
+	uint32_t own_j;
+	const uint32_t e = flat_to_entry(G, lo, own_j);
+	b1_out = own_j; // own bucket index j
 	const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
-	const uint64_t first = (uint64_t)(g - tile_prefix[e]) * kTileRecords;
+	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * ScatterLdsL2::kRecords;
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
 #pragma unroll
 	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
-		const uint64_t i = first + (uint64_t)u * kTileThreads + tid;
+		const uint64_t i = first + (uint64_t)u * kL2Threads + tid;
 		if (i < filled) rec[u] = __builtin_nontemporal_load(in + i);
 	}
 }
 
 template <int DBG = 0>
-__global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
-                                                             Counters *__restrict__ ctr)
+__global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
+                                                             Counters *__restrict__ ctr, uint32_t j0, uint32_t j1)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	ScatterLds &L = *reinterpret_cast<ScatterLds *>(lds_raw);
-	const uint32_t n_tiles = tile_prefix[G.n_ranks * G.B];
+	ScatterLdsL2 &L = *reinterpret_cast<ScatterLdsL2 *>(lds_raw);
+	const uint32_t first_tile = tile_prefix[j0 * G.n_ranks * G.n_sub], n_tiles = tile_prefix[j1 * G.n_ranks * G.n_sub]; // tiles of the own buckets [j0, j1)
+	// XCD-aware tile order: workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
+	// correctness), so XCD x takes the x-th eighth of the tile range -- whole level-1 buckets -- and every
+	// append point of a final bucket is fed through ONE L2: neighbouring 128-byte runs merge into full
+	// lines there instead of leaving eight XCDs as partial-line writes.
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, n_local = gridDim.x >> 3; // gridDim.x is a multiple of 8
+	const uint32_t span = n_tiles - first_tile;
+	const uint32_t lo_tile = first_tile + (uint32_t)(((uint64_t)span * xcd) >> 3), hi_tile = first_tile + (uint32_t)(((uint64_t)span * (xcd + 1u)) >> 3);
 	uint64_t nxt[16];
 	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
-	l2_load_tile(G, P, tile_prefix, blockIdx.x, n_tiles, nxt, nxt_b1);
-	for (uint32_t g = blockIdx.x; g < n_tiles; g += gridDim.x) {
+	l2_load_tile(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1);
+	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
 		uint64_t rec[16];
 		uint32_t bkt[16];
 		const uint32_t j = nxt_b1;
@@ -653,7 +690,7 @@ __global__ __launch_bounds__(kTileThreads) void k_scatter_l2(PartGeom G, PartSto
 			// an all-ones word is never a record: the neighbour fields only take the values 0..4
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
 		}
-		l2_load_tile(G, P, tile_prefix, g + gridDim.x, n_tiles, nxt, nxt_b1); // in flight during the scatter below
+		l2_load_tile(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
 		scatter_tile<16, DBG, true>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
 	}
 }
@@ -674,11 +711,11 @@ struct BuildLds {
 // 3 = emit without recomputing the keys
 template <int DBG = 0>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
-                                                                  Counters *__restrict__ ctr)
+                                                                  Counters *__restrict__ ctr, uint32_t first_region)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	BuildLds &L = *reinterpret_cast<BuildLds *>(lds_raw);
-	const uint32_t f = blockIdx.x;                       // LOCAL final bucket == local region index == (slot - slot_lo) >> 12
+	const uint32_t f = first_region + blockIdx.x;        // LOCAL final bucket == local region index == (slot - slot_lo) >> 12
 	const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits));
 	const uint64_t region_base = (uint64_t)f << kRegionBits;   // index into this shard's table
 	const uint64_t region_slot0 = G.slot_lo + region_base;     // global slot of the region's first entry

@@ -120,7 +120,11 @@ typedef struct dbgk_timings {
 	float fixup_ms;            /* PARTITION: overflow records through the direct path              */
 	float finalize_ms;         /* key-0 node, flags, count reduce                                  */
 	uint64_t insert_launches;  /* number of launches accumulated into insert_ms                    */
-	uint64_t reserved[3];
+	float l2_build_wall_ms;    /* PARTITION: wall time of the second-level scatter and the region build
+	                              together; they run concurrently on two streams, so partition_ms and
+	                              build_ms (sums of their launches) overlap and add up to more than this */
+	uint32_t partition_launches; /* launches accumulated into partition_ms (= into build_ms)         */
+	uint64_t reserved[2];
 } dbgk_timings;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
