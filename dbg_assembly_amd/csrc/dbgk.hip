@@ -783,8 +783,8 @@ static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_regi
 static int build_from_records(dbgk_handle *h)
 {
 	const PartGeom &G = h->geom;
-	static const int l2_wg_per_cu = getenv("DBGK_L2_WG_PER_CU") ? atoi(getenv("DBGK_L2_WG_PER_CU")) : 1;
-	const int l2_grid = h->n_cu * (l2_wg_per_cu > 0 ? l2_wg_per_cu : 1);
+	static const int l2_grid_env = getenv("DBGK_L2_GRID") ? atoi(getenv("DBGK_L2_GRID")) : 0; // tuning knob: level-2 workgroups (multiple of 8)
+	const int l2_grid = l2_grid_env >= 8 ? (l2_grid_env & ~7) : h->n_cu;
 	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;       // timing experiments, results are wrong
 	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
 	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 8; // 1 = level 2, then build
