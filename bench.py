@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--exchange", choices=["records", "nodes"], default="records",
                     help="N > 1: 'records' = slot-range ownership, level-1 buckets exchanged (default); "
                          "'nodes' = local tables, aggregated nodes exchanged by hash owner")
+    ap.add_argument("--exchange-chunks", type=int, default=8,
+                    help="N > 1, records flow: pieces the level-1 buckets travel in (the build of a piece overlaps "
+                         "the transfer of the next); 1 = one all-to-all, then the build")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +160,7 @@ def main():
             g.sync()
             return {"stored_kmers": n_reads * kpr, "count": 0}
         if sharded:
-            return sharded_finalize(g, device)
+            return sharded_finalize(g, device, exchange_chunks=args.exchange_chunks)
         st = g.finalize()
         if world > 1:
             return exchange_and_merge(engine)

@@ -42,7 +42,8 @@ class ShardInfo(C.Structure):
     _fields_ = [("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("table_slots_global", C.c_uint64),
                 ("slot_lo", C.c_uint64), ("slot_hi", C.c_uint64), ("d_send", C.c_void_p), ("d_recv", C.c_void_p),
                 ("chunk_bytes", C.c_uint64), ("d_send_cnt", C.c_void_p), ("d_recv_cnt", C.c_void_p),
-                ("cnt_chunk_bytes", C.c_uint64)]
+                ("cnt_chunk_bytes", C.c_uint64), ("buckets_per_rank", C.c_uint32), ("own_buckets", C.c_uint32),
+                ("bucket_bytes", C.c_uint64), ("cnt_bucket_bytes", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -101,6 +102,8 @@ SYMBOLS = [
     ("dbgk_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_shard_buffers", _i, [_vp, C.POINTER(ShardInfo)]),
     ("dbgk_shard_mark_exchanged", _i, [_vp]),
+    ("dbgk_shard_plan", _i, [_vp]),
+    ("dbgk_shard_build_range", _i, [_vp, C.c_uint32, C.c_uint32]),
     ("dbgk_shard_outgoing", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("dbgk_shard_overflow", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("dbgk_shard_merge", _i, [_vp, _vp, _u64, _i, _i]),
@@ -333,6 +336,12 @@ class Graph:
 
     def shard_mark_exchanged(self):
         _chk(lib().dbgk_shard_mark_exchanged(self._h), "dbgk_shard_mark_exchanged")
+
+    def shard_plan(self):
+        _chk(lib().dbgk_shard_plan(self._h), "dbgk_shard_plan")
+
+    def shard_build_range(self, j0, j1):
+        _chk(lib().dbgk_shard_build_range(self._h, j0, j1), "dbgk_shard_build_range")
 
     def shard_outgoing(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -108,6 +108,10 @@ struct dbgk_handle {
 	// PARTITION engine
 	bool part = false;            // records are partitioned at push time, table built at finalize
 	bool part_built = false;      // finalize already turned the records into the table
+	bool part_planned = false;    // level-2 tile plan made for this step (part_plan)
+	uint32_t next_bucket = 0;     // own level-1 buckets [0, next_bucket) have been handed to level 2 + build
+	uint32_t chunks_used = 0;     // chunk events consumed this step
+	TimedSpan wall_span;
 	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
 	PartGeom geom;
 	PartStore store;
@@ -272,6 +276,9 @@ static int reset_state(dbgk_handle *h)
 		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
 		h->exchanged = false;
+		h->part_planned = false;
+		h->next_bucket = 0;
+		h->chunks_used = 0;
 	} else {
 		int rc = zero_table_now(h);
 		if (rc) return rc;
@@ -780,82 +787,109 @@ static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_regi
 // full CU), the region build by instruction issue: they run CONCURRENTLY.  The own level-1 buckets
 // are cut into chunks; level 2 of chunk c+1 runs on `stream` while the regions of chunk c are built
 // on `stream2` (one 512-thread level-2 workgroup and one 1024-thread build workgroup fit a CU together).
-static int build_from_records(dbgk_handle *h)
+// ---- pieces of the finalize of the PARTITION engine ---------------------------------------------
+// part_plan: level-2 tile plan for all own buckets (needs every inbox fill count);
+// part_build_range: level 2 + region build of the own buckets [j0, j1), asynchronous, level 2 on
+// `stream`, the build behind it on `stream2`; part_finish: join, spill / overflow fix-ups.
+static int part_plan(dbgk_handle *h)
+{
+	if (h->part_planned) return DBGK_OK;
+	if (!h->stream2) {
+		HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+	}
+	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->geom, h->store, h->tile_prefix);
+	HIPCHK(hipGetLastError());
+	int rc = span_begin(h, PH_L2_BUILD_WALL, h->wall_span);
+	if (rc) return rc;
+	h->part_planned = true;
+	h->next_bucket = 0;
+	h->chunks_used = 0;
+	return DBGK_OK;
+}
+
+static int part_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1, bool two_streams)
 {
 	const PartGeom &G = h->geom;
 	static const int l2_grid_env = getenv("DBGK_L2_GRID") ? atoi(getenv("DBGK_L2_GRID")) : 0; // tuning knob: level-2 workgroups (multiple of 8)
 	const int l2_grid = l2_grid_env >= 8 ? (l2_grid_env & ~7) : h->n_cu;
 	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;       // timing experiments, results are wrong
 	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
+	if (j0 >= j1) return DBGK_OK;
+	hipStream_t bstream = two_streams ? h->stream2 : h->stream;
+	TimedSpan sp;
+	int rc = span_begin(h, PH_PARTITION, sp);
+	if (rc) return rc;
+	switch (dbg_l2) {
+		case 1: launch_l2<1>(h, l2_grid, j0, j1); break;
+		case 2: launch_l2<2>(h, l2_grid, j0, j1); break;
+		case 3: launch_l2<3>(h, l2_grid, j0, j1); break;
+		default: launch_l2<0>(h, l2_grid, j0, j1); break;
+	}
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	if (rc) return rc;
+	h->next_bucket = j1;
+	if (dbg_l2) return DBGK_OK; // never build regions from the garbage a timing experiment leaves behind
+	if (two_streams) {
+		if (h->chunk_ev.size() <= h->chunks_used) {
+			hipEvent_t e;
+			HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			h->chunk_ev.push_back(e);
+		}
+		hipEvent_t ev = h->chunk_ev[h->chunks_used++];
+		HIPCHK(hipEventRecord(ev, h->stream));
+		HIPCHK(hipStreamWaitEvent(bstream, ev, 0));
+	}
+	const uint32_t r0 = j0 * G.n2, r1 = std::min(j1 * G.n2, G.n_regions_own);
+	if (r1 <= r0) return DBGK_OK;
+	rc = span_begin(h, PH_BUILD, sp, bstream);
+	if (rc) return rc;
+	switch (dbg_build) {
+		case 1: launch_build<1>(h, bstream, r0, r1 - r0); break;
+		case 2: launch_build<2>(h, bstream, r0, r1 - r0); break;
+		case 3: launch_build<3>(h, bstream, r0, r1 - r0); break;
+		default: launch_build<0>(h, bstream, r0, r1 - r0); break;
+	}
+	HIPCHK(hipGetLastError());
+	return span_end(h, sp, bstream);
+}
+
+// Level 2 is bound by the memory system (8 waves per CU and 72 KiB of LDS reach the same time as a
+// full CU), the region build by instruction issue: they run CONCURRENTLY.  The own level-1 buckets
+// are cut into chunks; level 2 of chunk c+1 runs on `stream` while the regions of chunk c are built
+// on `stream2` (one 512-thread level-2 workgroup and one 1024-thread build workgroup fit a CU together).
+static int build_from_records(dbgk_handle *h)
+{
+	const PartGeom &G = h->geom;
+	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;
+	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
 	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 8; // 1 = level 2, then build
 	uint32_t n_chunks = (dbg_l2 || dbg_build || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
-	if (n_chunks > G.nb_own) n_chunks = G.nb_own ? G.nb_own : 1u;
-	if (n_chunks > 1 && !h->stream2) {
-		HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-		HIPCHK(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
-	}
-	while (h->chunk_ev.size() < n_chunks) {
-		hipEvent_t e;
-		HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-		h->chunk_ev.push_back(e);
-	}
-	hipStream_t bstream = n_chunks > 1 ? h->stream2 : h->stream;
-	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, G, h->store, h->tile_prefix);
-	HIPCHK(hipGetLastError());
-	TimedSpan wall;
-	{
-		const int rc0 = span_begin(h, PH_L2_BUILD_WALL, wall);
-		if (rc0) return rc0;
-	}
-	const uint32_t per = (G.nb_own + n_chunks - 1) / n_chunks;
-	for (uint32_t c = 0; c < n_chunks; c++) {
-		const uint32_t j0 = std::min(c * per, G.nb_own), j1 = std::min(j0 + per, G.nb_own);
-		if (j0 == j1) continue;
-		TimedSpan sp;
-		int rc = span_begin(h, PH_PARTITION, sp);
-		if (rc) return rc;
-		switch (dbg_l2) {
-			case 1: launch_l2<1>(h, l2_grid, j0, j1); break;
-			case 2: launch_l2<2>(h, l2_grid, j0, j1); break;
-			case 3: launch_l2<3>(h, l2_grid, j0, j1); break;
-			default: launch_l2<0>(h, l2_grid, j0, j1); break;
-		}
-		HIPCHK(hipGetLastError());
-		rc = span_end(h, sp);
-		if (rc) return rc;
-		if (dbg_l2) continue; // never build regions from the garbage a timing experiment leaves behind
-		if (n_chunks > 1) {
-			HIPCHK(hipEventRecord(h->chunk_ev[c], h->stream));
-			HIPCHK(hipStreamWaitEvent(bstream, h->chunk_ev[c], 0));
-		}
-		const uint32_t r0 = j0 * G.n2, r1 = std::min(j1 * G.n2, G.n_regions_own);
-		if (r1 <= r0) continue;
-		rc = span_begin(h, PH_BUILD, sp, bstream);
-		if (rc) return rc;
-		switch (dbg_build) {
-			case 1: launch_build<1>(h, bstream, r0, r1 - r0); break;
-			case 2: launch_build<2>(h, bstream, r0, r1 - r0); break;
-			case 3: launch_build<3>(h, bstream, r0, r1 - r0); break;
-			default: launch_build<0>(h, bstream, r0, r1 - r0); break;
-		}
-		HIPCHK(hipGetLastError());
-		rc = span_end(h, sp, bstream);
+	int rc = part_plan(h);
+	if (rc) return rc;
+	// whatever the caller has not built by ranges yet (dbgk_shard_build_range): all of it, normally
+	const uint32_t left = G.nb_own - std::min(h->next_bucket, G.nb_own);
+	if (n_chunks > left) n_chunks = left ? left : 1u;
+	const bool two_streams = n_chunks > 1 || h->chunks_used > 0;
+	const uint32_t per = (left + n_chunks - 1) / n_chunks;
+	for (uint32_t c = 0; c < n_chunks && h->next_bucket < G.nb_own; c++) {
+		const uint32_t j0 = h->next_bucket, j1 = std::min(j0 + per, G.nb_own);
+		rc = part_build_range(h, j0, j1, two_streams);
 		if (rc) return rc;
 	}
-	if (n_chunks > 1) { // everything after this point is ordered behind the last build on `stream` again
+	if (h->chunks_used > 0) { // everything after this point is ordered behind the last build on `stream` again
 		HIPCHK(hipEventRecord(h->join_ev, h->stream2));
 		HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
 	}
-	{
-		const int rc0 = span_end(h, wall);
-		if (rc0) return rc0;
-	}
+	rc = span_end(h, h->wall_span);
+	if (rc) return rc;
+	h->part_planned = false;
 	if (dbg_l2 || dbg_build) {
 		g_last_error = "DBGK_DEBUG_L2 / DBGK_DEBUG_BUILD set: timing experiment, no valid table was built";
 		return DBGK_ERR_STATE;
 	}
 	TimedSpan sp;
-	int rc;
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
@@ -1467,6 +1501,10 @@ extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 	out->slot_lo = G.slot_lo;
 	out->slot_hi = G.slot_hi;
 	out->table_slots_global = h->size;
+	out->buckets_per_rank = G.B;
+	out->own_buckets = G.nb_own;
+	out->bucket_bytes = (uint64_t)G.n_sub * G.cap1 * 8;
+	out->cnt_bucket_bytes = (uint64_t)G.n_sub * 4;
 	out->chunk_bytes = (uint64_t)G.B * G.n_sub * G.cap1 * 8;
 	out->cnt_chunk_bytes = (uint64_t)G.B * G.n_sub * 4;
 	out->d_send = h->store.l1;
@@ -1481,6 +1519,25 @@ extern "C" int dbgk_shard_mark_exchanged(dbgk_handle *h)
 	if (!h || !h->sharded) return DBGK_ERR_STATE;
 	h->exchanged = true;
 	return DBGK_OK;
+}
+
+extern "C" int dbgk_shard_plan(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->part || h->part_built || h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	return part_plan(h);
+}
+
+extern "C" int dbgk_shard_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->part || !h->part_planned || h->part_built || h->finalized) return DBGK_ERR_STATE;
+	if (j0 != h->next_bucket || j1 < j0 || j1 > h->geom.nb_own) return DBGK_ERR_ARG; // ranges are consumed in order, each bucket once
+	int rc = use_device(h);
+	if (rc) return rc;
+	return part_build_range(h, j0, j1, true);
 }
 
 static int shard_list(dbgk_handle *h, Node *list, unsigned long long *d_n, uint64_t cap, dbgk_node **d_nodes, uint64_t *n)

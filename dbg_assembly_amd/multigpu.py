@@ -114,7 +114,11 @@ def exchange_and_merge(engine, group=None):
 #
 #   1. all-reduce (sum) of the per-bucket record counts  -> global bucket fills (capacity check),
 #   2. all-to-all of the bucket fill counts and of the level-1 bucket stores themselves: chunk d of
-#      every rank's store goes to rank d (zero-copy slices of the library's own buffers),
+#      every rank's store goes to rank d (zero-copy slices of the library's own buffers).  The records
+#      travel in `exchange_chunks` pieces (ranges of own buckets, point-to-point sends/receives queued
+#      up front): the build of a piece starts as soon as it has arrived and overlaps the transfer of
+#      the next one -- every record crosses xGMI once (8 B x 7/8 of all k-mer occurrences per GPU),
+#      which takes about as long as the build itself,
 #   3. each rank builds only its slot range (level-2 partition + LDS region build),
 #   4. hand-offs that are normally empty or tiny: nodes whose probe ran off the end of a shard go
 #      to the next rank (ring), bucket-overflow observations are offered to every rank,
@@ -131,11 +135,27 @@ def wrap_device_memory(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def sharded_finalize(g, device, group=None, wrap=None):
+def _exchange_range(send, recv, info, j0, j1, world, rank, group):
+    """buckets [j0, j1) of every destination's chunk -> the same buckets of chunk `rank` at the destination"""
+    ops = []
+    for peer in range(world):
+        lo, hi = peer * info.chunk_bytes + j0 * info.bucket_bytes, peer * info.chunk_bytes + j1 * info.bucket_bytes
+        if peer == rank:
+            recv[lo:hi].copy_(send[lo:hi])
+        else:
+            ops.append(dist.P2POp(dist.isend, send[lo:hi], peer, group))
+            ops.append(dist.P2POp(dist.irecv, recv[lo:hi], peer, group))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+
+
+def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     """g: a sharded capi.Graph (shard_count == world, shard_index == rank) that has received all its
     pushes.  Performs steps 1-5 and returns the global totals; afterwards g's table holds this
     rank's slot range of the global table.  `wrap(ptr, nbytes, device)` turns the library's buffers
-    into tensors (default: zero-copy CUDA array interface; the gloo CPU test passes a host wrapper)."""
+    into tensors (default: zero-copy CUDA array interface; the gloo CPU test passes a host wrapper).
+    exchange_chunks <= 1: one all-to-all of the whole stores, then the build."""
     wrap_device_memory = wrap or globals()["wrap_device_memory"]
     on_gpu = torch.device(device).type == "cuda"
     world = dist.get_world_size(group)
@@ -155,9 +175,34 @@ def sharded_finalize(g, device, group=None, wrap=None):
 
     # 2. the exchange
     dist.all_to_all_single(recv_cnt, send_cnt, group=group)
-    dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=group)  # 8-byte records: counts stay < 2^31
-    if on_gpu:
-        torch.cuda.current_stream().synchronize()
+    n_chunks = max(1, min(int(exchange_chunks), int(info.buckets_per_rank)))
+    if n_chunks <= 1:
+        dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=group)  # 8-byte records: counts stay < 2^31
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
+    else:
+        # every rank cuts the SAME bucket ranges (buckets_per_rank is common; ranks that own fewer
+        # buckets build a shorter range but still take part in every transfer)
+        B = int(info.buckets_per_rank)
+        per = (B + n_chunks - 1) // n_chunks
+        ranges = [(j0, min(j0 + per, B)) for j0 in range(0, B, per)]
+        arrived = []
+        for j0, j1 in ranges:  # all transfers are queued before anything is waited for
+            _exchange_range(send, recv, info, j0, j1, world, rank, group)
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record()
+                arrived.append(ev)
+        planned = False
+        for i, (j0, j1) in enumerate(ranges):
+            if on_gpu:
+                arrived[i].synchronize()  # the fill counts (queued first) have arrived as well
+            if not planned:
+                g.shard_plan()
+                planned = True
+            own0, own1 = min(j0, int(info.own_buckets)), min(j1, int(info.own_buckets))
+            if own1 > own0:
+                g.shard_build_range(own0, own1)  # queues level 2 + build on the library's streams and returns
     g.shard_mark_exchanged()
 
     # 3. build this rank's slot range

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DBGK_ABI_VERSION 1
+#define DBGK_ABI_VERSION 2
 
 /* status codes */
 #define DBGK_OK               0
@@ -267,10 +267,22 @@ typedef struct dbgk_shard_info {
 	void    *d_send_cnt;           /* n_ranks chunks of cnt_chunk_bytes (u32 fill counts)          */
 	void    *d_recv_cnt;
 	uint64_t cnt_chunk_bytes;
+	/* a chunk is buckets_per_rank level-1 buckets of bucket_bytes each (fill counts: cnt_bucket_bytes);
+	 * this handle owns the first own_buckets of its range (the last rank may own fewer)          */
+	uint32_t buckets_per_rank, own_buckets;
+	uint64_t bucket_bytes, cnt_bucket_bytes;
 } dbgk_shard_info;
 
 int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out);
 int dbgk_shard_mark_exchanged(dbgk_handle *h);
+/* Exchange and build IN PIECES, so that the transfer of later buckets overlaps the build of earlier
+ * ones: once the fill counts have been exchanged call dbgk_shard_plan; whenever the records of the
+ * own buckets [j0, j1) have arrived from every rank (bucket j of chunk s of d_recv) call
+ * dbgk_shard_build_range(j0, j1) -- ranges in ascending order, each bucket once; the kernels are
+ * queued on the handle's streams and the call returns.  dbgk_shard_mark_exchanged + dbgk_finalize
+ * then build whatever is left and complete the step.                                            */
+int dbgk_shard_plan(dbgk_handle *h);
+int dbgk_shard_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1);
 /* after dbgk_finalize: device list of nodes that left this shard / of overflow observations
  * {kmer, lb | rb << 8}; the lists stay valid until the next dbgk_reset                            */
 int dbgk_shard_outgoing(dbgk_handle *h, dbgk_node **d_nodes, uint64_t *n);

@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """GPU sessions: bring torch's HIP runtime up BEFORE libdbgk.so is loaded.  The torch wheel bundles
+    its own libamdhip64 (ROCm 7.0) while libdbgk.so is linked against /opt/rocm's (7.2); loaded in this
+    order the process ends up with ONE runtime, in the other order torch.cuda.is_available() turns False
+    for the tests that need torch.distributed (test_gpu_multigpu.py).  bench.py does the same."""
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:  # noqa: BLE001 -- the tests that need torch report it themselves
+            pass
+
+
 def golden_cases():
     out = []
     for name in sorted(os.listdir(GOLDEN)):

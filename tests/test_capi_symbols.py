@@ -25,7 +25,7 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_errors():
     L = capi.lib()
-    assert L.dbgk_abi_version() == 1
+    assert L.dbgk_abi_version() == 2
     assert L.dbgk_strerror(capi.ERR_TABLE_FULL) == b"k-mer table full"
     # argument validation happens before any device work
     cfg = capi.Config(0, 250, 1009, 0, 0, 0, 0)

@@ -54,7 +54,8 @@ def test_exchange_and_merge_single_rank_nccl(engine):
         dist.destroy_process_group()
 
 
-def test_sharded_finalize_single_rank_nccl(oracle):
+@pytest.mark.parametrize("chunks", [8, 1])
+def test_sharded_finalize_single_rank_nccl(oracle, chunks):
     """slot-range ownership flow of bench.py (N > 1) with a one-rank shard: the all-to-all runs on
     the library's own device buffers wrapped as torch tensors, the handed-over nodes wrap around to
     the same shard; result == plain single-GPU build == oracle"""
@@ -79,7 +80,7 @@ def test_sharded_finalize_single_rank_nccl(oracle):
             for _ in range(2):  # two steps: the handle must be reusable (bench loop)
                 g.reset()
                 g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
-                out = sharded_finalize(g, torch.device("cuda", 0))
+                out = sharded_finalize(g, torch.device("cuda", 0), exchange_chunks=chunks)
             nodes = g.export_sorted()
             d_bases.free()
             d_off.free()

@@ -342,7 +342,7 @@ def test_full_size_direct_vs_partition_digest(capi):
 # sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
 # device copies.  Validates slot-range ownership end to end on real hardware.
 # ------------------------------------------------------------------------------------------------
-def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slots=PART_SLOTS, want_tables=True):
+def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slots=PART_SLOTS, want_tables=True, ranged=0):
     size = capi.find_next_prime_ref(slots)
     graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected_per_shard,
                          shard_count=n_shards, shard_index=i) for i in range(n_shards)]
@@ -356,10 +356,30 @@ def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slot
             assert a.slot_hi == b.slot_lo
         for s in range(n_shards):       # the all-to-all: chunk d of rank s -> slot s of rank d's inbox
             for d in range(n_shards):
-                graphs[0].memcpy_d2d(infos[d].d_recv + s * infos[d].chunk_bytes, infos[s].d_send + d * infos[s].chunk_bytes,
-                                     infos[s].chunk_bytes)
+                if not ranged:
+                    graphs[0].memcpy_d2d(infos[d].d_recv + s * infos[d].chunk_bytes, infos[s].d_send + d * infos[s].chunk_bytes,
+                                         infos[s].chunk_bytes)
                 graphs[0].memcpy_d2d(infos[d].d_recv_cnt + s * infos[d].cnt_chunk_bytes,
                                      infos[s].d_send_cnt + d * infos[s].cnt_chunk_bytes, infos[s].cnt_chunk_bytes)
+        if ranged:                      # the records travel in `ranged` pieces; every piece is built as soon as it is there
+            B = infos[0].buckets_per_rank
+            per = -(-B // ranged)
+            for g in graphs:
+                g.sync()
+                g.shard_plan()
+            for j0 in range(0, B, per):
+                j1 = min(j0 + per, B)
+                for s in range(n_shards):
+                    for d in range(n_shards):
+                        off_d, off_s = s * infos[d].chunk_bytes + j0 * infos[d].bucket_bytes, d * infos[s].chunk_bytes + j0 * infos[s].bucket_bytes
+                        graphs[0].memcpy_d2d(infos[d].d_recv + off_d, infos[s].d_send + off_s, (j1 - j0) * infos[s].bucket_bytes)
+                graphs[0].sync()
+                for g, info in zip(graphs, infos):
+                    own0, own1 = min(j0, info.own_buckets), min(j1, info.own_buckets)
+                    if own1 > own0:
+                        g.shard_build_range(own0, own1)
+                        with pytest.raises(capi.DbgkError):
+                            g.shard_build_range(own0, own1)  # a range is consumed once, in order
         stats = []
         for g in graphs:
             g.shard_mark_exchanged()
@@ -387,12 +407,12 @@ def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slot
             g.close()
 
 
-@pytest.mark.parametrize("n_shards", [2, 3])
-def test_sharded_table_equals_oracle(capi, oracle, n_shards):
+@pytest.mark.parametrize("n_shards,ranged", [(2, 0), (3, 0), (2, 4), (3, 64)])
+def test_sharded_table_equals_oracle(capi, oracle, n_shards, ranged):
     rng = random.Random(31 + n_shards)
     reads = rand_reads(rng, 4000, G=30000) + [b"A" * 150] * 300 + [b"T" * 99] * 50
     rng.shuffle(reads)
-    final, stats, nodes, infos, tables, (n_ovf, n_out), size = _sharded_build(capi, oracle, reads, n_shards, 600000)
+    final, stats, nodes, infos, tables, (n_ovf, n_out), size = _sharded_build(capi, oracle, reads, n_shards, 600000, ranged=ranged)
     ref = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=31, init_hash_size=0.002)
     assert sum(int(s.count) for s in final) == ref.count
     assert sum(int(s.total_kmers) for s in stats) == ref.total_kmers

@@ -151,17 +151,20 @@ class FakeShardGraph:
     bucketed by slot-range owner; finalize aggregates what arrived with numpy.  Only the interface
     sharded_finalize uses is provided."""
 
-    CAP = 1 << 15  # records per destination chunk
+    B = 5          # level-1 buckets per rank
+    CAP = 1 << 13  # records per bucket
 
     def __init__(self, O, reads, k, world, rank, size):
         self.O, self.world, self.rank, self.size = O, world, rank, size
         L = O.lib()
         span = -(-size // world)
+        sub = -(-span // self.B)
         self.slot_lo, self.slot_hi = rank * span, min(size, (rank + 1) * span)
-        self.send = np.zeros((world, self.CAP), NODE)
-        self.send_cnt = np.zeros((world, 1), np.uint32)
-        self.recv = np.zeros((world, self.CAP), NODE)
-        self.recv_cnt = np.zeros((world, 1), np.uint32)
+        self.send = np.zeros((world, self.B, self.CAP), NODE)
+        self.send_cnt = np.zeros((world, self.B), np.uint32)
+        self.recv = np.zeros((world, self.B, self.CAP), NODE)
+        self.recv_cnt = np.zeros((world, self.B), np.uint32)
+        self.calls, self.built = [], []
         self.polyA = np.zeros(8, np.int64)
         self.total_reads, self.total_kmers = len(reads), 0
         for seq in reads:
@@ -174,10 +177,12 @@ class FakeShardGraph:
                     if r != 4:
                         self.polyA[4 + r] += 1
                     continue
-                d = (L.orc_hash_code(key) % size) // span
-                i = int(self.send_cnt[d, 0])
-                self.send[d, i] = (key, l | (r << 8), 0)
-                self.send_cnt[d, 0] = i + 1
+                slot = L.orc_hash_code(key) % size
+                d = slot // span
+                j = (slot - d * span) // sub
+                i = int(self.send_cnt[d, j])
+                self.send[d, j, i] = (key, l | (r << 8), 0)
+                self.send_cnt[d, j] = i + 1
         self.nodes = np.zeros(0, NODE)
         self.extra = []
 
@@ -186,7 +191,9 @@ class FakeShardGraph:
             pass
         i = I()
         i.n_ranks, i.rank = self.world, self.rank
-        i.chunk_bytes, i.cnt_chunk_bytes = self.CAP * 16, 4
+        i.chunk_bytes, i.cnt_chunk_bytes = self.B * self.CAP * 16, self.B * 4
+        i.buckets_per_rank, i.own_buckets = self.B, self.B
+        i.bucket_bytes, i.cnt_bucket_bytes = self.CAP * 16, 4
         i.d_send, i.d_recv = self.send.ctypes.data, self.recv.ctypes.data
         i.d_send_cnt, i.d_recv_cnt = self.send_cnt.ctypes.data, self.recv_cnt.ctypes.data
         return i
@@ -196,6 +203,18 @@ class FakeShardGraph:
 
     def shard_mark_exchanged(self):
         self.exchanged = True
+
+    def shard_plan(self):
+        self.calls.append("plan")
+
+    def _take(self, j0, j1):
+        for j in range(j0, j1):
+            self.built.append(np.concatenate([self.recv[s, j, :int(self.recv_cnt[s, j])] for s in range(self.world)]))
+
+    def shard_build_range(self, j0, j1):
+        assert self.calls and self.calls[0] == "plan" and j0 == sum(b - a for _, a, b in self.calls[1:])  # in order, once
+        self.calls.append(("range", j0, j1))
+        self._take(j0, j1)  # what has arrived by now is what gets built: a late transfer would lose records
 
     def _aggregate(self, triples):
         if len(triples) == 0:
@@ -211,7 +230,9 @@ class FakeShardGraph:
 
     def finalize(self):
         assert self.exchanged
-        got = np.concatenate([self.recv[s, :int(self.recv_cnt[s, 0])] for s in range(self.world)])
+        done = sum(b - a for _, a, b in self.calls[1:])
+        self._take(done, self.B)  # whatever the caller did not build by ranges
+        got = np.concatenate(self.built)
         keys, cnt = self._aggregate(got)
         self.keys, self.cnt = keys, cnt
 
@@ -260,7 +281,7 @@ def _wrap_host(ptr, nbytes, device):
     return torch.frombuffer((C.c_uint8 * int(nbytes)).from_address(int(ptr)), dtype=torch.uint8)
 
 
-def _shard_worker(rank, world, port, reads, k, size, q):
+def _shard_worker(rank, world, port, reads, k, size, q, chunks):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import oracle_py as O
@@ -269,14 +290,15 @@ def _shard_worker(rank, world, port, reads, k, size, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = FakeShardGraph(O, reads[rank::world], k, world, rank, size)
-    out = sharded_finalize(g, "cpu", wrap=_wrap_host)
+    out = sharded_finalize(g, "cpu", wrap=_wrap_host, exchange_chunks=chunks)
+    out["ranged_calls"] = len(g.calls)
     q.put((rank, out, g.result_nodes().tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_finalize_gloo(oracle, world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 3), (3, 8)])
+def test_sharded_finalize_gloo(oracle, world, chunks):
     rng = random.Random(9)
     g = "".join(rng.choice("ACGT") for _ in range(2500))
     reads = []
@@ -289,7 +311,7 @@ def test_sharded_finalize_gloo(oracle, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, reads, k, size, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, reads, k, size, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
@@ -301,3 +323,4 @@ def test_sharded_finalize_gloo(oracle, world):
     assert np.array_equal(merged, whole.nodes.astype(NODE))
     for rank, out, _ in results:
         assert (out["count"], out["total_reads"], out["total_kmers"]) == (whole.count, whole.total_reads, whole.total_kmers)
+        assert (out["ranged_calls"] > 1) == (chunks > 1)  # the pieces were built as they arrived
