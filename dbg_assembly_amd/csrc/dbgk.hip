@@ -216,6 +216,7 @@ static void free_handle(dbgk_handle *h)
 {
 	if (!h) return;
 	(void)hipSetDevice(h->device);
+	if (h->stream2) (void)hipStreamSynchronize(h->stream2); // region builds of an unfinished ranged finalize
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	for (auto &s : h->slots) {
 		if (s.h_bases) (void)hipHostFree(s.h_bases);
@@ -271,6 +272,10 @@ static int reset_state(dbgk_handle *h)
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
 		h->part_built = false;
+		if (h->chunks_used > 0 && h->stream2) { // a ranged finalize was abandoned: its builds must not race the reset
+			HIPCHK(hipEventRecord(h->join_ev, h->stream2));
+			HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
+		}
 		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
