@@ -7,9 +7,11 @@
 // by one workgroup and written out once with coalesced 16-byte stores:
 //
 //   k_extract_scatter   reads -> records, scattered into n1 level-1 buckets (slot >> r)
-//   k_scatter_l2        every level-1 bucket -> n2 = 2^(r-12) final buckets (slot >> 12)
+//   k_scatter_l2        every level-1 bucket -> n2 = 2^(r-12) final buckets (slot >> 12); XCD-aware
+//                       tile order so that every append point is fed through one L2
 //   k_build_regions     one workgroup per final bucket: LDS open addressing on the region's own
-//                       slots (ds_cmpst claims, LDS CAS saturating counters), emit the region
+//                       slots (ds_cmpst claims, LDS CAS saturating counters), emit the region;
+//                       runs concurrently with k_scatter_l2 of the next bucket chunk (dbgk.hip)
 //   k_insert_triples    the few records that found no room in their bucket, through the
 //                       global-atomic path; region spill-over nodes go through k_merge_nodes
 //
@@ -25,17 +27,10 @@ namespace dbgk {
 constexpr int kRegionBits = 12;                 // 4096 slots = 64 KiB of nodes per region
 constexpr int kRegionSlots = 1 << kRegionBits;
 constexpr int kSpillSlots = 128;                // LDS slots past the region end: probe overflow
-constexpr int kTileThreads = 1024;              // scatter kernels: 16 waves
-constexpr int kTileRecords = kTileThreads * 16; // level 2: 16384 records staged in LDS (128 KiB), one workgroup per CU
+constexpr int kTileThreads = 1024;              // level 1: 16 waves, 16384-record tiles (level 2: kL2Threads below)
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
 constexpr int kSubStores = 1;                   // level-1 sub-stores per bucket (8 = one per XCD was measured: 7.04 ms against 7.07, so off)
-constexpr int kBPT = kMaxBuckets / kTileThreads; // histogram entries owned by one thread
-constexpr int kL1Threads = kTileThreads;        // level-1 kernel: same tile geometry as level 2
-#ifndef DBGK_SCHED_WINDOW
-#define DBGK_SCHED_WINDOW 0
-#endif
-constexpr uint32_t kSchedWindow = DBGK_SCHED_WINDOW; // positions the scheduler may interleave in the extraction loop (0 = all 16)
-constexpr int kL1BPT = kMaxBuckets / kL1Threads;
+constexpr int kL1Threads = kTileThreads;
 constexpr int kBuildThreads = 1024;            // 2 workgroups per CU (66 KiB LDS each) = 32 waves per CU, needs <= 64 VGPRs
 
 // ---- inverse of hash_code ------------------------------------------------------------------
@@ -101,11 +96,6 @@ struct PartStore {
 	unsigned long long *ovf_n;    // [0] = overflow triples, [1] = spill nodes
 	uint64_t ovf_cap, spill_cap;
 };
-
-__device__ __forceinline__ uint64_t make_record(uint64_t q, uint64_t slot, uint32_t r, uint32_t lb, uint32_t rb)
-{
-	return (q << (r + 6)) | ((slot & ((1ull << r) - 1ull)) << 6) | ((uint64_t)lb << 3) | (uint64_t)rb;
-}
 
 __device__ __forceinline__ uint64_t record_key(uint64_t rec, uint32_t b1, const PartGeom &G)
 {
@@ -456,9 +446,6 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 	return c;
 }
 
-// complement of a neighbour code that may be 4 (= none): 0<->3, 1<->2, 4 -> 4
-__device__ __forceinline__ uint32_t comp_code(uint32_t x) { return (0x4053u >> (x * 3u)) & 7u; } // packs {3,2,1,0,4}
-
 // ---- level 1: extraction fused with the first scatter ------------------------------------------
 // (A variant without LDS staging -- every lane storing its own 8-byte records into the reserved
 // bucket ranges -- was measured at 24.5 ms against 10.4 ms for the staged form: uncoalesced 8-byte
@@ -535,9 +522,6 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 				// roll to the next position (DBGgraph.cpp:71-73)
 				c.kbit = ((c.kbit << 2) | right) & head_mask;
 				c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
-				// keep the scheduler from interleaving all 16 positions (register pressure: the
-				// workgroup has 1024 threads, so 128 VGPRs per lane is the ceiling)
-				if (kSchedWindow && (i % (kSchedWindow ? kSchedWindow : 1)) == (kSchedWindow ? kSchedWindow : 1) - 1u) __builtin_amdgcn_sched_barrier(0);
 			}
 			// windows without a left / right neighbour: that side's code becomes 4 = none
 			const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
