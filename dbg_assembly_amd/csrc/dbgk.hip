@@ -265,8 +265,8 @@ static int zero_table_now(dbgk_handle *h)
 
 static int reset_state(dbgk_handle *h)
 {
-	if (h->kfreq) {
-		HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
+	if (h->kfreq) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
+	if (h->kfreq && !h->part) {
 	} else if (h->part) {
 		// the region build of finalize overwrites every slot, so the 16 B/slot memset is only needed
 		// if a direct-path write (merge) happens first
@@ -309,7 +309,9 @@ static int plan_partition(dbgk_handle *h)
 	memset(&h->geom, 0, sizeof h->geom);
 	h->tslots = h->size;
 	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
-	const int want = h->cfg.engine == DBGK_ENGINE_SEEDIDX ? DBGK_ENGINE_DIRECT : h->cfg.engine; // the seed index uses the plain table
+	const int want = h->cfg.engine == DBGK_ENGINE_SEEDIDX ? DBGK_ENGINE_DIRECT // the seed index uses the plain table
+	                 : h->cfg.engine == DBGK_ENGINE_KFREQ ? DBGK_ENGINE_AUTO   // KFREQ: only if the geometry is feasible
+	                                                      : h->cfg.engine;
 	const bool want_shard = h->cfg.shard_count >= 1; // shard_count == 1: one-rank sharded handle (same protocol, for testing)
 	if (want_shard && h->cfg.shard_index >= n_ranks) return DBGK_ERR_ARG;
 	if (!want_shard) {
@@ -406,6 +408,7 @@ static int setup_partition(dbgk_handle *h)
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
@@ -442,13 +445,31 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->seed = seed;
 	if (seed) h->cfg.max_read_len = 0x7FFFFFFF; // contigs are never trimmed (the pos field bounds them, see push)
 	h->size = kfreq ? 3 : cfg->table_slots;
+	// KFREQ with a known input size runs through the PARTITION engine: occurrences are partitioned by
+	// hash_code(key) % size like graph records and aggregated per key in LDS; `size` is only the modulus
+	// (no node table exists), chosen so that the LDS regions stay about half empty even if every second
+	// occurrence were a new key.  Without expected_kmers: direct atomics on the byte table.
+	static const bool kf_direct = getenv("DBGK_KFREQ_DIRECT") != nullptr;
+	const bool kf_part = kfreq && cfg->expected_kmers > 0 && cfg->shard_count == 0 && !kf_direct;
+	if (kf_part) {
+		const uint64_t want = std::max<uint64_t>(1ull << 26, cfg->expected_kmers / 2);
+		h->size = std::min<uint64_t>(want, (1ull << 32) - (1ull << 23)) | 1ull;
+	}
 	h->magic = make_mod_magic(h->size);
 	h->tslots = h->size;
-	if (!kfreq) {
+	if (!kfreq || kf_part) {
 		const int prc = plan_partition(h); // geometry first: a sharded handle holds only its slot range
 		if (prc != DBGK_OK) {
 			delete h;
 			return prc;
+		}
+		if (kfreq) {
+			if (!h->part) { // infeasible geometry: fall back to the direct table
+				h->size = 3;
+				h->magic = make_mod_magic(h->size);
+			}
+			h->geom.kf = h->part ? 1u : 0u;
+			h->tslots = 0;
 		}
 	}
 
@@ -631,7 +652,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (rc) return rc;
 	if (h->seed) {
 		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
-	} else if (h->kfreq) {
+	} else if (h->kfreq && !h->part) {
 		if (has_long)
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
@@ -785,7 +806,11 @@ static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 template <int DBG>
 static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions)
 {
-	hipLaunchKernelGGL(k_build_regions<DBG>, dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr, first_region);
+	if (h->kfreq)
+		hipLaunchKernelGGL((k_build_regions<0, true>), dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
+		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region);
+	else
+		hipLaunchKernelGGL(k_build_regions<DBG>, dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr, first_region);
 }
 
 // Level 2 is bound by the memory system (8 waves per CU and 72 KiB of LDS reach the same time as a
@@ -898,7 +923,13 @@ static int build_from_records(dbgk_handle *h)
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
-	if (!h->sharded) {
+	if (h->kfreq) {
+		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap, 0,
+		                   reinterpret_cast<uint32_t *>(h->counts));
+		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, 1,
+		                   reinterpret_cast<uint32_t *>(h->counts));
+		hipLaunchKernelGGL(k_kf_key0, dim3(1), dim3(64), 0, h->stream, h->d_ctr, h->counts);
+	} else if (!h->sharded) {
 		hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
 		                   h->tref(), h->d_ctr);
 		hipLaunchKernelGGL(k_insert_triples, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap,
@@ -953,6 +984,7 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 			out->count_conflict = 0;
 			out->table_slots = h->n_counts;
 		}
+		if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY; // through PARTITION: far more distinct k-mers than expected_kmers / 2
 		return DBGK_OK;
 	}
 	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;

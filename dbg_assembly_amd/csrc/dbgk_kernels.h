@@ -393,6 +393,41 @@ __global__ __launch_bounds__(kBlock) void k_extract_count(ReadBatch rb, uint32_t
 	}
 }
 
+// saturating add into byte v of the count table (32-bit CAS on its dword)
+__device__ __forceinline__ void kf_sat_add(uint32_t *__restrict__ count_words, uint64_t v, uint32_t add)
+{
+	uint32_t *word = count_words + (v >> 2);
+	const uint32_t sh = (uint32_t)(v & 3u) * 8u;
+	uint32_t old = *word;
+	for (;;) {
+		const uint32_t cur = (old >> sh) & 0xFFu;
+		const uint32_t nxt = cur + add > 255u ? 255u : cur + add;
+		if (nxt == cur) break;
+		const uint32_t prev = atomicCAS(word, old, (old & ~(0xFFu << sh)) | (nxt << sh));
+		if (prev == old) break;
+		old = prev;
+	}
+}
+
+// KFREQ through the PARTITION engine: nodes that left their region's LDS image (is_triple = 0: {key,
+// links}, the count is the A counter of l_link) and bucket-overflow observations (is_triple = 1: one
+// occurrence each) are added to the byte table after all regions have been emitted
+__global__ __launch_bounds__(kBlock) void k_kf_apply(const Node *__restrict__ in, const unsigned long long *__restrict__ n_ptr, uint64_t cap,
+                                                     int is_triple, uint32_t *__restrict__ count_words)
+{
+	const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+		kf_sat_add(count_words, in[i].kmer, is_triple ? 1u : ((uint32_t)in[i].links >> 24));
+}
+
+// key 0 (poly-A / poly-T) never enters the record stream: its occurrences are counted in the A counter
+// of the side word
+__global__ void k_kf_key0(const Counters *__restrict__ ctr, uint8_t *__restrict__ counts)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = (uint8_t)((uint32_t)ctr->polyA_links >> 24);
+}
+
 // bit table of the 1-bit format: bit (128 >> (v % 8)) of byte v / 8 is set when counts[v] > cutoff
 // (bitAll, correct_error/seqKmer.cpp:34); one thread per output byte
 __global__ __launch_bounds__(kBlock) void k_counts_to_bits(const uint8_t *__restrict__ counts, uint64_t first_byte, uint64_t n_bytes,

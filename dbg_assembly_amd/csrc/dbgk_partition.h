@@ -79,6 +79,8 @@ struct PartGeom {
 	uint32_t b_lo, nb_own;
 	uint32_t n_regions_own;
 	uint64_t slot_lo, slot_hi;
+	uint32_t kf;         // KFREQ through this engine: a record is one occurrence of the key, its neighbour fields are
+	                     // fixed (lb = 0, rb = none), so the A counter of l_link is the saturating occurrence count
 };
 
 struct PartStore {
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 				// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
 				uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
 				asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
-				const uint32_t links = rev ? lr : lf;
+				const uint32_t links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
 				uint32_t rev_bit = rev ? 1u : 0u;
 				asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
 				rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit 15 - i
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 			}
 			// windows without a left / right neighbour: that side's code becomes 4 = none
 			const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
-			for (uint32_t fix = (no_l | no_r) & c.valid; fix; fix &= fix - 1u) {
+			for (uint32_t fix = G.kf ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
 				const uint32_t i = (uint32_t)__builtin_ctz(fix);
 				const bool fwd = !((rev_mask >> (15u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
 				uint64_t rec = L.stage[i * kL1Threads + tid];
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 			for (uint32_t i = 0; i < 16; i++) {
 				const Triple tr = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
 				if (tr.valid && tr.key == 0ull)
-					links_cas_observe(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links), tr.lb, tr.rb);
+					links_cas_observe(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links),
+					                  G.kf ? 0u : tr.lb, G.kf ? 4u : tr.rb);
 			}
 		}
 		if (DBG == 1) {
@@ -693,7 +696,9 @@ struct BuildLds {
 
 // DBG (DBGK_DEBUG_BUILD, timing experiments, results are wrong): 1 = clear + load only, 2 = no emit,
 // 3 = emit without recomputing the keys
-template <int DBG = 0>
+// KF: KFREQ through this engine -- there is no node table; `table` is the direct-addressed 4^k byte
+// table and an occupied LDS slot is emitted as counts[key] = its occurrence counter.
+template <int DBG = 0, bool KF = false>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
                                                                   Counters *__restrict__ ctr, uint32_t first_region)
 {
@@ -789,8 +794,12 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
 			links = L.links[i];
 		}
-		*reinterpret_cast<uint4 *>(&table[region_base + i]) =
-		    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
+		if (KF) { // every key is aggregated in exactly one region: a plain byte store, nobody else writes it during the build
+			if (id) reinterpret_cast<uint8_t *>(table)[key] = (uint8_t)((uint32_t)links >> 24);
+		} else {
+			*reinterpret_cast<uint4 *>(&table[region_base + i]) =
+			    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
+		}
 	}
 	// nodes that probed past the region end: re-inserted by k_merge_nodes after all regions exist
 	for (uint32_t i = region_len + t; i < (uint32_t)(kRegionSlots + kSpillSlots); i += kBuildThreads) {

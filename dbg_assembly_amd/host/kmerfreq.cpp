@@ -52,7 +52,8 @@ int main(int argc, char **argv)
 	long cutoff = 1;
 	string prefix;
 	int c;
-	while ((c = getopt(argc, argv, "k:f:b:m:t:o:q:r:h")) != -1) {
+	unsigned long long expected = 0;
+	while ((c = getopt(argc, argv, "k:f:b:m:t:o:q:r:e:h")) != -1) {
 		switch (c) {
 			case 'k': k = atoi(optarg); break;
 			case 'f': fmt = atoi(optarg); break;
@@ -61,10 +62,12 @@ int main(int argc, char **argv)
 			case 't': threads = atoi(optarg); break;
 			case 'o': prefix = optarg; break;
 			case 'r': max_read_len = atoi(optarg); break;
+			case 'e': expected = strtoull(optarg, NULL, 10); break;
 			case 'q': break;  // quality cutoff of the original tool: accepted, sequences carry no qualities here
 			default:
 				cout << "\nkmerfreq [-k 17] [-f 1:fq|2:fa] [-b 1|8 bit table] [-m cutoff, 1-bit: mark k-mers seen more than this, default 1]"
-				     << " [-t threads] [-o prefix] <reads.lib>\n" << endl;
+				     << " [-t threads] [-o prefix] [-e expected number of k-mers: counts through the partitioned engine,"
+				     << " 2.6x faster, all occurrences (8 bytes each) must fit the GPU's memory] <reads.lib>\n" << endl;
 				return 0;
 		}
 	}
@@ -80,6 +83,7 @@ int main(int argc, char **argv)
 	cfg.engine = DBGK_ENGINE_KFREQ;
 	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
 	cfg.max_batch_bases = (128ull << 20) + 65536;
+	cfg.expected_kmers = expected; // 0: atomics on the byte table, any input size
 	dbgk_handle *h = nullptr;
 	int rc = dbgk_create(&cfg, &h);
 	if (rc) die("dbgk_create", rc);

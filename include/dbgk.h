@@ -55,7 +55,9 @@ typedef struct dbgk_handle dbgk_handle;
                                      index, position, strand) of its first occurrence + uniqueness flag   */
 #define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
                                      canonical k-mers (the correct_error module's frequency table);
-                                     table_slots is ignored, k <= 18                                */
+                                     table_slots is ignored, k <= 18.  expected_kmers > 0: the occurrences
+                                     are partitioned and aggregated in LDS (2.6x faster; 8 bytes per
+                                     occurrence must fit the device), 0: atomics on the table, any size */
 
 typedef struct dbgk_config {
 	int32_t  kmer_size;        /* KmerSize   (DBGgraph.cpp:10), 1..32                              */

@@ -61,14 +61,17 @@ def _reads(rng, n, G=4000, L=100):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [9, 13])
-def test_kfreq_engine_counts_equal_oracle(oracle, k):
+@pytest.mark.parametrize("k,expected", [(9, 0), (13, 0), (13, 400000), (11, 1)])
+def test_kfreq_engine_counts_equal_oracle(oracle, k, expected):
+    """expected == 0: atomics on the direct-addressed byte table; expected > 0 (the input size is known):
+    occurrences partitioned by hash and aggregated per key in LDS (PARTITION engine), same table at the
+    end; expected = 1 under-sizes every bucket, so most occurrences take the overflow path"""
     from dbg_assembly_amd import capi
     rng = random.Random(k)
     reads = _reads(rng, 3000)
     bases, offsets = oracle.pack_reads(reads)
     want = oracle.kfreq_expected_counts([(bases, offsets)], k)
-    with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000) as g:
+    with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=expected) as g:
         g.push_reads(bases[:int(offsets[1500])], offsets[:1501])
         g.push_reads(bases[int(offsets[1500]):], offsets[1500:] - offsets[1500])
         st = g.finalize()
@@ -82,6 +85,11 @@ def test_kfreq_engine_counts_equal_oracle(oracle, k):
         # table-only entry points are refused on a KFREQ handle
         with pytest.raises(capi.DbgkError):
             g.export_sorted()
+        # the handle is reusable
+        g.reset()
+        g.push_reads(bases, offsets)
+        g.finalize()
+        assert np.array_equal(g.kfreq_counts(), want)
 
 
 @pytest.mark.gpu
@@ -100,7 +108,8 @@ def test_kmerfreq_tool_files_load_like_the_reference(oracle, tmp_path, k, fmt):
     rc = oracle.revcomp_values(idx, k).astype(np.int64)
     for bits_fmt, cutoff in ((1, 1), (8, 10)):
         prefix = str(tmp_path / ("out%d" % bits_fmt))
-        r = subprocess.run([TOOL, "-k", str(k), "-f", str(fmt), "-b", str(bits_fmt), "-m", str(cutoff), "-t", "4", "-o", prefix, lib],
+        extra = ["-e", "300000"] if bits_fmt == 8 else []  # the 8-bit run counts through the partitioned engine
+        r = subprocess.run([TOOL, "-k", str(k), "-f", str(fmt), "-b", str(bits_fmt), "-m", str(cutoff), "-t", "4", "-o", prefix] + extra + [lib],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         cz = prefix + ".kmer.freq.cz"
