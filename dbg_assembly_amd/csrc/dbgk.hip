@@ -46,6 +46,8 @@ static int hip_fail(hipError_t e, const char *what, int line)
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t kMaxBuildLaunches = 4096; // build ranges per step (one work cursor each)
+
 enum Phase { PH_MARK = 0, PH_INSERT, PH_PARTITION, PH_BUILD, PH_FIXUP, PH_FINALIZE, PH_L2_BUILD_WALL, PH_COUNT };
 
 struct TimedSpan {
@@ -111,6 +113,8 @@ struct dbgk_handle {
 	bool part_planned = false;    // level-2 tile plan made for this step (part_plan)
 	uint32_t next_bucket = 0;     // own level-1 buckets [0, next_bucket) have been handed to level 2 + build
 	uint32_t chunks_used = 0;     // chunk events consumed this step
+	unsigned int *region_cursor = nullptr; // [kMaxBuildLaunches] work cursors of the persistent build launches
+	uint32_t cursors_used = 0;
 	TimedSpan wall_span;
 	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
 	PartGeom geom;
@@ -239,6 +243,7 @@ static void free_handle(dbgk_handle *h)
 		                (void *)h->store.spill, (void *)h->store.ovf_n})
 			if (p) (void)hipFree(p);
 		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
+		if (h->region_cursor) (void)hipFree(h->region_cursor);
 		for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
 		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
 		if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -387,6 +392,7 @@ static int setup_partition(dbgk_handle *h)
 	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
 	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) == hipSuccess &&
 	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->tile_prefix, (n_entries + 1) * 4) == hipSuccess &&
+	          hipMalloc(&h->region_cursor, kMaxBuildLaunches * sizeof(unsigned int)) == hipSuccess &&
 	          hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.outgoing_n, 8) == hipSuccess;
 	if (ok && h->sharded)
 		ok = hipMalloc(&h->inbox, l1_bytes) == hipSuccess && hipMalloc(&h->inbox_cnt, n_entries * 4) == hipSuccess;
@@ -804,13 +810,15 @@ static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 }
 
 template <int DBG>
-static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions)
+static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions, unsigned int *cursor)
 {
+	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 2u); // persistent: two 66-KiB workgroups fit a CU
 	if (h->kfreq)
-		hipLaunchKernelGGL((k_build_regions<0, true>), dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
-		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region);
+		hipLaunchKernelGGL((k_build_regions<0, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
+		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
 	else
-		hipLaunchKernelGGL(k_build_regions<DBG>, dim3(n_regions), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr, first_region);
+		hipLaunchKernelGGL(k_build_regions<DBG>, dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr,
+		                   first_region, n_regions, cursor);
 }
 
 // Level 2 is bound by the memory system (8 waves per CU and 72 KiB of LDS reach the same time as a
@@ -830,6 +838,8 @@ static int part_plan(dbgk_handle *h)
 	}
 	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->geom, h->store, h->tile_prefix);
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemsetAsync(h->region_cursor, 0, kMaxBuildLaunches * sizeof(unsigned int), h->stream)); // one work cursor per build launch
+	h->cursors_used = 0;
 	int rc = span_begin(h, PH_L2_BUILD_WALL, h->wall_span);
 	if (rc) return rc;
 	h->part_planned = true;
@@ -875,11 +885,16 @@ static int part_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1, bool two_s
 	if (r1 <= r0) return DBGK_OK;
 	rc = span_begin(h, PH_BUILD, sp, bstream);
 	if (rc) return rc;
+	if (h->cursors_used >= kMaxBuildLaunches) {
+		g_last_error = "too many build ranges in one step";
+		return DBGK_ERR_STATE;
+	}
+	unsigned int *cursor = h->region_cursor + h->cursors_used++;
 	switch (dbg_build) {
-		case 1: launch_build<1>(h, bstream, r0, r1 - r0); break;
-		case 2: launch_build<2>(h, bstream, r0, r1 - r0); break;
-		case 3: launch_build<3>(h, bstream, r0, r1 - r0); break;
-		default: launch_build<0>(h, bstream, r0, r1 - r0); break;
+		case 1: launch_build<1>(h, bstream, r0, r1 - r0, cursor); break;
+		case 2: launch_build<2>(h, bstream, r0, r1 - r0, cursor); break;
+		case 3: launch_build<3>(h, bstream, r0, r1 - r0, cursor); break;
+		default: launch_build<0>(h, bstream, r0, r1 - r0, cursor); break;
 	}
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp, bstream);

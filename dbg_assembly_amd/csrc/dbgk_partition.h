@@ -692,6 +692,7 @@ struct BuildLds {
 	unsigned long long ident[kRegionSlots + kSpillSlots]; // (record >> 6) + 1, 0 = empty
 	unsigned long long links[kRegionSlots + kSpillSlots];
 	unsigned long long red[kBuildThreads / 64];
+	uint32_t next_region;
 };
 
 // DBG (DBGK_DEBUG_BUILD, timing experiments, results are wrong): 1 = clear + load only, 2 = no emit,
@@ -700,120 +701,174 @@ struct BuildLds {
 // table and an occupied LDS slot is emitted as counts[key] = its occurrence counter.
 template <int DBG = 0, bool KF = false>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
-                                                                  Counters *__restrict__ ctr, uint32_t first_region)
+                                                                  Counters *__restrict__ ctr, uint32_t first_region, uint32_t n_regions,
+                                                                  unsigned int *__restrict__ cursor)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	BuildLds &L = *reinterpret_cast<BuildLds *>(lds_raw);
-	const uint32_t f = first_region + blockIdx.x;        // LOCAL final bucket == local region index == (slot - slot_lo) >> 12
-	const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits));
-	const uint64_t region_base = (uint64_t)f << kRegionBits;   // index into this shard's table
-	const uint64_t region_slot0 = G.slot_lo + region_base;     // global slot of the region's first entry
-	const uint32_t region_len = (uint32_t)((G.size - region_slot0 < (uint64_t)kRegionSlots) ? G.size - region_slot0 : kRegionSlots);
 	const int t = (int)fresh_tid();
-	const uint64_t filled = P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2;
-	const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
+	constexpr int kBatch = 4; // records per thread in one batch; one batch is inserted while the next is in flight
+	constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+	// Persistent workgroups pull regions from a cursor (self-balancing whatever the residency: while the
+	// level-2 kernel of the next bucket chunk shares the chip only one build workgroup fits a CU).  The
+	// records are consumed as ONE stream of batches across regions: while batch i is inserted, batch
+	// i+1 -- the next 4096 records of this region or the first ones of the next region -- is already
+	// in flight, in the registers the previous batch has just vacated (the kernel must stay inside the
+	// 64 VGPRs that two workgroups per CU allow).
+	auto load_batch = [&](uint32_t f, uint32_t base, uint64_t (&recs)[kBatch]) {
+#pragma unroll
+		for (int u = 0; u < kBatch; u++) recs[u] = ~0ull;
+		if (f == kNone) return;
+		const uint32_t filled = (uint32_t)(P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2);
+		const uint64_t *in = P.l2 + (uint64_t)f * G.cap2; // scalar base + 32-bit lane offset
+		const uint32_t lane_rec = base + fresh_tid();     // opaque: lane addresses are not worth keeping alive across batches
+#pragma unroll
+		for (int u = 0; u < kBatch; u++) {
+			const uint32_t i = (uint32_t)u * kBuildThreads + lane_rec;
+			if (i < filled) recs[u] = __builtin_nontemporal_load(in + i);
+		}
+	};
+	auto grab = [&]() { // one region index per workgroup, broadcast through LDS
+		if (t == 0) {
+			const unsigned int k = atomicAdd(cursor, 1u);
+			L.next_region = k < n_regions ? first_region + k : kNone;
+		}
+	};
 
 	for (int i = t; i < kRegionSlots + kSpillSlots; i += kBuildThreads) {
 		L.ident[i] = 0ull;
 		L.links[i] = 0ull;
 	}
+	grab();
 	lds_barrier();
+	uint32_t f = __builtin_amdgcn_readfirstlane(L.next_region); // scalar: everything derived from it stays in SGPRs
+	lds_barrier();
+	grab(); // the region after it
+	lds_barrier();
+	uint32_t f_after = __builtin_amdgcn_readfirstlane(L.next_region);
+	uint32_t base = 0;
+	uint64_t recs[kBatch];
+	load_batch(f, 0, recs);
+	uint32_t n_new = 0, n_conf = 0; // per thread: far below 2^32
 
-	uint32_t n_new = 0, n_conf = 0; // per thread and region: far below 2^32
-	constexpr int kBatch = 8; // records per thread loaded together before any LDS work
-	for (uint64_t base = 0; base < filled; base += (uint64_t)kBatch * kBuildThreads) {
-		uint64_t recs[kBatch];
-#pragma unroll
-		for (int u = 0; u < kBatch; u++) {
-			const uint64_t i = base + (uint64_t)u * kBuildThreads + t;
-			recs[u] = (i < filled) ? __builtin_nontemporal_load(in + i) : ~0ull;
-		}
+	while (f != kNone) {
+		const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits)); // f = LOCAL final bucket == local region index == (slot - slot_lo) >> 12
+		const uint64_t region_base = (uint64_t)f << kRegionBits;   // index into this shard's table
+		const uint64_t region_slot0 = G.slot_lo + region_base;     // global slot of the region's first entry
+		const uint32_t region_len = (uint32_t)((G.size - region_slot0 < (uint64_t)kRegionSlots) ? G.size - region_slot0 : kRegionSlots);
+		const uint32_t filled = (uint32_t)(P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2);
+		// the batch after this one
+		const bool last_of_region = base + (uint32_t)kBatch * kBuildThreads >= filled;
+		const uint32_t f_nxt = last_of_region ? f_after : f, base_nxt = last_of_region ? 0u : base + (uint32_t)kBatch * kBuildThreads;
+		uint64_t nxt[kBatch];
+		load_batch(f_nxt, base_nxt, nxt);
 		if (DBG == 1) {
 			uint64_t x = 0;
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) x ^= recs[u];
 			if (x == 0x1234567ull) table[t].kmer = x;
-			continue;
-		}
+		} else {
 #pragma unroll
-		for (int u = 0; u < kBatch; u++) {
-			// The loops below have ONE exit condition each and no breaks: the structurizer turns every
-			// extra exit of a divergent loop into a dozen scalar mask instructions per iteration, and this
-			// kernel is bound by instruction issue (profiles/dbg_modes_build.sh).
-			const uint64_t rec = recs[u];
-			const bool live = rec != ~0ull;
-			const unsigned long long id = (rec >> 6) + 1ull;
-			const uint32_t lb = (uint32_t)(rec >> 3) & 7u, rb = (uint32_t)rec & 7u;
-			const uint32_t home = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
-			uint32_t idx = home;
-			unsigned long long old = L.links[home]; // usually the key sits in its home slot: fetch its counters together with the first probe
-			bool probing = live, lost = false;
-			while (probing) {
-				unsigned long long cur = L.ident[idx];
-				if (cur == 0ull) {
-					const unsigned long long prev = atomicCAS(&L.ident[idx], 0ull, id);
-					cur = prev == 0ull ? id : prev;
-					n_new += (prev == 0ull && idx < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
+			for (int u = 0; u < kBatch; u++) {
+				// The loops below have ONE exit condition each and no breaks: the structurizer turns every
+				// extra exit of a divergent loop into a dozen scalar mask instructions per iteration, and this
+				// kernel is bound by instruction issue (profiles/dbg_modes_build.sh).
+				const uint64_t rec = recs[u];
+				const bool live = rec != ~0ull;
+				const unsigned long long id = (rec >> 6) + 1ull;
+				const uint32_t lb = (uint32_t)(rec >> 3) & 7u, rb = (uint32_t)rec & 7u;
+				const uint32_t home = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
+				uint32_t idx = home;
+				unsigned long long old = L.links[home]; // usually the key sits in its home slot: fetch its counters together with the first probe
+				bool probing = live, lost = false;
+				while (probing) {
+					unsigned long long cur = L.ident[idx];
+					if (cur == 0ull) {
+						const unsigned long long prev = atomicCAS(&L.ident[idx], 0ull, id);
+						cur = prev == 0ull ? id : prev;
+						n_new += (prev == 0ull && idx < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
+					}
+					const bool hit = cur == id;
+					idx += hit ? 0u : 1u;
+					n_conf += hit ? 0u : 1u;
+					lost = idx >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full
+					probing = !hit && !lost;
 				}
-				const bool hit = cur == id;
-				idx += hit ? 0u : 1u;
-				n_conf += hit ? 0u : 1u;
-				lost = idx >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full
-				probing = !hit && !lost;
+				// saturating +1 on the observed neighbour bytes (add_node_to_kmerset's "if (< 255) ++", kmerSet.cpp:253-273):
+				// both dwords at once, bytes that are already 255 masked out of the increment
+				const uint32_t dl = (lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
+				bool pending = live && !lost;
+				if (pending && idx != home) old = L.links[idx];
+				while (pending) {
+					const uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
+					const uint32_t sat_l = (((lo & 0x7F7F7F7Fu) + 0x01010101u) & lo & 0x80808080u) >> 7; // 0x01 in every byte that is 0xFF
+					const uint32_t sat_r = (((hi & 0x7F7F7F7Fu) + 0x01010101u) & hi & 0x80808080u) >> 7;
+					const unsigned long long upd = ((unsigned long long)(hi + (dr & ~sat_r)) << 32) | (lo + (dl & ~sat_l));
+					unsigned long long prev = old;
+					if (upd != old) prev = atomicCAS(&L.links[idx], old, upd);
+					pending = prev != old;
+					old = prev;
+				}
+				if (live && lost) push_overflow(P, record_key(rec, b1, G), lb, rb, ctr);
 			}
-			// saturating +1 on the observed neighbour bytes (add_node_to_kmerset's "if (< 255) ++", kmerSet.cpp:253-273):
-			// both dwords at once, bytes that are already 255 masked out of the increment
-			const uint32_t dl = (lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
-			bool pending = live && !lost;
-			if (pending && idx != home) old = L.links[idx];
-			while (pending) {
-				const uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
-				const uint32_t sat_l = (((lo & 0x7F7F7F7Fu) + 0x01010101u) & lo & 0x80808080u) >> 7; // 0x01 in every byte that is 0xFF
-				const uint32_t sat_r = (((hi & 0x7F7F7F7Fu) + 0x01010101u) & hi & 0x80808080u) >> 7;
-				const unsigned long long upd = ((unsigned long long)(hi + (dr & ~sat_r)) << 32) | (lo + (dl & ~sat_l));
-				unsigned long long prev = old;
-				if (upd != old) prev = atomicCAS(&L.links[idx], old, upd);
-				pending = prev != old;
-				old = prev;
+		}
+		if (last_of_region) {
+			lds_barrier();
+			if (DBG != 1 && DBG != 2) {
+				// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot)); the LDS
+				// image is cleared on the way for the next region.
+				// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
+				// written back into ident[], was measured: no change, 6.78 against 6.69-6.79 ms.)
+				for (uint32_t i = t; i < region_len; i += kBuildThreads) {
+					const unsigned long long id = L.ident[i];
+					uint64_t key = 0ull, links = 0ull;
+					if (id) {
+						const uint64_t v = id - 1ull;
+						const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
+						key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
+						links = L.links[i];
+						L.ident[i] = 0ull;
+						L.links[i] = 0ull;
+					}
+					if (KF) { // every key is aggregated in exactly one region: a plain byte store, nobody else writes it during the build
+						if (id) reinterpret_cast<uint8_t *>(table)[key] = (uint8_t)((uint32_t)links >> 24);
+					} else {
+						*reinterpret_cast<uint4 *>(&table[region_base + i]) =
+						    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
+					}
+				}
+				// nodes that probed past the region end: re-inserted by k_merge_nodes after all regions exist
+				for (uint32_t i = region_len + t; i < (uint32_t)(kRegionSlots + kSpillSlots); i += kBuildThreads) {
+					const unsigned long long id = L.ident[i];
+					if (!id) continue;
+					const uint64_t v = id - 1ull;
+					const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
+					const unsigned long long j = atomicAdd(&P.ovf_n[1], 1ull);
+					if (j < P.spill_cap) {
+						P.spill[j].kmer = hash_code_inverse((v >> G.r) * G.size + slot);
+						P.spill[j].links = L.links[i];
+					} else {
+						atomicOr(&ctr->error, 2u);
+					}
+					L.ident[i] = 0ull;
+					L.links[i] = 0ull;
+				}
+			} else {
+				for (int i = t; i < kRegionSlots + kSpillSlots; i += kBuildThreads) {
+					L.ident[i] = 0ull;
+					L.links[i] = 0ull;
+				}
 			}
-			if (live && lost) push_overflow(P, record_key(rec, b1, G), lb, rb, ctr);
+			grab(); // the region after the one whose first batch is already in flight
+			lds_barrier(); // the image is empty again, next_region is visible
+			f_after = __builtin_amdgcn_readfirstlane(L.next_region);
+			lds_barrier();
 		}
-	}
-	lds_barrier();
-	if (DBG == 1 || DBG == 2) return;
-
-	// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot)).
-	// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
-	// written back into ident[], was measured: no change, 6.78 against 6.69-6.79 ms.)
-	for (uint32_t i = t; i < region_len; i += kBuildThreads) {
-		const unsigned long long id = L.ident[i];
-		uint64_t key = 0ull, links = 0ull;
-		if (id) {
-			const uint64_t v = id - 1ull;
-			const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
-			key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
-			links = L.links[i];
-		}
-		if (KF) { // every key is aggregated in exactly one region: a plain byte store, nobody else writes it during the build
-			if (id) reinterpret_cast<uint8_t *>(table)[key] = (uint8_t)((uint32_t)links >> 24);
-		} else {
-			*reinterpret_cast<uint4 *>(&table[region_base + i]) =
-			    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
-		}
-	}
-	// nodes that probed past the region end: re-inserted by k_merge_nodes after all regions exist
-	for (uint32_t i = region_len + t; i < (uint32_t)(kRegionSlots + kSpillSlots); i += kBuildThreads) {
-		const unsigned long long id = L.ident[i];
-		if (!id) continue;
-		const uint64_t v = id - 1ull;
-		const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
-		const unsigned long long j = atomicAdd(&P.ovf_n[1], 1ull);
-		if (j < P.spill_cap) {
-			P.spill[j].kmer = hash_code_inverse((v >> G.r) * G.size + slot);
-			P.spill[j].links = L.links[i];
-		} else {
-			atomicOr(&ctr->error, 2u);
-		}
+		f = f_nxt;
+		base = base_nxt;
+#pragma unroll
+		for (int u = 0; u < kBatch; u++) recs[u] = nxt[u];
 	}
 	const unsigned long long a = block_sum_n<kBuildThreads>(n_new, L.red);
 	const unsigned long long b = block_sum_n<kBuildThreads>(n_conf, L.red);
