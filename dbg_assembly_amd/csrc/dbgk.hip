@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dbgk.h"
@@ -701,6 +702,26 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	return span_end(h, sp);
 }
 
+// pageable host buffer -> pinned staging buffer.  One memcpy thread moves ~12 GB/s, less than a third of
+// what the H2D copy behind it can take, so large batches are cut over a few threads (DBGK_COPY_THREADS,
+// default 4; the offset bookkeeping of the batch runs on the calling thread meanwhile).
+static void staged_copy(char *dst, const char *src, size_t n, std::vector<std::thread> &workers)
+{
+	static const int want = getenv("DBGK_COPY_THREADS") ? atoi(getenv("DBGK_COPY_THREADS")) : 4;
+	const size_t min_piece = 8u << 20;
+	size_t pieces = want > 1 ? std::min<size_t>((size_t)want, n / min_piece) : 1;
+	if (pieces <= 1) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const size_t per = ((n + pieces - 1) / pieces + 4095) & ~(size_t)4095;
+	for (size_t p = 1; p < pieces; p++) {
+		const size_t lo = p * per, hi = std::min(n, lo + per);
+		if (lo < hi) workers.emplace_back([=]() { memcpy(dst + lo, src + lo, hi - lo); });
+	}
+	memcpy(dst, src, std::min(n, per));
+}
+
 static int ensure_slot(dbgk_handle *h, StageSlot &s)
 {
 	if (s.d_bases) return DBGK_OK;
@@ -737,7 +758,12 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			s.busy = false;
 		}
 		const uint64_t nb = offsets[r1] - base0, nr = r1 - r0;
-		if (nb) memcpy(s.h_bases, bases + base0, nb);
+		std::vector<std::thread> copiers;
+		struct Join { // every exit path below waits for the copy threads
+			std::vector<std::thread> &w;
+			~Join() { for (auto &t : w) if (t.joinable()) t.join(); }
+		} join_copiers{copiers};
+		if (nb) staged_copy(s.h_bases, bases + base0, nb, copiers);
 		int has_long = 0;
 		for (uint64_t i = 0; i <= nr; i++) {
 			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
@@ -745,6 +771,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
 			if (h->seed && i && s.h_offsets[i] - s.h_offsets[i - 1] >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
 		}
+		for (auto &t : copiers) t.join();
 		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
 		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long);
