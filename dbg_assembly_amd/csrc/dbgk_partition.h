@@ -414,8 +414,13 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 	const uint32_t lane = fresh_tid() & 63u;
 	const uint64_t p0 = chunk * 16u;
 	const uint32_t w0 = pack16_ascii(raw.a0);
-	const uint32_t hw = pack16_ascii(raw.halo);
-	const uint32_t hw0 = __builtin_amdgcn_readlane(hw, 0), hw1 = __builtin_amdgcn_readlane(hw, 1);
+	// only lanes 0 and 1 hold halo chunks: broadcast their raw words and pack them on the scalar unit
+	// instead of packing a dummy in all 64 lanes
+	const uint4 h0 = make_uint4(__builtin_amdgcn_readlane(raw.halo.x, 0), __builtin_amdgcn_readlane(raw.halo.y, 0),
+	                            __builtin_amdgcn_readlane(raw.halo.z, 0), __builtin_amdgcn_readlane(raw.halo.w, 0));
+	const uint4 h1 = make_uint4(__builtin_amdgcn_readlane(raw.halo.x, 1), __builtin_amdgcn_readlane(raw.halo.y, 1),
+	                            __builtin_amdgcn_readlane(raw.halo.z, 1), __builtin_amdgcn_readlane(raw.halo.w, 1));
+	const uint32_t hw0 = pack16_ascii(h0), hw1 = pack16_ascii(h1);
 	uint32_t w1 = __shfl_down(w0, 1, 64), w2 = __shfl_down(w0, 2, 64);
 	if (lane == 63u) { w1 = hw0; w2 = hw1; }
 	if (lane == 62u) w2 = hw0;
