@@ -165,9 +165,11 @@ static int span_end(dbgk_handle *h, TimedSpan &s, hipStream_t stream = nullptr)
 	return DBGK_OK;
 }
 
-// after a stream synchronise: fold finished spans into the per-phase totals
+// fold finished spans into the per-phase totals.  The caller has synchronised `stream`; region builds
+// of a ranged finalize may still be running on `stream2` (their spans are recorded there).
 static int collect_spans(dbgk_handle *h)
 {
+	if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
 	for (auto &s : h->spans) {
 		float ms = 0.f;
 		HIPCHK(hipEventElapsedTime(&ms, s.a, s.b));

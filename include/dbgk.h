@@ -251,7 +251,9 @@ int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_handle *src, c
 
 /* ---- sharded table: reads shard by record, k-mers are owned by SLOT RANGE ---------------------
  * With shard_count = N every handle extracts its own reads into level-1 buckets of the GLOBAL table
- * (slot >> r); rank d owns the bucket range [d*B, (d+1)*B).  Between the pushes and dbgk_finalize
+ * (slot >> r); rank d owns the bucket range [d*B, (d+1)*B).  All N handles of a job must be created
+ * with the same kmer_size, table_slots and expected_kmers (they fix the bucket geometry and the
+ * capacity of the exchanged buffers; compare chunk_bytes across ranks if in doubt).  Between the pushes and dbgk_finalize
  * the caller moves chunk d of every rank's send buffer to rank d (an all-to-all: RCCL
  * ncclSend/ncclRecv, torch all_to_all_single, or peer copies), the bucket fill counts likewise,
  * then calls dbgk_shard_mark_exchanged.  finalize builds only the handle's slot range; the few

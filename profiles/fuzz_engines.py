@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the two graph engines on the GPU: for many random configurations
+(k, read-length mix, N rate, repeats, table size from 2^26 up to beyond 2^31 slots, batching, 1-3
+in-process shards with ranged delivery) the PARTITION engine must produce the same node multiset
+(count, k-mer totals, order-independent digest) as the DIRECT engine.  No oracle involved: both
+sides are device code; the oracle pins DIRECT and PARTITION separately in tests/.
+    python profiles/fuzz_engines.py [n_configs] [seed] [only_this_config]"""
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dbg_assembly_amd import capi  # noqa: E402
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def make_reads(rng, n, G, L, n_rate, repeat):
+    g = "".join(rng.choice("ACGT") for _ in range(G))
+    if repeat:
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40)))
+        g = g[:G // 2] + unit * (G // (2 * len(unit)) + 1)
+    out = []
+    for _ in range(n):
+        ln = L if rng.random() < 0.7 else rng.randint(0, L + 200)
+        ln = min(ln, len(g))
+        s = rng.randint(0, len(g) - ln)
+        r = list(g[s:s + ln])
+        if rng.random() < 0.5:
+            r = [COMP[c] for c in reversed(r)]
+        for j in range(len(r)):
+            x = rng.random()
+            if x < 0.01:
+                r[j] = rng.choice("ACGT")
+            elif x < 0.01 + n_rate:
+                r[j] = rng.choice("Nn")
+            elif x < 0.02 + n_rate:
+                r[j] = r[j].lower()
+        out.append("".join(r).encode())
+    if rng.random() < 0.5:
+        out += [b"A" * rng.randint(1, 300)] * rng.randint(1, 400) + [b"T" * rng.randint(1, 120)] * rng.randint(1, 50)
+    rng.shuffle(out)
+    return out
+
+
+def pack(reads):
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return bases, offs
+
+
+def push_in_batches(g, reads, rng):
+    cuts = sorted(rng.sample(range(len(reads)), min(len(reads), rng.randint(0, 3))))
+    for a, b in zip([0] + cuts, cuts + [len(reads)]):
+        if b > a:
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("   push reads [%d, %d) of %d, %d bases" % (a, b, len(reads), sum(len(r) for r in reads[a:b])), flush=True)
+            g.push_reads(*pack(reads[a:b]))
+
+
+def build_sharded(reads, k, size, n_shards, rng, max_read_len):
+    expected = rng.choice([1, 50000, 2000000])  # every shard of a job is created with the SAME geometry (size, k, expected_kmers)
+    graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected,
+                         shard_count=n_shards, shard_index=i, max_read_len=max_read_len) for i in range(n_shards)]
+    try:
+        for i, g in enumerate(graphs):
+            push_in_batches(g, reads[i::n_shards], rng)
+            g.sync()
+        infos = [g.shard_info() for g in graphs]
+        c0 = graphs[0]
+        for s in range(n_shards):
+            for d in range(n_shards):
+                c0.memcpy_d2d(infos[d].d_recv_cnt + s * infos[d].cnt_chunk_bytes, infos[s].d_send_cnt + d * infos[s].cnt_chunk_bytes,
+                              infos[s].cnt_chunk_bytes)
+        c0.sync()
+        B = infos[0].buckets_per_rank
+        pieces = rng.choice([1, 2, 5, B])
+        per = -(-B // pieces)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("   shards", n_shards, "B", B, "pieces", pieces, "own", [i.own_buckets for i in infos], "chunk_bytes", infos[0].chunk_bytes,
+                  "bucket_bytes", infos[0].bucket_bytes, "slots", [(i.slot_lo, i.slot_hi) for i in infos], flush=True)
+        if not os.environ.get("FUZZ_NO_PLAN"):
+            for g in graphs:
+                g.shard_plan()
+        for j0 in range(0, B, per):
+            j1 = min(j0 + per, B)
+            for s in range(n_shards):
+                for d in range(n_shards):
+                    c0.memcpy_d2d(infos[d].d_recv + s * infos[d].chunk_bytes + j0 * infos[d].bucket_bytes,
+                                  infos[s].d_send + d * infos[s].chunk_bytes + j0 * infos[s].bucket_bytes, (j1 - j0) * infos[s].bucket_bytes)
+            c0.sync()
+            for g, info in zip(graphs, infos):
+                a, b = min(j0, info.own_buckets), min(j1, info.own_buckets)
+                if b > a and rng.random() < float(os.environ.get("FUZZ_RANGED_P", "0.8")):   # sometimes leave the tail to dbgk_finalize
+                    if a == g_next[id(g)]:
+                        g.shard_build_range(a, b)
+                        g_next[id(g)] = b
+                        if os.environ.get("FUZZ_VERBOSE"):
+                            print("   rank", info.rank, "range", a, b, flush=True)
+        stats = []
+        for g in graphs:
+            g.shard_mark_exchanged()
+            stats.append(g.finalize())
+        ovf = [g.shard_overflow() for g in graphs]
+        out = [g.shard_outgoing() for g in graphs]
+        for (p, n) in ovf:
+            for g in graphs:
+                if n:
+                    g.shard_merge(p, n, is_triple=True)
+        for s, (p, n) in enumerate(out):
+            if n:
+                graphs[(s + 1) % n_shards].shard_merge(p, n, from_previous_shard=True)
+        for s in range(1, n_shards):
+            if stats[s].polyA_l_link or stats[s].polyA_r_link:
+                graphs[0].add_polyA(stats[s].polyA_l_link, stats[s].polyA_r_link)
+        final = [g.refresh_stats() for g in graphs]
+        return (sum(int(f.count) for f in final), sum(int(s.total_kmers) for s in stats), sum(int(s.stored_kmers) for s in stats),
+                sum(g.digest() for g in graphs) % (1 << 64))
+    finally:
+        for g in graphs:
+            g.close()
+
+
+class _Next(dict):
+    def __missing__(self, key):
+        return 0
+
+
+g_next = _Next()
+
+
+def main():
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # re-run one configuration
+    bad = 0
+    for c in range(n_cfg):
+        if only >= 0 and c != only:
+            continue
+        rng = random.Random(seed * 100003 + c)  # every configuration is reproducible on its own
+        k = rng.choice([31, 31, 32, 27, 21, 17, 12, 5, 1])
+        L = rng.choice([150, 100, 36, 250, 400])
+        max_read_len = rng.choice([250, 250, 100, 1000000])
+        reads = make_reads(rng, rng.randint(1, 6000), rng.randint(max(L, 50), 60000), L, rng.choice([0.0, 0.003, 0.05]), rng.random() < 0.3)
+        slots = rng.choice([1 << 26, 70_000_000, 100_000_007, 600_000_000, 2_200_000_000, 4_200_000_000])
+        size = capi.find_next_prime_ref(slots)
+        with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(3_000_000), engine=capi.ENGINE_DIRECT, max_read_len=max_read_len) as g:
+            push_in_batches(g, reads, rng)
+            st = g.finalize()
+            want = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
+        n_shards = rng.choice([0, 0, 1, 2, 3])
+        if n_shards == 0:
+            with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=rng.choice([1, 100000, 3000000]),
+                            max_read_len=max_read_len) as g:
+                push_in_batches(g, reads, rng)
+                st = g.finalize()
+                got = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
+        else:
+            g_next.clear()
+            got = build_sharded(reads, k, size, n_shards, rng, max_read_len)
+        ok = got == want
+        bad += not ok
+        print("cfg %3d k=%2d L=%3d maxlen=%7d reads=%5d slots=%10d shards=%d  %s" % (c, k, L, max_read_len, len(reads), size, n_shards,
+                                                                                    "ok" if ok else "MISMATCH %r != %r" % (got, want)), flush=True)
+    print("%d configurations, %d mismatches" % (n_cfg, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -380,6 +380,7 @@ def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slot
                         g.shard_build_range(own0, own1)
                         with pytest.raises(capi.DbgkError):
                             g.shard_build_range(own0, own1)  # a range is consumed once, in order
+                        g.sync()                             # legal between ranges: waits for both of the handle's streams
         stats = []
         for g in graphs:
             g.shard_mark_exchanged()
