@@ -163,6 +163,18 @@ def main():
             g_next.clear()
             got = build_sharded(reads, k, size, n_shards, rng, max_read_len)
         ok = got == want
+        if k <= 13:  # the k-mer frequency table: atomics on the byte table against the partitioned counting
+            tabs = []
+            # expected_kmers is an upper bound of what the handle will see (an under-sized value is tolerated
+            # only as far as the overflow stores reach, then dbgk_finalize reports DBGK_ERR_CAPACITY)
+            for expected in (0, max(1, want[2]) * rng.choice([1, 2, 50])):
+                with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=max_read_len, expected_kmers=expected) as g:
+                    push_in_batches(g, reads, rng)
+                    st = g.finalize()
+                    tabs.append((int(st.count), int(st.stored_kmers), g.kfreq_counts().tobytes()))
+            if tabs[0] != tabs[1] or tabs[0][1] != want[2]:
+                ok = False
+                got = ("kfreq", tabs[0][:2], tabs[1][:2])
         bad += not ok
         print("cfg %3d k=%2d L=%3d maxlen=%7d reads=%5d slots=%10d shards=%d  %s" % (c, k, L, max_read_len, len(reads), size, n_shards,
                                                                                     "ok" if ok else "MISMATCH %r != %r" % (got, want)), flush=True)
