@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--exchange-chunks", type=int, default=8,
                     help="N > 1, records flow: pieces the level-1 buckets travel in (the build of a piece overlaps "
                          "the transfer of the next); 1 = one all-to-all, then the build")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N > 1 code path (process group, slot-range shard, exchange in pieces) with the ranks "
+                         "there are, even one: rehearsal of the multi-GPU flow on a one-GPU box")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,6 +109,12 @@ def cpu_baseline(args, genome_len):
 
 def main():
     args = parse_args()
+    # stdout carries ONE line, the result.  RCCL prints a version banner to stdout when a communicator is
+    # created (any time up to the first point-to-point transfer), so file descriptor 1 is pointed at
+    # stderr for the whole run and the JSON line is written to the saved original.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
@@ -122,9 +131,14 @@ def main():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_sharded
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n_reads = args.reads_per_gpu
     genome_len = args.genome_per_gpu * world
@@ -133,7 +147,7 @@ def main():
     # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
     # (PARTITION engine, slot-range ownership; needs < 2^32 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
-    sharded = world > 1 and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
+    sharded = multi and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
     per_gpu_slots = args.table_slots if world == 1 else min(args.table_slots, (2 ** 32 - 2 ** 22) // world)
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
@@ -162,14 +176,14 @@ def main():
         if sharded:
             return sharded_finalize(g, device, exchange_chunks=args.exchange_chunks)
         st = g.finalize()
-        if world > 1:
+        if multi:
             return exchange_and_merge(engine)
         return {"stored_kmers": int(st.stored_kmers), "count": int(st.count)}
 
     def fence():
         g.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -184,7 +198,7 @@ def main():
         res = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -249,12 +263,13 @@ def main():
                 print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args, genome_len)
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
 
     d_bases.free()
     d_off.free()
     g.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

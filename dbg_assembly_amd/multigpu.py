@@ -58,6 +58,55 @@ class HipEngine:
         self.g.sync()
 
 
+# One message per peer and transfer is bounded: a single 3.5 GB all_to_all_single (the node buffers of a
+# bench-size table) was observed to move only its first 1.78 GB on this RCCL build and report success
+# (profiles/ history, round 1).  Every bulk transfer below goes through point-to-point sends/receives of
+# at most MAX_MESSAGE_BYTES; all peers' pieces of one round travel as one batch.
+MAX_MESSAGE_BYTES = 512 << 20
+
+
+def exchange_slices(pairs, rank, group=None):
+    """pairs: list of (send_view, recv_view, peer) of uint8 tensors, equal sizes on both ends of a pair.
+    Moves send_view of every pair to the peer's recv_view."""
+    longest = max([int(sv.numel()) for sv, _, _ in pairs] + [0])
+    for off in range(0, longest, MAX_MESSAGE_BYTES):
+        ops = []
+        for sv, rv, peer in pairs:
+            n = int(sv.numel())
+            if off >= n:
+                continue
+            hi = min(n, off + MAX_MESSAGE_BYTES)
+            if peer == rank:
+                rv[off:hi].copy_(sv[off:hi])
+            else:
+                ops.append(dist.P2POp(dist.isend, sv[off:hi], peer, group))
+                ops.append(dist.P2POp(dist.irecv, rv[off:hi], peer, group))
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+
+
+def _exchange_uneven(pairs, rank, group=None):
+    """like exchange_slices, but the two directions of a pair have their own lengths"""
+    longest = max([max(int(sv.numel()), int(rv.numel())) for sv, rv, _ in pairs] + [0])
+    for off in range(0, longest, MAX_MESSAGE_BYTES):
+        ops = []
+        for sv, rv, peer in pairs:
+            sn, rn = int(sv.numel()), int(rv.numel())
+            if peer == rank:
+                if off < sn:
+                    hi = min(sn, off + MAX_MESSAGE_BYTES)
+                    rv[off:hi].copy_(sv[off:hi])
+                continue
+            if off < sn:
+                ops.append(dist.P2POp(dist.isend, sv[off:min(sn, off + MAX_MESSAGE_BYTES)], peer, group))
+            if off < rn:
+                ops.append(dist.P2POp(dist.irecv, rv[off:min(rn, off + MAX_MESSAGE_BYTES)], peer, group))
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+
+
 def exchange_and_merge(engine, group=None):
     """Run collectives 1-3 for an engine whose local table is finalized.  Returns a dict with the
     global totals and this rank's owned node count.  After the call the engine's table holds
@@ -82,11 +131,17 @@ def exchange_and_merge(engine, group=None):
     recv = engine.new_buffer(int(recv_counts.sum()))
     engine.sync()
     n_send, n_recv = int(send_counts.sum()), int(recv_counts.sum())
-    dist.all_to_all_single(recv[:n_recv * NODE_BYTES], send[:n_send * NODE_BYTES],
-                           output_split_sizes=[int(c) * NODE_BYTES for c in recv_counts],
-                           input_split_sizes=[int(c) * NODE_BYTES for c in send_counts], group=group)
+    pairs, so, ro = [], 0, 0
+    for peer in range(world):
+        sn, rn = int(send_counts[peer]) * NODE_BYTES, int(recv_counts[peer]) * NODE_BYTES
+        # a pair's two ends have different lengths here (what I send to the peer / what it sends to me):
+        # one entry per direction, the other side empty
+        pairs.append((send[so:so + sn], recv[ro:ro + rn], peer))
+        so += sn
+        ro += rn
+    _exchange_uneven(pairs, rank, group)
     if recv.is_cuda:
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
 
     # owner-side merge into a fresh table
     engine.reset_table()
@@ -137,17 +192,11 @@ def wrap_device_memory(ptr, nbytes, device):
 
 def _exchange_range(send, recv, info, j0, j1, world, rank, group):
     """buckets [j0, j1) of every destination's chunk -> the same buckets of chunk `rank` at the destination"""
-    ops = []
+    pairs = []
     for peer in range(world):
         lo, hi = peer * info.chunk_bytes + j0 * info.bucket_bytes, peer * info.chunk_bytes + j1 * info.bucket_bytes
-        if peer == rank:
-            recv[lo:hi].copy_(send[lo:hi])
-        else:
-            ops.append(dist.P2POp(dist.isend, send[lo:hi], peer, group))
-            ops.append(dist.P2POp(dist.irecv, recv[lo:hi], peer, group))
-    if ops:
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+        pairs.append((send[lo:hi], recv[lo:hi], peer))
+    exchange_slices(pairs, rank, group)
 
 
 def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
@@ -177,9 +226,9 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     dist.all_to_all_single(recv_cnt, send_cnt, group=group)
     n_chunks = max(1, min(int(exchange_chunks), int(info.buckets_per_rank)))
     if n_chunks <= 1:
-        dist.all_to_all_single(recv.view(torch.int64), send.view(torch.int64), group=group)  # 8-byte records: counts stay < 2^31
+        _exchange_range(send, recv, info, 0, int(info.buckets_per_rank), world, rank, group)
         if on_gpu:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
     else:
         # every rank cuts the SAME bucket ranges (buckets_per_rank is common; ranks that own fewer
         # buckets build a shorter range but still take part in every transfer)
@@ -224,7 +273,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
         lists = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(lists, mine, group=group)
         if on_gpu:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
         for src in range(world):
             if all_sizes[src, 1]:
                 g.shard_merge(lists[src].data_ptr(), int(all_sizes[src, 1]), is_triple=True)
@@ -236,7 +285,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
         lists = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(lists, mine, group=group)
         if on_gpu:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
         prev = (rank - 1) % world
         if all_sizes[prev, 0]:
             g.shard_merge(lists[prev].data_ptr(), int(all_sizes[prev, 0]), from_previous_shard=True)

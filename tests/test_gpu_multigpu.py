@@ -90,3 +90,25 @@ def test_sharded_finalize_single_rank_nccl(oracle, chunks):
         assert np.array_equal(nodes, ref.nodes)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("extra", [[], ["--exchange", "nodes"], ["--exchange-chunks", "1"]])
+def test_bench_multi_gpu_code_path_rehearsal(extra):
+    """bench.py's N > 1 branch (process group, shard, exchange, JSON assembly) with the one rank a test box
+    has; stdout must carry exactly one line, the JSON record (RCCL prints a banner when a communicator is
+    created)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--reads-per-gpu", "300000",
+                        "--genome-per-gpu", "2000000", "--table-slots", "80000000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["nodes"] > 1000000 and out["value"] > 0
+    for key in ("metric", "unit", "ms_per_step", "roofline", "scaling", "dtype", "data"):
+        assert key in out
