@@ -386,7 +386,11 @@ static int setup_partition(dbgk_handle *h)
 	const PartGeom &G = h->geom;
 	PartStore &P = h->store;
 	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2 / G.n_ranks;
-	P.ovf_cap = expected / 64 + (1ull << 20);
+	// records that find their bucket full are kept as {key, lb, rb} triples and inserted through the global
+	// path after the build: a key that occurs more often than a final bucket holds (cap2, ~1.15x the mean
+	// bucket fill) sends its surplus here, so this bounds the share of occurrences that may belong to such
+	// heavy hitters (high-copy repeats): 1/16 of the input + 1 M; beyond it finalize returns DBGK_ERR_CAPACITY
+	P.ovf_cap = expected / 16 + (1ull << 20);
 	P.spill_cap = (uint64_t)G.n_regions_own * 8 + (1ull << 16);
 	P.outgoing_cap = 1ull << 16;
 	const size_t n_entries = (size_t)G.n_ranks * G.B * G.n_sub;
@@ -405,6 +409,8 @@ static int setup_partition(dbgk_handle *h)
 	}
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
@@ -627,8 +633,23 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 // ---------------------------------------------------------------------------------------------
 
 // queue mark + insert for a batch that is already in device memory
+// the equal-length level-1 kernel applies when every read of the batch is L bases long, nothing is trimmed
+// (L <= maxReadLen), a read has at least 64 windows (so that a tile's byte range fits its LDS image) and
+// the reads lie back to back from offset 0 (n_bases == n_reads * L)
+static bool uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t n_reads, uint64_t n_bases, int has_long)
+{
+	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
+	static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
+	if (off || dbg_mode || has_long || uniform_len <= 0) return false;
+	const uint64_t L = (uint64_t)uniform_len, k = (uint64_t)h->cfg.kmer_size;
+	if (L > (uint64_t)h->cfg.max_read_len || L < k + 63 || L >= (1ull << 24)) return false;
+	const uint64_t Q = (L - k + 1 + 15) / 16;
+	return Q < 2048 && n_bases == n_reads * L && n_reads * Q < (1ull << 32);
+}
+
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                        uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */)
+                        uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
+                        int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */)
 {
 	if (n_reads == 0) return DBGK_OK;
 	if (h->seed) has_long = 1; // the dead bitmap carries the 'N' positions
@@ -639,6 +660,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
 	if (has_long != 0) HIPCHK(hipMemsetAsync(d_dead, 0, words * 4, h->stream));
 	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, sizeof(unsigned int), h->stream));
+	HIPCHK(hipMemsetAsync(&h->d_ctr->scratch[0], 0xFF, sizeof(unsigned long long), h->stream)); // shortest read of the batch
+	HIPCHK(hipMemsetAsync(&h->d_ctr->scratch[1], 0, sizeof(unsigned long long), h->stream));    // longest
 	hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
 	                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr);
 	if (h->seed && n_bases)
@@ -646,10 +669,12 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
-	if (has_long < 0) {
+	if (has_long < 0 || (uniform_len < 0 && h->part)) {
 		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(&h->h_ctr->scratch[0], &h->d_ctr->scratch[0], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
-		has_long = h->h_ctr->any_dead ? 1 : 0;
+		if (has_long < 0) has_long = h->h_ctr->any_dead ? 1 : 0;
+		if (uniform_len < 0) uniform_len = h->h_ctr->scratch[0] == h->h_ctr->scratch[1] ? (int64_t)h->h_ctr->scratch[0] : 0;
 	}
 	const uint64_t id_base = h->total_reads; // contig index of the batch's first sequence (SEEDIDX)
 	h->total_reads += n_reads;
@@ -666,6 +691,20 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
+	} else if (h->part && uniform_mode(h, uniform_len, n_reads, n_bases, has_long)) {
+		// every read of the batch has the same length: lanes are mapped to chunks of valid windows
+		UniformGeom U;
+		U.L = (uint32_t)uniform_len;
+		U.W = U.L - (uint32_t)h->cfg.kmer_size + 1u;
+		U.Q = (U.W + 15u) / 16u;
+		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
+		U.n_lanes = n_reads * U.Q;
+		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
+		if (h->geom.size >= (1ull << 31))
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+		else
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
@@ -767,16 +806,18 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 		} join_copiers{copiers};
 		if (nb) staged_copy(s.h_bases, bases + base0, nb, copiers);
 		int has_long = 0;
+		int64_t uniform_len = nr ? (int64_t)(offsets[r0 + 1] - offsets[r0]) : 0;
 		for (uint64_t i = 0; i <= nr; i++) {
 			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
 			s.h_offsets[i] = offsets[r0 + i] - base0;
 			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
+			if (i && (int64_t)(s.h_offsets[i] - s.h_offsets[i - 1]) != uniform_len) uniform_len = 0;
 			if (h->seed && i && s.h_offsets[i] - s.h_offsets[i - 1] >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
 		}
 		for (auto &t : copiers) t.join();
 		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
-		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long);
+		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(s.done, h->stream));
 		s.busy = true;

@@ -105,12 +105,14 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
                                                  Counters *__restrict__ ctr)
 {
 	__shared__ unsigned long long red[kBlock / 64];
-	unsigned long long tot = 0, stored = 0;
+	unsigned long long tot = 0, stored = 0, len_lo = ~0ull, len_hi = 0ull;
 	unsigned int dead_seen = 0;
 	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
 	for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_reads; r += stride) {
 		const uint64_t s = offsets[r], e = offsets[r + 1];
 		const uint64_t len = e - s;
+		len_lo = len < len_lo ? len : len_lo;
+		len_hi = len > len_hi ? len : len_hi;
 		if (s < n_bases) atomicOr(&start_bits[s >> 5], 1u << (s & 31u));
 		if (len >= (uint64_t)k) {
 			tot += len - (uint64_t)k + 1;
@@ -137,6 +139,18 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 		if (b) atomicAdd(&ctr->stored_kmers, b);
 	}
 	if (dead_seen) atomicOr(&ctr->any_dead, 1u);
+	// shortest / longest read of the batch (scratch[0], scratch[1]): equal => the partition engine's
+	// equal-length level-1 kernel applies
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const unsigned long long a2 = __shfl_down(len_lo, off, 64), b2 = __shfl_down(len_hi, off, 64);
+		len_lo = a2 < len_lo ? a2 : len_lo;
+		len_hi = b2 > len_hi ? b2 : len_hi;
+	}
+	if ((threadIdx.x & 63) == 0 && len_hi >= len_lo) {
+		atomicMin(&ctr->scratch[0], len_lo);
+		atomicMax(&ctr->scratch[1], len_hi);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------

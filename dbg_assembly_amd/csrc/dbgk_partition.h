@@ -459,6 +459,80 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // stores are the wrong trade on this chip even though the L2 merges them into lines.)
 // DBG != 0 are timing experiments selected with DBGK_DEBUG_MODE (results are wrong): 1 = extraction
 // only, 2 = no copy-out, 3 = copy-out into a small window
+// all 16 positions of one lane: canonical k-mer, neighbour codes, hash, slot, record; the record is
+// parked in the (still unused) stage buffer, column i of this thread, and ranked right away with an LDS
+// histogram atomic (bkt[i] = (bucket << 16) | rank).  Returns true when some canonical k-mer of the lane
+// is 0 (poly-A / poly-T): rare, the caller then feeds the key-0 side node.
+template <bool WIDE_D>
+__device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
+                                             uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
+{
+	// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
+	// first / last window are patched afterwards (rare per lane, so the loop stays lean).
+	// Complemented neighbour codes (3 - x == x ^ 3) for all 16 positions at once:
+	const uint32_t lwc = ~c.lw, nbc = ~c.nb;
+	uint32_t rev_mask = 0, key_min = ~0u;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; i++) {
+		const uint32_t sh = 30u - 2u * i;
+		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+		const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
+		const uint64_t key = rev ? c.rc : c.kbit;
+		// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
+		uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
+		asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
+		const uint32_t links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
+		uint32_t rev_bit = rev ? 1u : 0u;
+		asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
+		rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit 15 - i
+		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
+		uint64_t q;
+		const uint32_t slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q)
+		                             : divmod_magic_small(hash_code(key), G.magic.m, (uint32_t)G.magic.d, q);
+		// only one packed register per position stays live across the tile
+		const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+		const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
+		const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
+		L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
+		const bool valid = (c.valid >> i) & 1u;
+		const bool zero = key == 0ull;
+		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
+		const uint32_t b = (valid && !zero) ? (slot >> G.r) : (uint32_t)kMaxBuckets + (tid & 63u);
+		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+		// roll to the next position (DBGgraph.cpp:71-73)
+		c.kbit = ((c.kbit << 2) | right) & head_mask;
+		c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
+	}
+	// windows without a left / right neighbour: that side's code becomes 4 = none
+	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
+	for (uint32_t fix = G.kf ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
+		const uint32_t i = (uint32_t)__builtin_ctz(fix);
+		const bool fwd = !((rev_mask >> (15u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+		uint64_t rec = L.stage[i * kL1Threads + tid];
+		uint32_t lb = ((uint32_t)rec >> 3) & 7u, rbb = (uint32_t)rec & 7u;
+		if (fwd ? nl : nr) lb = 4u;
+		if (fwd ? nr : nl) rbb = 4u;
+		L.stage[i * kL1Threads + tid] = (rec & ~63ull) | (lb << 3) | rbb;
+	}
+	return key_min == 0u;
+}
+
+// after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
+template <int DBG>
+__device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
+                                                const uint32_t (&bkt)[16])
+{
+	lds_barrier(); // hist complete
+	uint32_t my_gbase[ScatterLds::kBpt];
+	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
+	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
+	uint64_t rec[16];
+#pragma unroll
+	for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
+	lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
+	scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+}
+
 template <bool HAS_DEAD, int DBG = 0, bool WIDE_D = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
@@ -489,61 +563,10 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 		uint32_t bkt[16]; // (bucket << 16) | rank once the position has been processed
 		L.hist[tid] = 0;
 		lds_barrier();
-		uint32_t zero_mask = 0; // this lane saw a canonical k-mer 0 (poly-A / poly-T): rare, handled below
-		{
-			Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
-			if (chunk >= n_chunks) c.valid = 0u;
-			// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
-			// first / last window are patched afterwards (rare per lane, so the loop stays lean).
-			// Complemented neighbour codes (3 - x == x ^ 3) for all 16 positions at once:
-			const uint32_t lwc = ~c.lw, nbc = ~c.nb;
-			uint32_t rev_mask = 0, key_min = ~0u;
-#pragma unroll
-			for (uint32_t i = 0; i < 16; i++) {
-				const uint32_t sh = 30u - 2u * i;
-				const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
-				const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
-				const uint64_t key = rev ? c.rc : c.kbit;
-				// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
-				uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
-				asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
-				const uint32_t links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
-				uint32_t rev_bit = rev ? 1u : 0u;
-				asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
-				rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit 15 - i
-				key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
-				uint64_t q;
-				const uint32_t slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q)
-				                             : divmod_magic_small(hash_code(key), G.magic.m, (uint32_t)G.magic.d, q);
-				// park the record in the (still unused) stage buffer, column i of this thread, and rank it
-				// right away: only one packed register per position stays live across the tile
-				const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-				const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
-				const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
-				L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
-				const bool valid = (c.valid >> i) & 1u;
-				const bool zero = key == 0ull;
-				// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
-				const uint32_t b = (valid && !zero) ? (slot >> G.r) : (uint32_t)kMaxBuckets + (tid & 63u);
-				bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-				// roll to the next position (DBGgraph.cpp:71-73)
-				c.kbit = ((c.kbit << 2) | right) & head_mask;
-				c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
-			}
-			// windows without a left / right neighbour: that side's code becomes 4 = none
-			const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
-			for (uint32_t fix = G.kf ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
-				const uint32_t i = (uint32_t)__builtin_ctz(fix);
-				const bool fwd = !((rev_mask >> (15u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
-				uint64_t rec = L.stage[i * kL1Threads + tid];
-				uint32_t lb = ((uint32_t)rec >> 3) & 7u, rbb = (uint32_t)rec & 7u;
-				if (fwd ? nl : nr) lb = 4u;
-				if (fwd ? nr : nl) rbb = 4u;
-				L.stage[i * kL1Threads + tid] = (rec & ~63ull) | (lb << 3) | rbb;
-			}
-			zero_mask = key_min == 0u; // rare: the plain path below finds which (valid) positions it was
-		}
-		if (zero_mask) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
+		Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
+		if (chunk >= n_chunks) c.valid = 0u;
+		const bool zero_seen = l1_positions<WIDE_D>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		if (zero_seen) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
 			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
 #pragma unroll 1
 			for (uint32_t i = 0; i < 16; i++) {
@@ -563,15 +586,162 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 			continue;
 		}
 		const RawChunk nxt = fetch(tile + gridDim.x);
-		lds_barrier(); // hist complete
-		uint32_t my_gbase[ScatterLds::kBpt];
-		const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
-		scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-		uint64_t rec[16];
+		l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
+		raw = nxt;
+	}
+}
+
+// ---- level 1 for batches of EQUAL-LENGTH reads ----------------------------------------------------
+// The flat kernel above gives every lane 16 consecutive base positions, so a fifth of the positions of
+// 150-base reads at k = 31 are windows that straddle a read boundary (hashed, divided, ranked in a dummy
+// bin and thrown away).  When every read of a batch has the same length L (the usual case for short
+// reads; decided per batch, the flat kernel stays the general path) lanes are mapped to chunks of VALID
+// windows instead: read r = lane / Q, chunk c = lane % Q, Q = ceil(W / 16), W = L - k + 1 windows per
+// read.  The lanes of a tile no longer own aligned 16-byte blocks, so the tile's byte range is packed
+// to 2 bits per base cooperatively into LDS first (one aligned 16-byte load per lane, as before) and each
+// lane funnels its own window out of five packed words; the boundary predicates are arithmetic.
+struct UniformGeom {
+	uint32_t L;          // length of every read of the batch, k <= L <= maxReadLen (no trimming in this mode)
+	uint32_t W;          // windows per read = L - k + 1, >= 64
+	uint32_t Q;          // lanes per read = ceil(W / 16), < 2048
+	uint32_t qmagic;     // ceil(2^22 / Q): (x * qmagic) >> 22 == x / Q for x < 2048 + Q
+	uint64_t n_lanes;    // n_reads * Q
+};
+
+constexpr int kPkWords = 1792; // packed words of one tile's byte range: <= 1024 lanes * 16 (1 + (k - 1) / W) bases + slack
+struct UniformLds {
+	ScatterLds s;
+	uint32_t pk[kPkWords];
+};
+
+__device__ __forceinline__ uint32_t funnel_left(uint32_t hi, uint32_t lo, uint32_t sh) // ({hi,lo} << sh) >> 32, sh in 0..30 (even)
+{
+	return sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+}
+
+// the side node of key 0 for one lane, from its decoded window (rare path, rolled)
+__device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask, uint32_t rc_shift, uint32_t kf, Counters *ctr)
+{
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16; i++) {
+		const uint32_t sh = 30u - 2u * i;
+		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+		const bool rev = c.rc < c.kbit;
+		const uint64_t key = rev ? c.rc : c.kbit;
+		if (((c.valid >> i) & 1u) && key == 0ull) {
+			const uint32_t lc = ((c.has_l >> i) & 1u) ? left : 4u, rcd = ((c.has_r >> i) & 1u) ? right : 4u;
+			const uint32_t lb = rev ? (rcd == 4u ? 4u : 3u - rcd) : lc, rb = rev ? (lc == 4u ? 4u : 3u - lc) : rcd;
+			links_cas_observe(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links), kf ? 0u : lb, kf ? 4u : rb);
+		}
+		c.kbit = ((c.kbit << 2) | right) & head_mask;
+		c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
+	}
+}
+
+template <int DBG = 0, bool WIDE_D = false>
+__global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, PartGeom G, PartStore P,
+                                                                         Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	UniformLds &UL = *reinterpret_cast<UniformLds *>(lds_raw);
+	ScatterLds &L = UL.s;
+	const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;
+	const uint32_t rc_shift = 2u * k - 2u;
+	const uint32_t rel_mask = (1u << G.r) - 1u, q_shift = G.r + 6u;
+
+	// (read, chunk) of a tile's first lane; advanced by the grid stride without dividing again
+	const uint64_t stride_lanes = (uint64_t)gridDim.x * kL1Threads;
+	const uint64_t stride_r = stride_lanes / U.Q;
+	const uint32_t stride_c = (uint32_t)(stride_lanes - stride_r * U.Q);
+	uint64_t r0 = ((uint64_t)blockIdx.x * kL1Threads) / U.Q;
+	uint32_t c0 = (uint32_t)((uint64_t)blockIdx.x * kL1Threads - r0 * U.Q);
+
+	// first byte (16-aligned) and number of 16-byte blocks of the range the tile starting at (rr, cc) touches
+	auto tile_range = [&](uint64_t tile, uint64_t rr, uint32_t cc, uint64_t &B0) -> uint32_t {
+		const uint64_t p_first = rr * U.L + 16u * cc;
+		B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
+		const uint64_t lane_last = min((tile + 1u) * kL1Threads, U.n_lanes) - 1u;
+		const uint32_t x = cc + (uint32_t)(lane_last - tile * kL1Threads);
+		const uint32_t dr = (x * U.qmagic) >> 22;
+		const uint64_t p_last = (rr + dr) * U.L + 16u * (x - dr * U.Q);
+		uint64_t end = p_last + 16u + k + 2u;
+		end = min(end, (rb.n_bases + 15u) & ~15ull);
+		return end > B0 ? (uint32_t)((end - B0 + 15u) >> 4) : 0u;
+	};
+	struct RawU {
+		uint4 a, b;
+	};
+	auto fetch = [&](uint64_t tile, uint64_t rr, uint32_t cc) {
+		RawU raw;
+		raw.a = raw.b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+		if (tile >= n_tiles) return raw;
+		uint64_t B0;
+		const uint32_t n_blocks = tile_range(tile, rr, cc, B0);
+		const uint32_t t = fresh_tid();
+		if (t < n_blocks) raw.a = load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + t);
+		if (t + kL1Threads < n_blocks) raw.b = load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + t + kL1Threads);
+		return raw;
+	};
+
+	RawU raw = fetch(blockIdx.x, r0, c0);
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		uint64_t B0;
+		const uint32_t n_blocks = tile_range(tile, r0, c0, B0);
+		// pack the tile's bytes (block tid, block tid + 1024) into LDS, 16 bases per word
+		if (tid < n_blocks) UL.pk[tid] = pack16_ascii(raw.a);
+		if (tid + kL1Threads < n_blocks && tid + kL1Threads < (uint32_t)kPkWords) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
+		uint32_t bkt[16];
+		L.hist[tid] = 0;
+		lds_barrier();
+		// this lane's chunk
+		const uint64_t lane_g = tile * kL1Threads + tid;
+		const uint32_t x = c0 + tid;
+		const uint32_t dr = (x * U.qmagic) >> 22;
+		const uint32_t cc = x - dr * U.Q;
+		const uint64_t p = (r0 + dr) * U.L + 16u * cc;   // flat position of the lane's first window
+		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
+		Chunk16 c;
+		{
+			const uint32_t rel = lane_g < U.n_lanes ? (uint32_t)(s0 - B0) : 0u;
+			const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u), sh = 2u * (rel & 15u);
+			const uint32_t x0 = UL.pk[d], x1 = UL.pk[d + 1], x2 = UL.pk[d + 2], x3 = UL.pk[d + 3], x4 = UL.pk[d + 4];
+			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
+			// stream Y starts at position p (X starts at p - 1 unless p == 0)
+			const uint32_t adv = p ? 2u : 0u;
+			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
+			c.lw = p ? X0 : (X0 >> 2); // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
+			c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
+			c.rc = revcomp_kbit(c.kbit, (int)k);
+			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
+			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
+			c.nb = funnel_left(ya, yb, wsh);
+			const uint32_t first_w = 16u * cc; // index of the lane's first window inside its read
+			const uint32_t nv = (lane_g < U.n_lanes && first_w < U.W) ? min(16u, U.W - first_w) : 0u;
+			const uint32_t nr = (lane_g < U.n_lanes && first_w + 1u < U.W) ? min(16u, U.W - 1u - first_w) : 0u;
+			c.valid = (1u << nv) - 1u;
+			c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
+			c.has_l = cc ? 0xFFFFu : 0xFFFEu;   // its first window no left one
+		}
+		const bool zero_seen = l1_positions<WIDE_D>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
+		// next tile
+		r0 += stride_r;
+		c0 += stride_c;
+		if (c0 >= U.Q) { c0 -= U.Q; r0 += 1u; }
+		if (DBG == 1) {
+			uint64_t xx = 0;
 #pragma unroll
-		for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
-		lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
-		scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+			for (int u = 0; u < 16; u++) xx ^= L.stage[u * kL1Threads + tid] + bkt[u];
+			if (xx == 0x1234567u) P.l1[threadIdx.x] = xx;
+			lds_barrier();
+			raw = fetch(tile + gridDim.x, r0, c0);
+			continue;
+		}
+		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
+		l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
 		raw = nxt;
 	}
 }

@@ -18,14 +18,14 @@ from dbg_assembly_amd import capi  # noqa: E402
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
 
 
-def make_reads(rng, n, G, L, n_rate, repeat):
+def make_reads(rng, n, G, L, n_rate, repeat, uniform=False):
     g = "".join(rng.choice("ACGT") for _ in range(G))
     if repeat:
         unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40)))
         g = g[:G // 2] + unit * (G // (2 * len(unit)) + 1)
     out = []
     for _ in range(n):
-        ln = L if rng.random() < 0.7 else rng.randint(0, L + 200)
+        ln = L if (uniform or rng.random() < 0.7) else rng.randint(0, L + 200)
         ln = min(ln, len(g))
         s = rng.randint(0, len(g) - ln)
         r = list(g[s:s + ln])
@@ -41,7 +41,14 @@ def make_reads(rng, n, G, L, n_rate, repeat):
                 r[j] = r[j].lower()
         out.append("".join(r).encode())
     if rng.random() < 0.5:
-        out += [b"A" * rng.randint(1, 300)] * rng.randint(1, 400) + [b"T" * rng.randint(1, 120)] * rng.randint(1, 50)
+        if uniform:  # equal-length batches take the partition engine's equal-length level-1 kernel
+            ln = len(out[0]) if out else L
+            out = [r for r in out if len(r) == ln]
+            out += [b"A" * ln] * rng.randint(1, 400) + [b"T" * ln] * rng.randint(1, 50)
+        else:
+            out += [b"A" * rng.randint(1, 300)] * rng.randint(1, 400) + [b"T" * rng.randint(1, 120)] * rng.randint(1, 50)
+    elif uniform and out:
+        out = [r for r in out if len(r) == len(out[0])]
     rng.shuffle(out)
     return out
 
@@ -62,8 +69,14 @@ def push_in_batches(g, reads, rng):
             g.push_reads(*pack(reads[a:b]))
 
 
-def build_sharded(reads, k, size, n_shards, rng, max_read_len):
-    expected = rng.choice([1, 50000, 2000000])  # every shard of a job is created with the SAME geometry (size, k, expected_kmers)
+def pick_expected(rng, actual):
+    """expected_kmers is an upper bound of what a handle will extract; a gross under-estimate is tolerated only as
+    far as the overflow stores reach (then dbgk_finalize reports DBGK_ERR_CAPACITY), so it is tried on small inputs only"""
+    return rng.choice([max(1, actual), 3 * actual + 1, 1 if actual < 300000 else actual])
+
+
+def build_sharded(reads, k, size, n_shards, rng, max_read_len, actual):
+    expected = pick_expected(rng, actual)  # every shard of a job is created with the SAME geometry (size, k, expected_kmers)
     graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected,
                          shard_count=n_shards, shard_index=i, max_read_len=max_read_len) for i in range(n_shards)]
     try:
@@ -138,6 +151,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # re-run one configuration
     bad = 0
+    capacity_skips = 0
     for c in range(n_cfg):
         if only >= 0 and c != only:
             continue
@@ -145,7 +159,8 @@ def main():
         k = rng.choice([31, 31, 32, 27, 21, 17, 12, 5, 1])
         L = rng.choice([150, 100, 36, 250, 400])
         max_read_len = rng.choice([250, 250, 100, 1000000])
-        reads = make_reads(rng, rng.randint(1, 6000), rng.randint(max(L, 50), 60000), L, rng.choice([0.0, 0.003, 0.05]), rng.random() < 0.3)
+        reads = make_reads(rng, rng.randint(1, 6000), rng.randint(max(L, 50), 60000), L, rng.choice([0.0, 0.003, 0.05]), rng.random() < 0.3,
+                           uniform=rng.random() < 0.45)
         slots = rng.choice([1 << 26, 70_000_000, 100_000_007, 600_000_000, 2_200_000_000, 4_200_000_000])
         size = capi.find_next_prime_ref(slots)
         with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(3_000_000), engine=capi.ENGINE_DIRECT, max_read_len=max_read_len) as g:
@@ -153,15 +168,24 @@ def main():
             st = g.finalize()
             want = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
         n_shards = rng.choice([0, 0, 1, 2, 3])
-        if n_shards == 0:
-            with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=rng.choice([1, 100000, 3000000]),
+        try:
+          if n_shards == 0:
+            with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=pick_expected(rng, want[2]),
                             max_read_len=max_read_len) as g:
                 push_in_batches(g, reads, rng)
                 st = g.finalize()
                 got = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
-        else:
+          else:
             g_next.clear()
-            got = build_sharded(reads, k, size, n_shards, rng, max_read_len)
+            got = build_sharded(reads, k, size, n_shards, rng, max_read_len, want[2])
+        except capi.DbgkError as e:
+            # tandem-repeat inputs put more than 1/16 of all occurrences on a handful of keys: the documented limit
+            # of the partition engine's overflow store (DBGK_ERR_CAPACITY); anything else is a failure
+            if e.status != capi.ERR_CAPACITY:
+                raise
+            capacity_skips += 1
+            print("cfg %3d k=%2d reads=%5d  skipped: heavy hitters beyond the overflow store" % (c, k, len(reads)), flush=True)
+            continue
         ok = got == want
         if k <= 13:  # the k-mer frequency table: atomics on the byte table against the partitioned counting
             tabs = []
@@ -179,7 +203,9 @@ def main():
         print("cfg %3d k=%2d L=%3d maxlen=%7d reads=%5d slots=%10d shards=%d  %s" % (c, k, L, max_read_len, len(reads), size, n_shards,
                                                                                     "ok" if ok else "MISMATCH %r != %r" % (got, want)), flush=True)
     print("%d configurations, %d mismatches" % (n_cfg, bad))
-    sys.exit(1 if bad else 0)
+    if capacity_skips:
+        print("%d skipped at the heavy-hitter limit" % capacity_skips)
+    sys.exit(1 if bad or capacity_skips > n_cfg // 10 else 0)
 
 
 if __name__ == "__main__":
