@@ -216,7 +216,8 @@ def main():
         # buckets on two streams: their launch durations overlap (each is stretched by the other), so
         # the window they share is attributed pro rata when the dominant kernel is chosen; the
         # figures printed per kernel stay the measured launch durations, which is what rocprofv3 shows.
-        l1_name = "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else "k_extract_scatter"
+        l1_name = "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else \
+                  ("k_extract_scatter_uniform" if tm.uniform_launches else "k_extract_scatter")  # equal-length reads take the former
         l2_ms, build_ms, wall_ms = tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
         phase_kernels = {l1_name: tm.insert_ms / launches, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
         share = wall_ms / (l2_ms + build_ms) if (l2_ms + build_ms) > 0 else 1.0   # < 1 when the two overlap

@@ -61,7 +61,7 @@ class Timings(C.Structure):
     _fields_ = [("mark_ms", C.c_float), ("insert_ms", C.c_float), ("partition_ms", C.c_float),
                 ("build_ms", C.c_float), ("fixup_ms", C.c_float), ("finalize_ms", C.c_float),
                 ("insert_launches", C.c_uint64), ("l2_build_wall_ms", C.c_float), ("partition_launches", C.c_uint32),
-                ("reserved", C.c_uint64 * 2)]
+                ("uniform_launches", C.c_uint32), ("reserved32", C.c_uint32), ("reserved", C.c_uint64 * 1)]
 
 
 class DbgkError(RuntimeError):

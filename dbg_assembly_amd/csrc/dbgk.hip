@@ -134,6 +134,7 @@ struct dbgk_handle {
 	float phase_ms[PH_COUNT] = {0};
 	uint64_t insert_launches = 0;
 	uint32_t partition_launches = 0;
+	uint32_t uniform_launches = 0;
 
 	TableRef tref() const { return TableRef{table, size, magic}; }
 };
@@ -699,6 +700,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		U.Q = (U.W + 15u) / 16u;
 		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
 		U.n_lanes = n_reads * U.Q;
+		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
 		if (h->geom.size >= (1ull << 31))
@@ -1814,6 +1816,7 @@ extern "C" int dbgk_get_timings(dbgk_handle *h, dbgk_timings *out)
 	out->insert_launches = h->insert_launches;
 	out->l2_build_wall_ms = h->phase_ms[PH_L2_BUILD_WALL];
 	out->partition_launches = h->partition_launches;
+	out->uniform_launches = h->uniform_launches;
 	return DBGK_OK;
 }
 
@@ -1823,6 +1826,7 @@ extern "C" int dbgk_reset_timings(dbgk_handle *h)
 	for (auto &v : h->phase_ms) v = 0.f;
 	h->insert_launches = 0;
 	h->partition_launches = 0;
+	h->uniform_launches = 0;
 	return DBGK_OK;
 }
 

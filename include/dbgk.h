@@ -126,7 +126,10 @@ typedef struct dbgk_timings {
 	                              together; they run concurrently on two streams, so partition_ms and
 	                              build_ms (sums of their launches) overlap and add up to more than this */
 	uint32_t partition_launches; /* launches accumulated into partition_ms (= into build_ms)         */
-	uint64_t reserved[2];
+	uint32_t uniform_launches;   /* of insert_launches: batches of equal-length reads, which take the
+	                                PARTITION engine's k_extract_scatter_uniform instead of k_extract_scatter */
+	uint32_t reserved32;
+	uint64_t reserved[1];
 } dbgk_timings;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
