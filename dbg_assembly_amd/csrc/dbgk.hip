@@ -410,8 +410,10 @@ static int setup_partition(dbgk_handle *h)
 	}
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
@@ -644,7 +646,7 @@ static bool uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t n_r
 	if (off || dbg_mode || has_long || uniform_len <= 0) return false;
 	const uint64_t L = (uint64_t)uniform_len, k = (uint64_t)h->cfg.kmer_size;
 	if (L > (uint64_t)h->cfg.max_read_len || L < k + 63 || L >= (1ull << 24)) return false;
-	const uint64_t Q = (L - k + 1 + 15) / 16;
+	const uint64_t Q = (L - k + 1 + 14) / 15; // the larger of the two lane counts per read (15 or 16 windows per lane)
 	return Q < 2048 && n_bases == n_reads * L && n_reads * Q < (1ull << 32);
 }
 
@@ -697,16 +699,24 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		UniformGeom U;
 		U.L = (uint32_t)uniform_len;
 		U.W = U.L - (uint32_t)h->cfg.kmer_size + 1u;
-		U.Q = (U.W + 15u) / 16u;
+		// 16 or 15 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: 15 -> none)
+		const uint32_t q16 = (U.W + 15u) / 16u, q15 = (U.W + 14u) / 15u;
+		const bool c15 = q15 * 15u - U.W < q16 * 16u - U.W;
+		U.Q = c15 ? q15 : q16;
 		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
 		U.n_lanes = n_reads * U.Q;
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
-		if (h->geom.size >= (1ull << 31))
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+		const bool wide = h->geom.size >= (1ull << 31);
+		if (wide && c15)
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true, 15>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+		else if (wide)
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true, 16>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+		else if (c15)
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false, 15>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
 		else
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false, 16>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU

@@ -463,7 +463,7 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // parked in the (still unused) stage buffer, column i of this thread, and ranked right away with an LDS
 // histogram atomic (bkt[i] = (bucket << 16) | rank).  Returns true when some canonical k-mer of the lane
 // is 0 (poly-A / poly-T): rare, the caller then feeds the key-0 side node.
-template <bool WIDE_D>
+template <bool WIDE_D, int NPOS = 16>
 __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
 {
@@ -473,7 +473,9 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 	const uint32_t lwc = ~c.lw, nbc = ~c.nb;
 	uint32_t rev_mask = 0, key_min = ~0u;
 #pragma unroll
-	for (uint32_t i = 0; i < 16; i++) {
+	for (uint32_t i = NPOS; i < 16; i++) bkt[i] = (uint32_t)kMaxBuckets << 16; // lanes own NPOS positions: the rest never holds a record
+#pragma unroll
+	for (uint32_t i = 0; i < (uint32_t)NPOS; i++) {
 		const uint32_t sh = 30u - 2u * i;
 		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
 		const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
@@ -484,7 +486,7 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 		const uint32_t links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
 		uint32_t rev_bit = rev ? 1u : 0u;
 		asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
-		rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit 15 - i
+		rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit NPOS - 1 - i
 		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 		uint64_t q;
 		const uint32_t slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q)
@@ -507,7 +509,7 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
 	for (uint32_t fix = G.kf ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
 		const uint32_t i = (uint32_t)__builtin_ctz(fix);
-		const bool fwd = !((rev_mask >> (15u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+		const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
 		uint64_t rec = L.stage[i * kL1Threads + tid];
 		uint32_t lb = ((uint32_t)rec >> 3) & 7u, rbb = (uint32_t)rec & 7u;
 		if (fwd ? nl : nr) lb = 4u;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 struct UniformGeom {
 	uint32_t L;          // length of every read of the batch, k <= L <= maxReadLen (no trimming in this mode)
 	uint32_t W;          // windows per read = L - k + 1, >= 64
-	uint32_t Q;          // lanes per read = ceil(W / 16), < 2048
+	uint32_t Q;          // lanes per read = ceil(W / C), < 2048; C = 16 or 15 windows per lane, whichever wastes fewer slots
 	uint32_t qmagic;     // ceil(2^22 / Q): (x * qmagic) >> 22 == x / Q for x < 2048 + Q
 	uint64_t n_lanes;    // n_reads * Q
 };
@@ -638,7 +640,7 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 	}
 }
 
-template <int DBG = 0, bool WIDE_D = false>
+template <int DBG = 0, bool WIDE_D = false, int C = 16>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, PartGeom G, PartStore P,
                                                                          Counters *__restrict__ ctr)
 {
@@ -660,12 +662,12 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 
 	// first byte (16-aligned) and number of 16-byte blocks of the range the tile starting at (rr, cc) touches
 	auto tile_range = [&](uint64_t tile, uint64_t rr, uint32_t cc, uint64_t &B0) -> uint32_t {
-		const uint64_t p_first = rr * U.L + 16u * cc;
+		const uint64_t p_first = rr * U.L + (uint32_t)C * cc;
 		B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
 		const uint64_t lane_last = min((tile + 1u) * kL1Threads, U.n_lanes) - 1u;
 		const uint32_t x = cc + (uint32_t)(lane_last - tile * kL1Threads);
 		const uint32_t dr = (x * U.qmagic) >> 22;
-		const uint64_t p_last = (rr + dr) * U.L + 16u * (x - dr * U.Q);
+		const uint64_t p_last = (rr + dr) * U.L + (uint32_t)C * (x - dr * U.Q);
 		uint64_t end = p_last + 16u + k + 2u;
 		end = min(end, (rb.n_bases + 15u) & ~15ull);
 		return end > B0 ? (uint32_t)((end - B0 + 15u) >> 4) : 0u;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		const uint32_t x = c0 + tid;
 		const uint32_t dr = (x * U.qmagic) >> 22;
 		const uint32_t cc = x - dr * U.Q;
-		const uint64_t p = (r0 + dr) * U.L + 16u * cc;   // flat position of the lane's first window
+		const uint64_t p = (r0 + dr) * U.L + (uint32_t)C * cc;   // flat position of the lane's first window
 		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
 		Chunk16 c;
 		{
@@ -718,14 +720,14 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
 			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
 			c.nb = funnel_left(ya, yb, wsh);
-			const uint32_t first_w = 16u * cc; // index of the lane's first window inside its read
-			const uint32_t nv = (lane_g < U.n_lanes && first_w < U.W) ? min(16u, U.W - first_w) : 0u;
-			const uint32_t nr = (lane_g < U.n_lanes && first_w + 1u < U.W) ? min(16u, U.W - 1u - first_w) : 0u;
+			const uint32_t first_w = (uint32_t)C * cc; // index of the lane's first window inside its read
+			const uint32_t nv = (lane_g < U.n_lanes && first_w < U.W) ? min((uint32_t)C, U.W - first_w) : 0u;
+			const uint32_t nr = (lane_g < U.n_lanes && first_w + 1u < U.W) ? min((uint32_t)C, U.W - 1u - first_w) : 0u;
 			c.valid = (1u << nv) - 1u;
 			c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
 			c.has_l = cc ? 0xFFFFu : 0xFFFEu;   // its first window no left one
 		}
-		const bool zero_seen = l1_positions<WIDE_D>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		const bool zero_seen = l1_positions<WIDE_D, C>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile
 		r0 += stride_r;
