@@ -48,6 +48,7 @@ static int hip_fail(hipError_t e, const char *what, int line)
 namespace {
 
 constexpr uint32_t kMaxBuildLaunches = 4096; // build ranges per step (one work cursor each)
+constexpr uint64_t kHeavyHitterSlots = 4194301; // side table for the surplus of heavy hitters (prime, 64 MiB)
 
 enum Phase { PH_MARK = 0, PH_INSERT, PH_PARTITION, PH_BUILD, PH_FIXUP, PH_FINALIZE, PH_L2_BUILD_WALL, PH_COUNT };
 
@@ -247,6 +248,7 @@ static void free_handle(dbgk_handle *h)
 		                (void *)h->store.spill, (void *)h->store.ovf_n})
 			if (p) (void)hipFree(p);
 		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
+		if (h->store.hh) (void)hipFree(h->store.hh);
 		if (h->region_cursor) (void)hipFree(h->region_cursor);
 		for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
 		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
@@ -288,6 +290,7 @@ static int reset_state(dbgk_handle *h)
 		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
 		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
+		if (h->store.hh) HIPCHK(hipMemsetAsync(h->store.hh, 0, h->store.hh_size * sizeof(Node), h->stream));
 		HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
 		h->exchanged = false;
 		h->part_planned = false;
@@ -407,6 +410,13 @@ static int setup_partition(dbgk_handle *h)
 	if (!ok) {
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		return DBGK_ERR_NOMEM;
+	}
+	P.hh = nullptr;
+	P.hh_size = 0;
+	if (!h->sharded) {
+		if (hipMalloc(&P.hh, kHeavyHitterSlots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+		P.hh_size = kHeavyHitterSlots;
+		P.hh_magic = make_mod_magic(kHeavyHitterSlots);
 	}
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
@@ -1025,11 +1035,16 @@ static int build_from_records(dbgk_handle *h)
 		                   reinterpret_cast<uint32_t *>(h->counts));
 		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, 1,
 		                   reinterpret_cast<uint32_t *>(h->counts));
+		hipLaunchKernelGGL(k_kf_apply_table, dim3(grid_for(h, h->store.hh_size)), dim3(kBlock), 0, h->stream, h->store.hh, h->store.hh_size,
+		                   reinterpret_cast<uint32_t *>(h->counts));
 		hipLaunchKernelGGL(k_kf_key0, dim3(1), dim3(64), 0, h->stream, h->d_ctr, h->counts);
 	} else if (!h->sharded) {
 		hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
 		                   h->tref(), h->d_ctr);
 		hipLaunchKernelGGL(k_insert_triples, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap,
+		                   h->tref(), h->d_ctr);
+		// the aggregated surplus of heavy hitters (empty slots are all-zero records and add nothing)
+		hipLaunchKernelGGL(k_merge_nodes, dim3(grid_for(h, h->store.hh_size)), dim3(kBlock), 0, h->stream, h->store.hh, h->store.hh_size,
 		                   h->tref(), h->d_ctr);
 	} else {
 		// spill nodes of this shard's regions stay in the shard unless they run off its end (-> outgoing);

@@ -435,6 +435,14 @@ __global__ __launch_bounds__(kBlock) void k_kf_apply(const Node *__restrict__ in
 		kf_sat_add(count_words, in[i].kmer, is_triple ? 1u : ((uint32_t)in[i].links >> 24));
 }
 
+// the same for the side table that aggregates the surplus of heavy hitters (empty slots are skipped)
+__global__ __launch_bounds__(kBlock) void k_kf_apply_table(const Node *__restrict__ in, uint64_t n, uint32_t *__restrict__ count_words)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+		if (in[i].kmer != 0ull) kf_sat_add(count_words, in[i].kmer, (uint32_t)in[i].links >> 24);
+}
+
 // key 0 (poly-A / poly-T) never enters the record stream: its occurrences are counted in the A counter
 // of the side word
 __global__ void k_kf_key0(const Counters *__restrict__ ctr, uint8_t *__restrict__ counts)

@@ -97,6 +97,12 @@ struct PartStore {
 	Node *spill;                  // nodes that probed past the end of their region
 	unsigned long long *ovf_n;    // [0] = overflow triples, [1] = spill nodes
 	uint64_t ovf_cap, spill_cap;
+	// once the overflow list is full, further observations are AGGREGATED in a small open-addressed table
+	// (global atomics): the surplus of heavy hitters -- a satellite repeat's k-mers occur millions of times
+	// -- collapses onto a handful of nodes there.  Merged into the main table after the build.
+	Node *hh;                     // null: not available (sharded handles)
+	uint64_t hh_size;
+	ModMagic hh_magic;
 };
 
 __device__ __forceinline__ uint64_t record_key(uint64_t rec, uint32_t b1, const PartGeom &G)
@@ -112,6 +118,20 @@ __device__ __forceinline__ void push_overflow(const PartStore &P, uint64_t key, 
 	if (i < P.ovf_cap) {
 		P.ovf[i].kmer = key;
 		P.ovf[i].links = (uint64_t)lb | ((uint64_t)rb << 8);
+	} else if (P.hh) {
+		const TableRef T{P.hh, P.hh_size, P.hh_magic};
+		const uint64_t slot = fast_mod(hash_code(key), T.magic);
+		const uint4 v = *reinterpret_cast<const uint4 *>(&T.nodes[slot]);
+		Node first;
+		first.kmer = ((uint64_t)v.y << 32) | v.x;
+		first.links = ((uint64_t)v.w << 32) | v.z;
+		uint64_t guess;
+		unsigned long long dummy_new = 0, dummy_conf = 0; // counted when the node is merged into the main table
+		const uint64_t s = find_or_claim(T, key, slot, first, guess, dummy_new, dummy_conf);
+		if (s == ~0ull)
+			atomicOr(&ctr->error, 2u); // more distinct overflowing keys than the side table holds
+		else
+			links_cas_observe(reinterpret_cast<unsigned long long *>(&T.nodes[s].links), guess, lb, rb);
 	} else {
 		atomicOr(&ctr->error, 2u); // overflow store exhausted: results would be incomplete
 	}

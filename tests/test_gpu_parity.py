@@ -433,6 +433,21 @@ def test_sharded_table_equals_oracle(capi, oracle, n_shards, ranged):
     assert oracle.check_host_table(whole, fl, size, ref.count - 1) == 0
 
 
+def test_heavy_hitters_beyond_the_overflow_list(capi, oracle):
+    """a tandem repeat puts millions of occurrences on a handful of k-mers: their final buckets overflow, the
+    overflow list (1/16 of the input + 1 M) fills up, and the rest is aggregated in the side table"""
+    rng = random.Random(99)
+    unit = "ACGGTCA"
+    reads = [(unit * 30)[rng.randint(0, 6):][:150].encode() for _ in range(30000)] + rand_reads(rng, 2000, G=20000)
+    rng.shuffle(reads)
+    ref = oracle.build_graph(files_mem=[oracle.pack_reads(reads)], k=31, init_hash_size=0.002)
+    with capi.Graph(k=31, table_slots=PART_SLOTS, engine=capi.ENGINE_PARTITION, expected_kmers=ref.total_kmers) as g:
+        g.push_reads(*oracle.pack_reads(reads))
+        st = g.finalize()
+        assert st.count == ref.count and st.total_kmers == ref.total_kmers
+        assert np.array_equal(g.export_sorted(), ref.nodes)
+
+
 def test_tables_of_2_31_slots_and_more_use_the_wide_divisor_path(capi, oracle):
     """the 8-GPU bench builds ONE table of ~2^32 slots: above 2^31 slots the level-1 kernel divides with the
     two-step 2-by-1 form instead of the multiply-high shortcut; single handle and two shards"""
