@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -672,9 +673,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (rc) return rc;
 	HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
 	if (has_long != 0) HIPCHK(hipMemsetAsync(d_dead, 0, words * 4, h->stream));
-	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, sizeof(unsigned int), h->stream));
-	HIPCHK(hipMemsetAsync(&h->d_ctr->scratch[0], 0xFF, sizeof(unsigned long long), h->stream)); // shortest read of the batch
-	HIPCHK(hipMemsetAsync(&h->d_ctr->scratch[1], 0, sizeof(unsigned long long), h->stream));    // longest
+	static_assert(offsetof(Counters, len_max) + sizeof(unsigned long long) - offsetof(Counters, any_dead) == 20, "per-batch fields are contiguous");
+	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream)); // any_dead, len_min_inv, len_max
 	hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
 	                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr);
 	if (h->seed && n_bases)
@@ -683,11 +683,10 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	rc = span_end(h, sp);
 	if (rc) return rc;
 	if (has_long < 0 || (uniform_len < 0 && h->part)) {
-		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(&h->h_ctr->scratch[0], &h->d_ctr->scratch[0], 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, 20, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (has_long < 0) has_long = h->h_ctr->any_dead ? 1 : 0;
-		if (uniform_len < 0) uniform_len = h->h_ctr->scratch[0] == h->h_ctr->scratch[1] ? (int64_t)h->h_ctr->scratch[0] : 0;
+		if (uniform_len < 0) uniform_len = ~h->h_ctr->len_min_inv == h->h_ctr->len_max ? (int64_t)h->h_ctr->len_max : 0;
 	}
 	const uint64_t id_base = h->total_reads; // contig index of the batch's first sequence (SEEDIDX)
 	h->total_reads += n_reads;

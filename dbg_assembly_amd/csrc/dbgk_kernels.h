@@ -33,9 +33,12 @@ struct Counters {
 	unsigned long long stored_kmers;   // windows extracted
 	unsigned long long polyA_links;    // key-0 node, l_link | r_link << 32
 	unsigned int       error;          // bit 0: table full
+	// per batch, cleared with ONE memset before k_mark (any_dead .. len_max are contiguous):
 	unsigned int       any_dead;       // some read longer than maxReadLen in the current batch
+	unsigned long long len_min_inv;    // ~(shortest read length) of the batch (inverted so that 0 is the neutral start value)
+	unsigned long long len_max;        // longest read length of the batch
 	unsigned long long polyA_slot;     // where the key-0 node was placed for export (or ~0)
-	unsigned long long scratch[4];
+	unsigned long long scratch[2];
 };
 
 struct TableRef {
@@ -139,8 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 		if (b) atomicAdd(&ctr->stored_kmers, b);
 	}
 	if (dead_seen) atomicOr(&ctr->any_dead, 1u);
-	// shortest / longest read of the batch (scratch[0], scratch[1]): equal => the partition engine's
-	// equal-length level-1 kernel applies
+	// shortest / longest read of the batch: equal => the partition engine's equal-length level-1 kernel applies
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) {
 		const unsigned long long a2 = __shfl_down(len_lo, off, 64), b2 = __shfl_down(len_hi, off, 64);
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 		len_hi = b2 > len_hi ? b2 : len_hi;
 	}
 	if ((threadIdx.x & 63) == 0 && len_hi >= len_lo) {
-		atomicMin(&ctr->scratch[0], len_lo);
-		atomicMax(&ctr->scratch[1], len_hi);
+		atomicMax(&ctr->len_min_inv, ~len_lo);
+		atomicMax(&ctr->len_max, len_hi);
 	}
 }
 
