@@ -421,10 +421,14 @@ static int setup_partition(dbgk_handle *h)
 	}
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
@@ -647,23 +651,41 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 // ---------------------------------------------------------------------------------------------
 
 // queue mark + insert for a batch that is already in device memory
-// the equal-length level-1 kernel applies when every read of the batch is L bases long, nothing is trimmed
-// (L <= maxReadLen), a read has at least 64 windows (so that a tile's byte range fits its LDS image) and
-// the reads lie back to back from offset 0 (n_bases == n_reads * L)
-static bool uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t n_reads, uint64_t n_bases, int has_long)
+// The lane-per-chunk-of-valid-windows level-1 kernel (k_extract_scatter_uniform) applies when nothing is
+// trimmed (longest read <= maxReadLen), the longest read has at least 64 windows (a tile's byte range
+// must fit its LDS image) and either
+//   * every read has that length and they lie back to back from offset 0 (EQUAL), or
+//   * lengths differ, but giving every read the lane count of the longest one still needs fewer lane
+//     slots than the flat kernel has positions (RAGGED: reads mostly full length, some shorter).
+// Returns 0 = flat kernel, 1 = equal, 2 = ragged; fills U.
+static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_max, uint64_t n_reads, uint64_t n_bases, int has_long,
+                        UniformGeom &U, bool &c15)
 {
 	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
 	static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-	if (off || dbg_mode || has_long || uniform_len <= 0) return false;
-	const uint64_t L = (uint64_t)uniform_len, k = (uint64_t)h->cfg.kmer_size;
-	if (L > (uint64_t)h->cfg.max_read_len || L < k + 63 || L >= (1ull << 24)) return false;
-	const uint64_t Q = (L - k + 1 + 14) / 15; // the larger of the two lane counts per read (15 or 16 windows per lane)
-	return Q < 2048 && n_bases == n_reads * L && n_reads * Q < (1ull << 32);
+	if (off || dbg_mode || has_long || n_reads == 0) return 0;
+	const uint64_t L = uniform_len > 0 ? (uint64_t)uniform_len : len_max, k = (uint64_t)h->cfg.kmer_size;
+	if (L > (uint64_t)h->cfg.max_read_len || L < k + 63 || L >= (1ull << 24)) return 0;
+	const uint32_t W = (uint32_t)(L - k + 1);
+	// 16 or 15 windows per lane, whichever leaves fewer empty slots at the end of a full-length read (W = 120: 15 -> none)
+	const uint32_t q16 = (W + 15u) / 16u, q15 = (W + 14u) / 15u;
+	c15 = q15 * 15u - W < q16 * 16u - W;
+	const uint64_t Q = c15 ? q15 : q16, C = c15 ? 15 : 16;
+	if (Q >= 2048 || n_reads * Q >= (1ull << 32)) return 0;
+	if ((1024 / Q + 2) * L + 96 > (uint64_t)kPkWords * 16) return 0; // bytes a tile of 1024 lanes can touch
+	U.L = (uint32_t)L;
+	U.W = W;
+	U.Q = (uint32_t)Q;
+	U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
+	U.n_lanes = n_reads * Q;
+	if (uniform_len > 0) return n_bases == n_reads * L ? 1 : 0;
+	return (double)(n_reads * Q * C) <= 0.93 * (double)n_bases ? 2 : 0;
 }
 
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
-                        int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */)
+                        int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */,
+                        uint64_t len_max = 0 /* longest read of the batch (with uniform_len >= 0) */)
 {
 	if (n_reads == 0) return DBGK_OK;
 	if (h->seed) has_long = 1; // the dead bitmap carries the 'N' positions
@@ -686,13 +708,19 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, 20, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (has_long < 0) has_long = h->h_ctr->any_dead ? 1 : 0;
-		if (uniform_len < 0) uniform_len = ~h->h_ctr->len_min_inv == h->h_ctr->len_max ? (int64_t)h->h_ctr->len_max : 0;
+		if (uniform_len < 0) {
+			uniform_len = ~h->h_ctr->len_min_inv == h->h_ctr->len_max ? (int64_t)h->h_ctr->len_max : 0;
+			len_max = h->h_ctr->len_max;
+		}
 	}
 	const uint64_t id_base = h->total_reads; // contig index of the batch's first sequence (SEEDIDX)
 	h->total_reads += n_reads;
 	if (n_bases == 0) return DBGK_OK;
 
 	ReadBatch rb{d_bases, n_bases, d_start, has_long ? d_dead : nullptr, h->cfg.kmer_size};
+	UniformGeom U{};
+	bool c15 = false;
+	int umode = 0;
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
@@ -703,29 +731,23 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
-	} else if (h->part && uniform_mode(h, uniform_len, n_reads, n_bases, has_long)) {
-		// every read of the batch has the same length: lanes are mapped to chunks of valid windows
-		UniformGeom U;
-		U.L = (uint32_t)uniform_len;
-		U.W = U.L - (uint32_t)h->cfg.kmer_size + 1u;
-		// 16 or 15 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: 15 -> none)
-		const uint32_t q16 = (U.W + 15u) / 16u, q15 = (U.W + 14u) / 15u;
-		const bool c15 = q15 * 15u - U.W < q16 * 16u - U.W;
-		U.Q = c15 ? q15 : q16;
-		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
-		U.n_lanes = n_reads * U.Q;
+	} else if (h->part && (umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15)) != 0) {
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
-		const bool wide = h->geom.size >= (1ull << 31);
-		if (wide && c15)
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true, 15>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
-		else if (wide)
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, true, 16>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
-		else if (c15)
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false, 15>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
-		else
-			hipLaunchKernelGGL((k_extract_scatter_uniform<0, false, 16>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, h->geom, h->store, h->d_ctr);
+		const bool wide = h->geom.size >= (1ull << 31), ragged = umode == 2;
+#define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
+	                   d_offsets, h->geom, h->store, h->d_ctr)
+		if (wide && c15 && ragged) DBGK_LAUNCH_UNIFORM(true, 15, true);
+		else if (wide && c15) DBGK_LAUNCH_UNIFORM(true, 15, false);
+		else if (wide && ragged) DBGK_LAUNCH_UNIFORM(true, 16, true);
+		else if (wide) DBGK_LAUNCH_UNIFORM(true, 16, false);
+		else if (c15 && ragged) DBGK_LAUNCH_UNIFORM(false, 15, true);
+		else if (c15) DBGK_LAUNCH_UNIFORM(false, 15, false);
+		else if (ragged) DBGK_LAUNCH_UNIFORM(false, 16, true);
+		else DBGK_LAUNCH_UNIFORM(false, 16, false);
+#undef DBGK_LAUNCH_UNIFORM
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
@@ -828,17 +850,19 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 		if (nb) staged_copy(s.h_bases, bases + base0, nb, copiers);
 		int has_long = 0;
 		int64_t uniform_len = nr ? (int64_t)(offsets[r0 + 1] - offsets[r0]) : 0;
+		uint64_t len_max = 0;
 		for (uint64_t i = 0; i <= nr; i++) {
 			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
 			s.h_offsets[i] = offsets[r0 + i] - base0;
 			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
 			if (i && (int64_t)(s.h_offsets[i] - s.h_offsets[i - 1]) != uniform_len) uniform_len = 0;
+			if (i) len_max = std::max<uint64_t>(len_max, s.h_offsets[i] - s.h_offsets[i - 1]);
 			if (h->seed && i && s.h_offsets[i] - s.h_offsets[i - 1] >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
 		}
 		for (auto &t : copiers) t.join();
 		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
-		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len);
+		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(s.done, h->stream));
 		s.busy = true;

@@ -623,8 +623,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 // to 2 bits per base cooperatively into LDS first (one aligned 16-byte load per lane, as before) and each
 // lane funnels its own window out of five packed words; the boundary predicates are arithmetic.
 struct UniformGeom {
-	uint32_t L;          // length of every read of the batch, k <= L <= maxReadLen (no trimming in this mode)
-	uint32_t W;          // windows per read = L - k + 1, >= 64
+	uint32_t L;          // length of every read of the batch (RAGGED: of the longest), k + 63 <= L <= maxReadLen (no trimming in this mode)
+	uint32_t W;          // windows of a read of length L = L - k + 1, >= 64
 	uint32_t Q;          // lanes per read = ceil(W / C), < 2048; C = 16 or 15 windows per lane, whichever wastes fewer slots
 	uint32_t qmagic;     // ceil(2^22 / Q): (x * qmagic) >> 22 == x / Q for x < 2048 + Q
 	uint64_t n_lanes;    // n_reads * Q
@@ -660,9 +660,13 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 	}
 }
 
-template <int DBG = 0, bool WIDE_D = false, int C = 16>
-__global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, PartGeom G, PartStore P,
-                                                                         Counters *__restrict__ ctr)
+// RAGGED: the reads are NOT all L long.  Every read still gets Q = ceil(W_max / C) lanes (W_max from the
+// longest read of the batch, L holds its length), a read's own offset and length come from `offsets`, and
+// the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
+// length -- the host compares n_reads * Q * C lane slots with the n_bases positions of the flat kernel.
+template <int DBG = 0, bool WIDE_D = false, int C = 16, bool RAGGED = false>
+__global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
+                                                                         PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	UniformLds &UL = *reinterpret_cast<UniformLds *>(lds_raw);
@@ -680,54 +684,65 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	uint64_t r0 = ((uint64_t)blockIdx.x * kL1Threads) / U.Q;
 	uint32_t c0 = (uint32_t)((uint64_t)blockIdx.x * kL1Threads - r0 * U.Q);
 
-	// first byte (16-aligned) and number of 16-byte blocks of the range the tile starting at (rr, cc) touches
-	auto tile_range = [&](uint64_t tile, uint64_t rr, uint32_t cc, uint64_t &B0) -> uint32_t {
-		const uint64_t p_first = rr * U.L + (uint32_t)C * cc;
-		B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
-		const uint64_t lane_last = min((tile + 1u) * kL1Threads, U.n_lanes) - 1u;
-		const uint32_t x = cc + (uint32_t)(lane_last - tile * kL1Threads);
-		const uint32_t dr = (x * U.qmagic) >> 22;
-		const uint64_t p_last = (rr + dr) * U.L + (uint32_t)C * (x - dr * U.Q);
-		uint64_t end = p_last + 16u + k + 2u;
-		end = min(end, (rb.n_bases + 15u) & ~15ull);
-		return end > B0 ? (uint32_t)((end - B0 + 15u) >> 4) : 0u;
-	};
+	auto read_start = [&](uint64_t r) -> uint64_t { return RAGGED ? offsets[r] : r * U.L; };
+	// everything a lane needs of a tile, requested one tile ahead: its 16-byte blocks of the tile's byte
+	// range (block t and block t + 1024), where that range starts, and the lane's own read
 	struct RawU {
 		uint4 a, b;
+		uint64_t B0;       // first byte of the tile's range (16-aligned)
+		uint64_t p;        // flat position of the lane's first window
+		uint32_t n_blocks; // 16-byte blocks of the range
+		uint32_t cc;       // the lane's chunk inside its read
+		uint32_t W;        // windows of the lane's read (0: lane beyond the batch or read shorter than k)
 	};
-	auto fetch = [&](uint64_t tile, uint64_t rr, uint32_t cc) {
+	auto fetch = [&](uint64_t tile, uint64_t rr, uint32_t c_first) {
 		RawU raw;
 		raw.a = raw.b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+		raw.B0 = raw.p = 0;
+		raw.n_blocks = raw.cc = raw.W = 0;
 		if (tile >= n_tiles) return raw;
-		uint64_t B0;
-		const uint32_t n_blocks = tile_range(tile, rr, cc, B0);
 		const uint32_t t = fresh_tid();
-		if (t < n_blocks) raw.a = load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + t);
-		if (t + kL1Threads < n_blocks) raw.b = load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + t + kL1Threads);
+		// the tile's byte range: from one base before its first lane's first window to the end of its last lane's window
+		const uint64_t p_first = read_start(rr) + (uint32_t)C * c_first;
+		raw.B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
+		const uint64_t lane_last = min((tile + 1u) * kL1Threads, U.n_lanes) - 1u;
+		const uint32_t xl = c_first + (uint32_t)(lane_last - tile * kL1Threads);
+		const uint32_t drl = (xl * U.qmagic) >> 22;
+		uint64_t end = read_start(rr + drl) + (uint32_t)C * (xl - drl * U.Q) + (uint32_t)C + k + 2u;
+		end = min(end, (rb.n_bases + 15u) & ~15ull);
+		raw.n_blocks = end > raw.B0 ? min((uint32_t)((end - raw.B0 + 15u) >> 4), (uint32_t)kPkWords) : 0u;
+		if (t < raw.n_blocks) raw.a = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t);
+		if (t + kL1Threads < raw.n_blocks) raw.b = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t + kL1Threads);
+		// this lane
+		const uint32_t x = c_first + t;
+		const uint32_t dr = (x * U.qmagic) >> 22;
+		raw.cc = x - dr * U.Q;
+		if (tile * kL1Threads + t < U.n_lanes) {
+			const uint64_t r = rr + dr;
+			const uint64_t s = read_start(r);
+			const uint64_t len = RAGGED ? offsets[r + 1] - s : (uint64_t)U.L;
+			raw.p = s + (uint32_t)C * raw.cc;
+			raw.W = len >= k ? (uint32_t)(len - k + 1u) : 0u;
+		}
 		return raw;
 	};
 
 	RawU raw = fetch(blockIdx.x, r0, c0);
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t tid = fresh_tid();
-		uint64_t B0;
-		const uint32_t n_blocks = tile_range(tile, r0, c0, B0);
 		// pack the tile's bytes (block tid, block tid + 1024) into LDS, 16 bases per word
-		if (tid < n_blocks) UL.pk[tid] = pack16_ascii(raw.a);
-		if (tid + kL1Threads < n_blocks && tid + kL1Threads < (uint32_t)kPkWords) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
+		if (tid < raw.n_blocks) UL.pk[tid] = pack16_ascii(raw.a);
+		if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
 		uint32_t bkt[16];
 		L.hist[tid] = 0;
 		lds_barrier();
-		// this lane's chunk
-		const uint64_t lane_g = tile * kL1Threads + tid;
-		const uint32_t x = c0 + tid;
-		const uint32_t dr = (x * U.qmagic) >> 22;
-		const uint32_t cc = x - dr * U.Q;
-		const uint64_t p = (r0 + dr) * U.L + (uint32_t)C * cc;   // flat position of the lane's first window
+		const uint64_t p = raw.p;                        // flat position of the lane's first window
 		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
+		const uint32_t first_w = (uint32_t)C * raw.cc;   // index of the lane's first window inside its read
+		const bool live = first_w < raw.W;               // (raw.W == 0 for lanes beyond the batch)
 		Chunk16 c;
 		{
-			const uint32_t rel = lane_g < U.n_lanes ? (uint32_t)(s0 - B0) : 0u;
+			const uint32_t rel = live ? (uint32_t)(s0 - raw.B0) : 0u;
 			const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u), sh = 2u * (rel & 15u);
 			const uint32_t x0 = UL.pk[d], x1 = UL.pk[d + 1], x2 = UL.pk[d + 2], x3 = UL.pk[d + 3], x4 = UL.pk[d + 4];
 			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
@@ -740,12 +755,11 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
 			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
 			c.nb = funnel_left(ya, yb, wsh);
-			const uint32_t first_w = (uint32_t)C * cc; // index of the lane's first window inside its read
-			const uint32_t nv = (lane_g < U.n_lanes && first_w < U.W) ? min((uint32_t)C, U.W - first_w) : 0u;
-			const uint32_t nr = (lane_g < U.n_lanes && first_w + 1u < U.W) ? min((uint32_t)C, U.W - 1u - first_w) : 0u;
+			const uint32_t nv = live ? min((uint32_t)C, raw.W - first_w) : 0u;
+			const uint32_t nr = (live && first_w + 1u < raw.W) ? min((uint32_t)C, raw.W - 1u - first_w) : 0u;
 			c.valid = (1u << nv) - 1u;
-			c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
-			c.has_l = cc ? 0xFFFFu : 0xFFFEu;   // its first window no left one
+			c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
+			c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
 		}
 		const bool zero_seen = l1_positions<WIDE_D, C>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);

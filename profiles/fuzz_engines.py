@@ -18,14 +18,17 @@ from dbg_assembly_amd import capi  # noqa: E402
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
 
 
-def make_reads(rng, n, G, L, n_rate, repeat, uniform=False):
+def make_reads(rng, n, G, L, n_rate, repeat, uniform=False, nearly=False):
     g = "".join(rng.choice("ACGT") for _ in range(G))
     if repeat:
         unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40)))
         g = g[:G // 2] + unit * (G // (2 * len(unit)) + 1)
     out = []
     for _ in range(n):
-        ln = L if (uniform or rng.random() < 0.7) else rng.randint(0, L + 200)
+        if nearly:   # mostly full length, some shorter, none longer: the ragged form of the lane-per-chunk level-1 kernel
+            ln = L if rng.random() < 0.85 else rng.randint(max(0, L - 60), L)
+        else:
+            ln = L if (uniform or rng.random() < 0.7) else rng.randint(0, L + 200)
         ln = min(ln, len(g))
         s = rng.randint(0, len(g) - ln)
         r = list(g[s:s + ln])
@@ -40,7 +43,10 @@ def make_reads(rng, n, G, L, n_rate, repeat, uniform=False):
             elif x < 0.02 + n_rate:
                 r[j] = r[j].lower()
         out.append("".join(r).encode())
-    if rng.random() < 0.5:
+    if nearly:
+        if rng.random() < 0.5:
+            out += [b"A" * L] * rng.randint(1, 400) + [b"T" * rng.randint(max(1, L - 50), L)] * rng.randint(1, 50)
+    elif rng.random() < 0.5:
         if uniform:  # equal-length batches take the partition engine's equal-length level-1 kernel
             ln = len(out[0]) if out else L
             out = [r for r in out if len(r) == ln]
@@ -159,8 +165,9 @@ def main():
         k = rng.choice([31, 31, 32, 27, 21, 17, 12, 5, 1])
         L = rng.choice([150, 100, 36, 250, 400])
         max_read_len = rng.choice([250, 250, 100, 1000000])
+        shape = rng.random()
         reads = make_reads(rng, rng.randint(1, 6000), rng.randint(max(L, 50), 60000), L, rng.choice([0.0, 0.003, 0.05]), rng.random() < 0.3,
-                           uniform=rng.random() < 0.45)
+                           uniform=shape < 0.35, nearly=0.35 <= shape < 0.6)
         slots = rng.choice([1 << 26, 70_000_000, 100_000_007, 600_000_000, 2_200_000_000, 4_200_000_000])
         size = capi.find_next_prime_ref(slots)
         with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(3_000_000), engine=capi.ENGINE_DIRECT, max_read_len=max_read_len) as g:
