@@ -403,7 +403,7 @@ __device__ __forceinline__ RawChunk load_raw(const ReadBatch &rb, uint64_t chunk
 		r.a0 = *reinterpret_cast<const uint4 *>(rb.bases + chunk * 16u);
 		if (lane < 2u) r.halo = *reinterpret_cast<const uint4 *>(rb.bases + halo_chunk * 16u);
 	}
-	if (lane == 0u && chunk > 0u && (!GUARDED || chunk <= n_chunks)) r.prevb = (uint8_t)rb.bases[chunk * 16u - 1u];
+	if (lane == 0u && chunk > 0u && (!GUARDED || chunk * 16u - 1u < rb.n_bases)) r.prevb = (uint8_t)rb.bases[chunk * 16u - 1u];
 	const uint64_t p0 = chunk * 16u;
 	const uint64_t wi = p0 >> 5; // the bitmaps are padded by 4 words, safe for every chunk < n_chunks
 	r.s0 = r.s1 = r.s2 = r.d0 = r.d1 = r.d2 = 0u;
@@ -588,7 +588,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 		Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
 		if (chunk >= n_chunks) c.valid = 0u;
 		const bool zero_seen = l1_positions<WIDE_D>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
-		if (zero_seen) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
+		if (zero_seen && chunk < n_chunks) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
+			// (lanes past the last chunk hold 'A' padding, i.e. key 0 everywhere: nothing of theirs is valid)
 			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
 #pragma unroll 1
 			for (uint32_t i = 0; i < 16; i++) {
@@ -703,7 +704,9 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		if (tile >= n_tiles) return raw;
 		const uint32_t t = fresh_tid();
 		// the tile's byte range: from one base before its first lane's first window to the end of its last lane's window
-		const uint64_t p_first = read_start(rr) + (uint32_t)C * c_first;
+		// RAGGED: a tile may start in the empty tail lanes of a read shorter than C * c_first; the range then
+		// starts at the next read (the first live lane's window), never past it
+		const uint64_t p_first = RAGGED ? min(offsets[rr] + (uint32_t)C * c_first, offsets[rr + 1]) : read_start(rr) + (uint32_t)C * c_first;
 		raw.B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
 		const uint64_t lane_last = min((tile + 1u) * kL1Threads, U.n_lanes) - 1u;
 		const uint32_t xl = c_first + (uint32_t)(lane_last - tile * kL1Threads);

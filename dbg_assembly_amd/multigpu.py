@@ -258,14 +258,14 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     st = g.finalize()
     local = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers))
 
-    # 4. hand-offs
-    p_out, n_out = g.shard_outgoing()
+    # 4. hand-offs.  Overflow observations first: merging them can push further nodes off the end of a
+    # shard, so the outgoing lists are read only afterwards.
     p_ovf, n_ovf = g.shard_overflow()
-    sizes = torch.tensor([n_out, n_ovf], dtype=torch.int64, device=device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    all_sizes = torch.stack(all_sizes).cpu().numpy()
-    max_out, max_ovf = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    sizes = torch.tensor([n_ovf], dtype=torch.int64, device=device)
+    ovf_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(ovf_sizes, sizes, group=group)
+    ovf_sizes = torch.stack(ovf_sizes).cpu().numpy()[:, 0]
+    max_ovf = int(ovf_sizes.max())
     if max_ovf:
         mine = torch.zeros(max_ovf * NODE_BYTES, dtype=torch.uint8, device=device)
         if n_ovf:
@@ -275,9 +275,15 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
         if on_gpu:
             torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
         for src in range(world):
-            if all_sizes[src, 1]:
-                g.shard_merge(lists[src].data_ptr(), int(all_sizes[src, 1]), is_triple=True)
+            if ovf_sizes[src]:
+                g.shard_merge(lists[src].data_ptr(), int(ovf_sizes[src]), is_triple=True)
         g.sync()
+    p_out, n_out = g.shard_outgoing()
+    sizes = torch.tensor([n_out], dtype=torch.int64, device=device)
+    out_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(out_sizes, sizes, group=group)
+    out_sizes = torch.stack(out_sizes).cpu().numpy()[:, 0]
+    max_out = int(out_sizes.max())
     if max_out:
         mine = torch.zeros(max_out * NODE_BYTES, dtype=torch.uint8, device=device)
         if n_out:
@@ -287,8 +293,8 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
         if on_gpu:
             torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
         prev = (rank - 1) % world
-        if all_sizes[prev, 0]:
-            g.shard_merge(lists[prev].data_ptr(), int(all_sizes[prev, 0]), from_previous_shard=True)
+        if out_sizes[prev]:
+            g.shard_merge(lists[prev].data_ptr(), int(out_sizes[prev]), from_previous_shard=True)
             g.sync()
             _, n_again = g.shard_outgoing()
             if n_again != n_out:
@@ -309,4 +315,4 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global,
-            "handed_over_nodes": int(all_sizes[:, 0].sum()), "overflow_observations": int(all_sizes[:, 1].sum())}
+            "handed_over_nodes": int(out_sizes.sum()), "overflow_observations": int(ovf_sizes.sum())}

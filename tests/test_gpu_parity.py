@@ -338,6 +338,39 @@ def test_full_size_direct_vs_partition_digest(capi):
     assert res[0] == res[1]
 
 
+@pytest.mark.parametrize("L,k", [(100, 31), (130, 31), (110, 17)])
+def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle, L, k):
+    """RAGGED form of the lane-per-chunk level-1 kernel with a lane count per read (Q) that does not divide
+    the 1024 lanes of a tile, and some reads much shorter than C * (Q - 1): a tile can then start in the
+    empty tail lanes of a short read, and its byte range must start at the NEXT read (round-1 advisor
+    finding: the range started past it and live lanes decoded stale LDS words).  ~93 % full-length reads
+    keep the batch inside the ragged gate; checked against the oracle and the DIRECT engine."""
+    rng = np.random.default_rng(L * 100 + k)
+    n_reads, G = 200000, 400000
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    lens = np.full(n_reads, L, dtype=np.int64)
+    short = rng.random(n_reads) < 0.07
+    lens[short] = rng.integers(k, 2 * k, int(short.sum()))
+    starts = rng.integers(0, G - L, n_reads)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    idx = np.repeat(starts - offsets[:-1].astype(np.int64), lens) + np.arange(int(offsets[-1]))
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[idx]].copy()
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    res = []
+    for engine in (capi.ENGINE_DIRECT, capi.ENGINE_PARTITION):
+        with capi.Graph(k=k, table_slots=size, engine=engine, expected_kmers=int(offsets[-1]), max_batch_bases=int(offsets[-1]) + 4096) as g:
+            g.push_reads(bases, offsets)   # ONE batch: the tiles of interest need many reads in a row
+            st = g.finalize()
+            if engine == capi.ENGINE_PARTITION:
+                assert g.timings().uniform_launches == 1, "the batch was expected to take the ragged lane-per-chunk kernel"
+            res.append((int(st.count), int(st.stored_kmers), g.digest()))
+            nodes = g.export_sorted()
+    assert res[0] == res[1]
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=k, init_hash_size=0.02, threads=1)
+    assert res[1][0] == ref.count and np.array_equal(nodes, ref.nodes)
+
+
 # ------------------------------------------------------------------------------------------------
 # sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
 # device copies.  Validates slot-range ownership end to end on real hardware.
