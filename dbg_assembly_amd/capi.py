@@ -85,6 +85,8 @@ SYMBOLS = [
     ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_sync", _i, [_vp]),
     ("dbgk_resize_table", _i, [_vp, _u64]),
+    ("dbgk_flush", _i, [_vp]),
+    ("dbgk_store_room", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("dbgk_copy_nodes_peer", _i, [_vp, _vp, _vp, _vp, _u64]),
     ("dbgk_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
@@ -228,6 +230,14 @@ class Graph:
     def reset(self):
         _chk(lib().dbgk_reset(self._h), "dbgk_reset")
         self.stats = None
+
+    def flush(self):
+        _chk(lib().dbgk_flush(self._h), "dbgk_flush")
+
+    def store_room(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(lib().dbgk_store_room(self._h, C.byref(a), C.byref(b)), "dbgk_store_room")
+        return a.value, b.value
 
     def resize_table(self, new_slots):
         _chk(lib().dbgk_resize_table(self._h, new_slots), "dbgk_resize_table")

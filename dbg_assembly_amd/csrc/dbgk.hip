@@ -120,6 +120,9 @@ struct dbgk_handle {
 	uint32_t cursors_used = 0;
 	TimedSpan wall_span;
 	bool zero_pending = false;    // table content is stale and must be zeroed before a direct-path write
+	bool incr = false;            // the table holds nodes of an earlier flush: the next region build loads them back (INCR)
+	uint64_t pending_kmers = 0;   // upper bound of the k-mer occurrences sitting in the record store
+	uint64_t store_capacity = 0;  // occurrences the record store is sized for (expected_kmers)
 	PartGeom geom;
 	PartStore store;
 	uint32_t *tile_prefix = nullptr; // [n_ranks * B + 1] level-2 tile plan
@@ -222,6 +225,20 @@ extern "C" const char *dbgk_strerror(int status)
 	}
 }
 
+// record stores of the PARTITION engine (re-allocated when the table is resized: the geometry changes)
+static void free_partition_stores(dbgk_handle *h)
+{
+	for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
+	                (void *)h->store.spill, (void *)h->store.ovf_n, (void *)h->tile_prefix, (void *)h->store.hh, (void *)h->region_cursor,
+	                (void *)h->inbox, (void *)h->inbox_cnt, (void *)h->store.outgoing, (void *)h->store.outgoing_n})
+		if (p) (void)hipFree(p);
+	memset(&h->store, 0, sizeof h->store);
+	h->tile_prefix = nullptr;
+	h->region_cursor = nullptr;
+	h->inbox = nullptr;
+	h->inbox_cnt = nullptr;
+}
+
 static void free_handle(dbgk_handle *h)
 {
 	if (!h) return;
@@ -245,19 +262,10 @@ static void free_handle(dbgk_handle *h)
 	if (h->dev_start) (void)hipFree(h->dev_start);
 	if (h->dev_dead) (void)hipFree(h->dev_dead);
 	if (h->part) {
-		for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
-		                (void *)h->store.spill, (void *)h->store.ovf_n})
-			if (p) (void)hipFree(p);
-		if (h->tile_prefix) (void)hipFree(h->tile_prefix);
-		if (h->store.hh) (void)hipFree(h->store.hh);
-		if (h->region_cursor) (void)hipFree(h->region_cursor);
+		free_partition_stores(h);
 		for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
 		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
 		if (h->stream2) (void)hipStreamDestroy(h->stream2);
-		if (h->inbox) (void)hipFree(h->inbox);
-		if (h->inbox_cnt) (void)hipFree(h->inbox_cnt);
-		if (h->store.outgoing) (void)hipFree(h->store.outgoing);
-		if (h->store.outgoing_n) (void)hipFree(h->store.outgoing_n);
 	}
 	if (h->table) (void)hipFree(h->table);
 	if (h->counts) (void)hipFree(h->counts);
@@ -275,6 +283,27 @@ static int zero_table_now(dbgk_handle *h)
 	return DBGK_OK;
 }
 
+// empty the record stores of the PARTITION engine (the table and the counters stay)
+static int clear_record_store(dbgk_handle *h)
+{
+	if (h->chunks_used > 0 && h->stream2) { // region builds on the second stream must not race the memsets
+		HIPCHK(hipEventRecord(h->join_ev, h->stream2));
+		HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
+	}
+	HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
+	HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
+	HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
+	if (h->store.hh) HIPCHK(hipMemsetAsync(h->store.hh, 0, h->store.hh_size * sizeof(Node), h->stream));
+	HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
+	h->part_built = false;
+	h->exchanged = false;
+	h->part_planned = false;
+	h->next_bucket = 0;
+	h->chunks_used = 0;
+	h->pending_kmers = 0;
+	return DBGK_OK;
+}
+
 static int reset_state(dbgk_handle *h)
 {
 	if (h->kfreq) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
@@ -283,20 +312,9 @@ static int reset_state(dbgk_handle *h)
 		// the region build of finalize overwrites every slot, so the 16 B/slot memset is only needed
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
-		h->part_built = false;
-		if (h->chunks_used > 0 && h->stream2) { // a ranged finalize was abandoned: its builds must not race the reset
-			HIPCHK(hipEventRecord(h->join_ev, h->stream2));
-			HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
-		}
-		HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
-		HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
-		HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
-		if (h->store.hh) HIPCHK(hipMemsetAsync(h->store.hh, 0, h->store.hh_size * sizeof(Node), h->stream));
-		HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
-		h->exchanged = false;
-		h->part_planned = false;
-		h->next_bucket = 0;
-		h->chunks_used = 0;
+		h->incr = false;
+		int rc = clear_record_store(h);
+		if (rc) return rc;
 	} else {
 		int rc = zero_table_now(h);
 		if (rc) return rc;
@@ -421,6 +439,7 @@ static int setup_partition(dbgk_handle *h)
 	}
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
+	h->store_capacity = expected;
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
@@ -442,6 +461,8 @@ static int setup_partition(dbgk_handle *h)
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
@@ -585,6 +606,85 @@ extern "C" int dbgk_sync(dbgk_handle *h)
 
 extern "C" void *dbgk_stream(dbgk_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+static int build_from_records(dbgk_handle *h);
+static int plan_partition(dbgk_handle *h);
+static int setup_partition(dbgk_handle *h);
+
+// PARTITION engine, streaming use: records -> table now (regions that already hold nodes are loaded back
+// into LDS first), record store emptied.
+static int flush_records(dbgk_handle *h)
+{
+	if (!h->part || h->finalized) return DBGK_OK;
+	if (h->sharded) {
+		g_last_error = "dbgk_flush: a sharded handle is flushed by its communicator (dbgk_comm_flush)";
+		return DBGK_ERR_STATE;
+	}
+	if (h->pending_kmers == 0) return DBGK_OK;
+	int rc = build_from_records(h);
+	if (rc) return rc;
+	h->incr = true;
+	return clear_record_store(h);
+}
+
+// the PARTITION engine's bucket geometry is a function of the table size: a resize re-seats the nodes
+// (k_rehash, global atomics) and re-plans / re-allocates the record stores.  Pending records are flushed first.
+static int resize_partition_table(dbgk_handle *h, uint64_t new_slots)
+{
+	if (h->kfreq || h->sharded) {
+		g_last_error = "dbgk_resize_table: not available for KFREQ and sharded handles";
+		return DBGK_ERR_STATE;
+	}
+	int rc = flush_records(h);
+	if (rc) return rc;
+	dbgk_handle probe_cfg;           // feasibility first: nothing is touched if the new size does not fit the engine
+	probe_cfg.cfg = h->cfg;
+	probe_cfg.size = new_slots;
+	probe_cfg.magic = make_mod_magic(new_slots);
+	rc = plan_partition(&probe_cfg);
+	if (rc) return rc;
+	if (!probe_cfg.part) {
+		g_last_error = "dbgk_resize_table: the new size does not fit the PARTITION engine's geometry";
+		return DBGK_ERR_ARG;
+	}
+	Node *fresh = nullptr;
+	if (hipMalloc(&fresh, new_slots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	const TableRef dst{fresh, new_slots, make_mod_magic(new_slots)};
+	if (h->incr) { // the old table holds nodes
+		hipError_t e = hipMemsetAsync(fresh, 0, new_slots * sizeof(Node), h->stream);
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, dst, h->d_ctr,
+			                   (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+		if (e != hipSuccess) {
+			(void)hipFree(fresh);
+			return hip_fail(e, "resize_table(partition)", __LINE__);
+		}
+		if (h->h_ctr->error & 1u) {
+			(void)hipFree(fresh);
+			HIPCHK(hipMemsetAsync(&h->d_ctr->error, 0, sizeof(unsigned int), h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+			return DBGK_ERR_TABLE_FULL;
+		}
+	}
+	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->stream2) HIPCHK(hipStreamSynchronize(h->stream2));
+	(void)hipFree(h->table);
+	h->table = fresh;
+	h->size = new_slots;
+	h->magic = dst.magic;
+	h->cfg.table_slots = new_slots;
+	free_partition_stores(h);
+	rc = plan_partition(h);
+	if (rc == DBGK_OK && !h->part) rc = DBGK_ERR_STATE;
+	if (rc == DBGK_OK) rc = setup_partition(h);
+	if (rc) return rc;
+	h->zero_pending = !h->incr; // nothing built yet: the first region build writes every slot
+	return clear_record_store(h);
+}
+
 extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 {
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
@@ -594,10 +694,7 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 	rc = dbgk_sync(h);
 	if (rc) return rc;
 	if (new_slots == h->size) return DBGK_OK;
-	if (h->part) {
-		g_last_error = "dbgk_resize_table: the PARTITION engine's geometry is fixed at create";
-		return DBGK_ERR_STATE;
-	}
+	if (h->part) return resize_partition_table(h, new_slots);
 	Node *fresh = nullptr;
 	unsigned long long *fresh_first = nullptr;
 	if (hipMalloc(&fresh, new_slots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
@@ -827,12 +924,32 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 	if (h->seed && h->total_reads + n_reads > 0xFFFFFFFFull) return DBGK_ERR_ARG; // id is a 32-bit field
 	int rc = use_device(h);
 	if (rc) return rc;
+	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
+	auto windows_of = [&](uint64_t len) { const uint64_t rl = len > max_len ? max_len : len; return rl >= K ? rl - K + 1 : 0ull; };
+	// PARTITION engine: the record store holds store_capacity occurrences; a batch that would not fit is
+	// preceded by a flush (records -> table, dbgk_flush).  Batches are cut to the room that is left only when
+	// the store is at least one staging batch large; a smaller store (expected_kmers a gross under-estimate)
+	// takes whole batches and sends the excess through its overflow lists as before.
+	const bool streaming = h->part && !h->sharded;
+	const bool cut_to_room = streaming && h->store_capacity >= h->cap_bases;
 	uint64_t r0 = 0;
 	while (r0 < n_reads) {
-		// largest [r0, r1) that fits the staging buffers
-		uint64_t r1 = r0;
+		// largest [r0, r1) that fits the staging buffers (and the record store)
+		uint64_t r1 = r0, batch_windows = 0;
 		const uint64_t base0 = offsets[r0];
-		while (r1 < n_reads && (r1 - r0) < h->cap_reads && offsets[r1 + 1] - base0 <= h->cap_bases) r1++;
+		const uint64_t room = h->store_capacity > h->pending_kmers ? h->store_capacity - h->pending_kmers : 0;
+		while (r1 < n_reads && (r1 - r0) < h->cap_reads && offsets[r1 + 1] - base0 <= h->cap_bases) {
+			if (offsets[r1 + 1] < offsets[r1]) return DBGK_ERR_ARG;
+			const uint64_t w = windows_of(offsets[r1 + 1] - offsets[r1]);
+			if (cut_to_room && batch_windows + w > room && (r1 > r0 || h->pending_kmers > 0)) break;
+			batch_windows += w;
+			r1++;
+		}
+		if (streaming && h->pending_kmers > 0 && (r1 == r0 || (!cut_to_room && h->pending_kmers + batch_windows > h->store_capacity))) {
+			rc = flush_records(h);
+			if (rc) return rc;
+			if (r1 == r0) continue; // cut again with the whole store free
+		}
 		if (r1 == r0) return DBGK_ERR_ARG; // a single read larger than max_batch_bases
 		StageSlot &s = h->slots[h->next_slot];
 		rc = ensure_slot(h, s);
@@ -864,6 +981,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
 		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
 		if (rc) return rc;
+		h->pending_kmers += batch_windows;
 		HIPCHK(hipEventRecord(s.done, h->stream));
 		s.busy = true;
 		h->next_slot ^= 1;
@@ -891,7 +1009,32 @@ extern "C" int dbgk_push_reads_device(dbgk_handle *h, const char *d_bases, const
 		if (hipMalloc(&h->dev_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
 		h->dev_bits_words = words;
 	}
-	return launch_batch(h, d_bases, d_offsets, n_reads, n_bases, h->dev_start, h->dev_dead, -1);
+	// the record store takes what it was sized for; the number of windows of a device batch is only known as
+	// an upper bound here (one per base)
+	if (h->part && !h->sharded && h->pending_kmers > 0 && h->pending_kmers + n_bases > h->store_capacity) {
+		rc = flush_records(h);
+		if (rc) return rc;
+	}
+	rc = launch_batch(h, d_bases, d_offsets, n_reads, n_bases, h->dev_start, h->dev_dead, -1);
+	if (rc == DBGK_OK) h->pending_kmers += n_bases;
+	return rc;
+}
+
+extern "C" int dbgk_flush(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	return flush_records(h);
+}
+
+extern "C" int dbgk_store_room(dbgk_handle *h, uint64_t *pending_kmers, uint64_t *capacity_kmers)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (pending_kmers) *pending_kmers = h->part ? h->pending_kmers : 0;
+	if (capacity_kmers) *capacity_kmers = h->part ? h->store_capacity : 0;
+	return DBGK_OK;
 }
 
 static int read_counters(dbgk_handle *h)
@@ -928,9 +1071,15 @@ template <int DBG>
 static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions, unsigned int *cursor)
 {
 	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 2u); // persistent: two 66-KiB workgroups fit a CU
-	if (h->kfreq)
+	if (h->kfreq && h->incr)
+		hipLaunchKernelGGL((k_build_regions<0, true, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
+		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
+	else if (h->kfreq)
 		hipLaunchKernelGGL((k_build_regions<0, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
 		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
+	else if (h->incr && DBG == 0)
+		hipLaunchKernelGGL((k_build_regions<0, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table,
+		                   h->d_ctr, first_region, n_regions, cursor);
 	else
 		hipLaunchKernelGGL(k_build_regions<DBG>, dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr,
 		                   first_region, n_regions, cursor);
@@ -1091,8 +1240,11 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 			g_last_error = "sharded handle: exchange the level-1 buckets (dbgk_shard_buffers) and call dbgk_shard_mark_exchanged first";
 			return DBGK_ERR_STATE;
 		}
-		rc = build_from_records(h);
-		if (rc) return rc;
+		if (!(h->incr && h->pending_kmers == 0 && !h->sharded)) { // (a flushed handle with nothing new: the table is complete)
+			rc = build_from_records(h);
+			if (rc) return rc;
+			h->pending_kmers = 0;
+		}
 	}
 	if (h->kfreq) {
 		unsigned long long *d_sum = nullptr, res[2] = {0, 0};
@@ -1632,10 +1784,10 @@ extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (n == 0) return DBGK_OK;
-	if (h->zero_pending) { // PARTITION handle used as a plain merge target: the region build will not run
-		rc = zero_table_now(h);
+	if (h->zero_pending) { // PARTITION handle used as a merge target before any region build: the table must be
+		rc = zero_table_now(h); // empty for the direct path; records pushed so far (or later) are built on top of it
 		if (rc) return rc;
-		h->part_built = true;
+		h->incr = true;
 	}
 	TimedSpan sp;
 	rc = span_begin(h, PH_FIXUP, sp);

@@ -913,7 +913,13 @@ struct BuildLds {
 // 3 = emit without recomputing the keys
 // KF: KFREQ through this engine -- there is no node table; `table` is the direct-addressed 4^k byte
 // table and an occupied LDS slot is emitted as counts[key] = its occurrence counter.
-template <int DBG = 0, bool KF = false>
+// INCR: the table already holds nodes (an earlier flush of a streaming build, dbgk_flush): before a region's
+// records are inserted its 4096 table slots are loaded back into the LDS image.  A node whose home slot lies
+// in the region gets the identity its records carry; a node that probed in from an earlier region (merged
+// there by k_merge_spill) is a foreign blocker: it keeps its slot, takes no record of this region (its
+// records go to its home region, run off that region's end again and are merged by k_merge_spill) and is
+// left untouched by the emit.  KF + INCR: counts[key] += the occurrences of this flush, saturating.
+template <int DBG = 0, bool KF = false, bool INCR = false>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
                                                                   Counters *__restrict__ ctr, uint32_t first_region, uint32_t n_regions,
                                                                   unsigned int *__restrict__ cursor)
@@ -950,6 +956,23 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		}
 	};
 
+	constexpr unsigned long long kForeign = 1ull << 63; // identity of a node that lives here but belongs to an earlier region
+	auto load_image = [&](uint32_t ff) { // INCR, graph tables only: the image is empty, fill it from the table
+		if (ff == kNone) return;
+		const uint64_t rbase = (uint64_t)ff << kRegionBits, rslot0 = G.slot_lo + rbase;
+		const uint32_t rlen = (uint32_t)((G.size - rslot0 < (uint64_t)kRegionSlots) ? G.size - rslot0 : kRegionSlots);
+		for (uint32_t i = fresh_tid(); i < rlen; i += kBuildThreads) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(&table[rbase + i]);
+			const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+			if (key == 0ull) continue;
+			uint64_t q;
+			const uint64_t home = fast_divmod(hash_code(key), G.magic, q);
+			const bool native = home >= rslot0 && home < rslot0 + rlen;
+			L.ident[i] = native ? ((q << G.r) | (home & ((1ull << G.r) - 1ull))) + 1ull : (kForeign | i);
+			L.links[i] = ((uint64_t)v.w << 32) | v.z;
+		}
+	};
+
 	for (int i = t; i < kRegionSlots + kSpillSlots; i += kBuildThreads) {
 		L.ident[i] = 0ull;
 		L.links[i] = 0ull;
@@ -957,6 +980,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	grab();
 	lds_barrier();
 	uint32_t f = __builtin_amdgcn_readfirstlane(L.next_region); // scalar: everything derived from it stays in SGPRs
+	if (INCR && !KF) load_image(f);
 	lds_barrier();
 	grab(); // the region after it
 	lds_barrier();
@@ -1037,16 +1061,22 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 				for (uint32_t i = t; i < region_len; i += kBuildThreads) {
 					const unsigned long long id = L.ident[i];
 					uint64_t key = 0ull, links = 0ull;
+					const bool foreign = INCR && !KF && (id & kForeign);
 					if (id) {
 						const uint64_t v = id - 1ull;
 						const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
-						key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
+						if (!foreign) key = (DBG == 3) ? v + slot : hash_code_inverse((v >> G.r) * G.size + slot);
 						links = L.links[i];
 						L.ident[i] = 0ull;
 						L.links[i] = 0ull;
 					}
 					if (KF) { // every key is aggregated in exactly one region: a plain byte store, nobody else writes it during the build
-						if (id) reinterpret_cast<uint8_t *>(table)[key] = (uint8_t)((uint32_t)links >> 24);
+						if (id) {
+							uint8_t *cell = reinterpret_cast<uint8_t *>(table) + key;
+							const uint32_t c = (uint32_t)links >> 24, sum = INCR ? min(255u, (uint32_t)*cell + c) : c;
+							*cell = (uint8_t)sum;
+						}
+					} else if (foreign) { // the slot keeps the node another region's spill merge put there
 					} else {
 						*reinterpret_cast<uint4 *>(&table[region_base + i]) =
 						    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
@@ -1077,6 +1107,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			grab(); // the region after the one whose first batch is already in flight
 			lds_barrier(); // the image is empty again, next_region is visible
 			f_after = __builtin_amdgcn_readfirstlane(L.next_region);
+			if (INCR && !KF) load_image(f_nxt); // the region whose records come next
 			lds_barrier();
 		}
 		f = f_nxt;

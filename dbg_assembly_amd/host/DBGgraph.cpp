@@ -50,6 +50,9 @@ int DbgkLastStatus = 0;
 
 namespace {
 
+const uint64_t kPartitionMinSlots = 67108879;   // smallest table the PARTITION engine takes (2^26 slots), a prime above it
+const uint64_t kPartitionMaxSlots = 4290772992ull; // 2^32 - 2^22
+
 struct Session {
 	dbgk_handle *h = nullptr;
 	std::vector<char> bases;          // sequences of the pending batch, back to back
@@ -58,10 +61,17 @@ struct Session {
 	uint64_t device_slots = 0;
 	uint64_t next_progress = 0;
 	int status = DBGK_OK;
+	bool partition = false;                // PARTITION engine (streaming: records are flushed into the table as needed)
+	// The reference's table, tracked exactly (DBGgraph.cpp:329-351): after every FULL block of BufferNum
+	// reads `count > max` decides about a doubling, and at the -e cap about abandoning the file.
+	uint64_t ref_size = 0, ref_max = 0;    // size / max of the kset the reference would hold now
+	uint64_t count_known = 0;              // distinct non-zero keys on the device at the last exact reading
+	uint64_t bound_since = 0;              // k-mer windows handed over (pushed or pending here) since then: new keys <= this
+	uint64_t reads_in_block = 0;           // reads since the last full block of the current file
+	bool stop_file = false;                // the reference would have left this file's block loop (-e cap)
 	// DBGK_LAYOUT=ref: reproduce the reference's -t 1 slot layout (first-seen order replay)
 	bool ref_layout = false;
 	uint64_t pos = 0;                      // bases handed to the device so far (+ pending batch)
-	uint64_t reads_in_block = 0;           // reads since the last full block of the current file
 	std::vector<uint64_t> full_block_ends; // position right after every FULL block of BufferNum reads
 };
 
@@ -72,23 +82,49 @@ void fail(Session &S, int rc, const char *what)
 	if (S.status == DBGK_OK) {
 		S.status = rc;
 		cerr << "\nAlert message: " << what << " failed: " << dbgk_strerror(rc);
-		if (rc == DBGK_ERR_HIP) cerr << " [" << dbgk_last_error() << "]";
+		if (rc == DBGK_ERR_HIP || rc == DBGK_ERR_ARG || rc == DBGK_ERR_STATE) cerr << " [" << dbgk_last_error() << "]";
 		cerr << "; the remaining input is ignored" << endl;
 	}
 }
 
-// make sure the device table can absorb `incoming` more distinct keys, growing it if necessary
-// (the device-side counterpart of the reference's enlarge step; the size the HOST table finally
-// gets is decided separately in final_host_size()).
-void reserve_device_slots(Session &S, uint64_t incoming)
+inline uint64_t windows_of(size_t len)
 {
+	const uint64_t rl = std::min<uint64_t>(len, (uint64_t)maxReadLen);
+	return rl >= (uint64_t)KmerSize ? rl - (uint64_t)KmerSize + 1 : 0;
+}
+
+inline float clamped_load_factor()
+{
+	return hashLoadFactor <= 0 ? 0.25f : (hashLoadFactor >= 1 ? 0.75f : hashLoadFactor); // kmerSet.cpp:107-108
+}
+
+// distinct non-zero keys on the device, exactly: everything handed over so far is in the table afterwards
+// (the PARTITION engine flushes its record store for it)
+void exact_count(Session &S)
+{
+	if (S.status != DBGK_OK) return;
+	int rc = S.partition ? dbgk_flush(S.h) : DBGK_OK;
+	if (rc != DBGK_OK) return fail(S, rc, "dbgk_flush");
 	dbgk_stats st;
-	int rc = dbgk_refresh_stats(S.h, &st);
+	rc = dbgk_refresh_stats(S.h, &st);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_refresh_stats");
-	const double need = (double)st.count + (double)incoming;
+	S.count_known = st.count - 1;   // st.count includes the key-0 node, which the reference adds last (DBGgraph.cpp:418)
+	S.bound_since = 0;
+	for (size_t i = 1; i < S.offsets.size(); i++) S.bound_since += windows_of(S.offsets[i] - S.offsets[i - 1]); // not pushed yet
+}
+
+// make sure the device table can absorb everything handed over so far, growing it if necessary (the
+// device-side counterpart of the reference's enlarge step; the size of the HOST table follows the
+// reference's own schedule, see end_of_full_block).  No device round trip while the bound says it fits.
+void reserve_device_slots(Session &S)
+{
+	if ((double)S.count_known + (double)S.bound_since <= 0.80 * (double)S.device_slots) return;
+	exact_count(S);
+	if (S.status != DBGK_OK) return;
+	const double need = (double)S.count_known + (double)S.bound_since;
 	if (need <= 0.80 * (double)S.device_slots) return;
 	const uint64_t target = find_next_prime((uint64_t)(need / 0.55) + 16);
-	rc = dbgk_resize_table(S.h, target);
+	int rc = dbgk_resize_table(S.h, target);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_resize_table");
 	S.device_slots = target;
 	cerr << "Enlarge device hash array size to be: " << target << endl;
@@ -102,7 +138,7 @@ void flush_batch(Session &S)
 		S.offsets.assign(1, 0);
 		return;
 	}
-	reserve_device_slots(S, S.bases.size());  // every base starts at most one new k-mer
+	reserve_device_slots(S);
 	if (S.status == DBGK_OK) {
 		int rc = dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
 		if (rc != DBGK_OK) fail(S, rc, "dbgk_push_reads");
@@ -116,50 +152,54 @@ void flush_batch(Session &S)
 	S.offsets.assign(1, 0);
 }
 
+// The reference's check after every FULL block (DBGgraph.cpp:337-351): count > max -> one
+// enlarge_kmerset_parallel(kset, 1, ...) while doublings are left, else the rest of the file is abandoned.
+// count is only read from the device when the bound since the last exact reading could exceed max.
+void end_of_full_block(Session &S)
+{
+	S.reads_in_block = 0;
+	if (S.ref_layout) S.full_block_ends.push_back(S.pos);
+	if (S.count_known + S.bound_since <= S.ref_max) return;
+	flush_batch(S);
+	exact_count(S);
+	if (S.status != DBGK_OK || S.count_known <= S.ref_max) return;
+	if (doubleHashTimes < maxDoubleHashTimes) {
+		const float lf = clamped_load_factor();
+		do {
+			S.ref_size = find_next_prime(S.ref_size * 2);   // kmerSet.cpp:136
+		} while ((float)S.ref_size * lf < (float)(S.count_known + 1));
+		S.ref_max = (uint64_t)((float)S.ref_size * lf);     // kmerSet.cpp:145
+		doubleHashTimes++;
+		cerr << "Enlarge hash array size to be: " << S.ref_size << endl;
+		cerr << "The expanded memory used now:  " << (double)S.ref_size / 1000000000 * 16 << " G" << endl;
+	} else {
+		cerr << "\nAlert message: Memory reach the maximum allowed, program have loaded " << Total_reads_num
+		     << " reads, the left others are ignored\n" << endl;
+		S.stop_file = true;
+	}
+}
+
 inline void add_read(Session &S, const char *seq, size_t len)
 {
 	S.bases.insert(S.bases.end(), seq, seq + len);
 	S.offsets.push_back(S.bases.size());
-	if (S.ref_layout) {
-		S.pos += len;
-		if (++S.reads_in_block == (uint64_t)std::max(BufferNum, 1)) { // the reference checks count > max here (DBGgraph.cpp:337)
-			S.full_block_ends.push_back(S.pos);
-			S.reads_in_block = 0;
-		}
-	}
-	if (S.bases.size() >= S.batch_limit) flush_batch(S);
-}
-
-// the host table size the reference would end with for `keys` distinct non-zero keys: start from
-// the initial "prime" and double (find_next_prime(2*size)) while count > max, at most
-// maxDoubleHashTimes times (DBGgraph.cpp:337-351, kmerSet.cpp:140-145).  The reference tests this
-// after every full block of BufferNum reads; evaluating it once on the final count gives the
-// same chain element except when only the last, short block pushes count over max.
-uint64_t final_host_size(uint64_t initial, uint64_t keys, float lf, uint64_t &doublings, bool &capped)
-{
-	if (lf <= 0) lf = 0.25f; else if (lf >= 1) lf = 0.75f;
-	uint64_t size = initial;
-	doublings = 0;
-	capped = false;
-	while (keys > (uint64_t)((float)size * lf)) {
-		if (doublings >= maxDoubleHashTimes) { capped = true; break; }
-		size = find_next_prime(size * 2);
-		doublings++;
-	}
-	return size;
+	S.bound_since += windows_of(len);
+	S.pos += len;
+	if (++S.reads_in_block == (uint64_t)std::max(BufferNum, 1)) end_of_full_block(S);
+	else if (S.bases.size() >= S.batch_limit) flush_batch(S);
 }
 
 }  // namespace
 
 void *thread_parseBlock(void *)
 {
-	cerr << "thread_parseBlock: this stage runs on the GPU in this build (k_extract_insert)" << endl;
+	cerr << "thread_parseBlock: this stage runs on the GPU in this build (k_extract_insert / k_extract_scatter)" << endl;
 	abort();
 }
 
 void *thread_updatekmers(void *)
 {
-	cerr << "thread_updatekmers: this stage runs on the GPU in this build (k_extract_insert)" << endl;
+	cerr << "thread_updatekmers: this stage runs on the GPU in this build (k_extract_insert / k_build_regions)" << endl;
 	abort();
 }
 
@@ -168,13 +208,15 @@ void parse_one_reads_file(string &reads_file)
 {
 	if (!g_session) return;
 	Session &S = *g_session;
-	if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); })) {
+	S.stop_file = false;
+	S.reads_in_block = 0;
+	if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); }, &S.stop_file)) {
 		cerr << "fail to open reads file " << reads_file << endl;
 		return;
 	}
 	flush_batch(S);
 	S.reads_in_block = 0; // a file's last, short block is never followed by an enlarge check (DBGgraph.cpp:329-331)
-	cerr << "this block has reach the end of file " << endl;
+	if (!S.stop_file) cerr << "this block has reach the end of file " << endl;
 }
 
 // DBGK_LAYOUT=ref: rebuild the host table exactly as the reference's single-threaded path lays it
@@ -183,14 +225,15 @@ void parse_one_reads_file(string &reads_file)
 // BufferNum reads the table is enlarged in place when count > max (:337-343, kmerSet.cpp:132-189).
 // The slot layout therefore depends only on the ORDER in which distinct keys first appear and on
 // where the block boundaries fall between them -- both known here: the device returns the nodes
-// sorted by first-seen position, the parser recorded the position after every full block.
+// sorted by first-seen position, the parser recorded the position after every full block (and left a
+// file where the reference would have, so no read beyond the -e cap is in the input).
 static KmerSet *replay_reference_layout(Session &S, const std::vector<dbgk_node> &nodes, const std::vector<uint64_t> &first_pos,
                                         uint64_t initial_size, uint32_t polyA_l, uint32_t polyA_r)
 {
 	KmerSet *ks = init_kmerset_parallel(initial_size, hashLoadFactor, std::max(threadNum, 1));
 	if (!ks) return NULL;
 	size_t i = 0;
-	bool alerted = false;
+	uint64_t doublings = 0;
 	auto insert_until = [&](uint64_t limit) {
 		for (; i < nodes.size() && first_pos[i] < limit; i++) {
 			uint64_t hc = hash_code(nodes[i].kmer) % ks->size;
@@ -207,16 +250,9 @@ static KmerSet *replay_reference_layout(Session &S, const std::vector<dbgk_node>
 	};
 	for (uint64_t end : S.full_block_ends) {
 		insert_until(end);
-		if (ks->count > ks->max) {
-			if (doubleHashTimes >= maxDoubleHashTimes && !alerted) {
-				// the reference drops the rest of the file here (DBGgraph.cpp:346-350); every read is kept
-				cerr << "\nAlert message: Memory reach the maximum allowed by -e " << maxDoubleHashTimes << "; all reads were kept" << endl;
-				alerted = true;
-			}
+		if (ks->count > ks->max && doublings < maxDoubleHashTimes) {
 			enlarge_kmerset_parallel(ks, 1, std::max(threadNum, 1));
-			doubleHashTimes++;
-			cerr << "Enlarge hash array size to be: " << ks->size << endl;
-			cerr << "The expanded memory used now:  " << (double)ks->size / 1000000000 * 16 << " G" << endl;
+			doublings++;
 		}
 	}
 	insert_until(~0ull);
@@ -231,6 +267,25 @@ static void release_session()
 	if (g_session->h) dbgk_destroy(g_session->h);
 	delete g_session;
 	g_session = nullptr;
+}
+
+// plain (not gzip'ed) input: the sum of the file sizes bounds the number of k-mer windows; 0 = unknown
+static uint64_t input_size_bound(const vector<string> &files)
+{
+	uint64_t total = 0;
+	for (const string &f : files) {
+		FILE *fp = fopen(f.c_str(), "rb");
+		if (!fp) continue;
+		unsigned char magic[2] = {0, 0};
+		const size_t got = fread(magic, 1, 2, fp);
+		const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+		fseek(fp, 0, SEEK_END);
+		const long sz = ftell(fp);
+		fclose(fp);
+		if (gz || sz < 0) return 0;
+		total += (uint64_t)sz;
+	}
+	return total;
 }
 
 void build_debruijn_graph(vector<string> &reads_files)
@@ -252,8 +307,10 @@ void build_debruijn_graph(vector<string> &reads_files)
 	Session *S = new Session();
 	g_session = S;
 	S->offsets.assign(1, 0);
-	S->device_slots = initial_size;
+	S->ref_size = initial_size;
+	S->ref_max = (uint64_t)((float)initial_size * clamped_load_factor());   // kmerSet.cpp:114
 	if (const char *mb = getenv("DBGK_BATCH_MB")) S->batch_limit = std::max<uint64_t>(1, strtoull(mb, NULL, 10)) << 20;
+	if (const char *bb = getenv("DBGK_BATCH_BYTES")) S->batch_limit = std::max<uint64_t>(1024, strtoull(bb, NULL, 10)); // tests: many small batches
 	S->bases.reserve(S->batch_limit + (1u << 16));
 
 	S->ref_layout = getenv("DBGK_LAYOUT") && string(getenv("DBGK_LAYOUT")) == "ref";
@@ -261,13 +318,27 @@ void build_debruijn_graph(vector<string> &reads_files)
 	memset(&cfg, 0, sizeof cfg);
 	cfg.kmer_size = KmerSize;
 	cfg.max_read_len = maxReadLen;
-	cfg.table_slots = initial_size;
 	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
-	cfg.engine = getenv("DBGK_ENGINE") ? atoi(getenv("DBGK_ENGINE")) : DBGK_ENGINE_AUTO;
-	if (S->ref_layout) {
-		cfg.engine = DBGK_ENGINE_DIRECT;
-		cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
+	// Engine: PARTITION (records radix-partitioned by slot range, table regions built in LDS; input of unknown
+	// size streams through its record store) unless DBGK_ENGINE=1 asks for DIRECT (global atomics) or the
+	// reference's slot layout is wanted (needs DIRECT's first-seen tracking).  The device table is independent
+	// of the host table the consumer gets: at least 2^26 slots for PARTITION, grown as needed.
+	const int want_engine = getenv("DBGK_ENGINE") ? atoi(getenv("DBGK_ENGINE")) : DBGK_ENGINE_AUTO;
+	S->partition = !S->ref_layout && want_engine != DBGK_ENGINE_DIRECT && initial_size <= kPartitionMaxSlots;
+	S->device_slots = S->partition ? std::max(initial_size, kPartitionMinSlots) : initial_size;
+	cfg.table_slots = S->device_slots;
+	cfg.engine = S->partition ? DBGK_ENGINE_PARTITION : DBGK_ENGINE_DIRECT;
+	if (S->partition) {
+		// record store: what the input can hold at most (plain files: one window per byte), at most 2^30
+		// occurrences (~19 GB of stores); more input is flushed into the table in rounds
+		uint64_t store = getenv("DBGK_STORE_KMERS") ? strtoull(getenv("DBGK_STORE_KMERS"), NULL, 10) : 0;
+		if (!store) {
+			const uint64_t bound = input_size_bound(reads_files);
+			store = bound ? std::min<uint64_t>(bound, 1ull << 30) : (1ull << 30);
+		}
+		cfg.expected_kmers = std::max<uint64_t>(store, 1024);
 	}
+	if (S->ref_layout) cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
 	int rc = dbgk_create(&cfg, &S->h);
 	if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
@@ -313,34 +384,30 @@ void build_debruijn_graph(vector<string> &reads_files)
 		}
 	} else if (S->status == DBGK_OK) {
 		Kmer_total_num = st.total_kmers;
-		bool capped = false;
-		const uint64_t host_size = final_host_size(initial_size, st.count - 1, hashLoadFactor, doubleHashTimes, capped);
-		if (doubleHashTimes) {
-			cerr << "Enlarge hash array size to be: " << host_size << endl;
-			cerr << "The expanded memory used now:  " << (double)host_size / 1000000000 * 16 << " G" << endl;
-		}
-		uint64_t use_size = host_size;
-		if (capped) {
-			// The reference stops reading here and drops the rest of the file (DBGgraph.cpp:346-350).
-			// All reads are already in the graph on the device, so keep them and size the host table
-			// to fit instead of silently losing data.
-			cerr << "\nAlert message: Memory reach the maximum allowed by -e " << maxDoubleHashTimes
-			     << "; all " << Total_reads_num << " reads were kept, the host table is sized to hold them" << endl;
-			while (st.count > (uint64_t)((float)use_size * 0.95f)) use_size = find_next_prime(use_size * 2);
-		}
-		KmerNode *array = static_cast<KmerNode *>(malloc(use_size * sizeof(KmerNode)));
-		uint8_t *nul = static_cast<uint8_t *>(malloc(use_size / 8 + 1));
-		uint8_t *del = static_cast<uint8_t *>(calloc(use_size / 8 + 1, 1));
-		if (!array || !nul || !del) {
-			free(array), free(nul), free(del);
-			fail(*S, DBGK_ERR_NOMEM, "host table allocation");
+		// the host table has the size the reference's own schedule arrived at (tracked block by block above)
+		const uint64_t use_size = S->ref_size;
+		KmerNode *array = NULL;
+		uint8_t *nul = NULL, *del = NULL;
+		if (st.count > use_size) {
+			// the reference would now spin forever looking for a free slot (DBGgraph.cpp:170-205)
+			cerr << "\nAlert message: " << st.count << " kmer nodes do not fit the hash array of " << use_size
+			     << " entries the -i/-e settings allow" << endl;
+			fail(*S, DBGK_ERR_TABLE_FULL, "host table");
 		} else {
-			rc = dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
-			if (rc != DBGK_OK) {
+			array = static_cast<KmerNode *>(malloc(use_size * sizeof(KmerNode)));
+			nul = static_cast<uint8_t *>(malloc(use_size / 8 + 1));
+			del = static_cast<uint8_t *>(calloc(use_size / 8 + 1, 1));
+			if (!array || !nul || !del) {
 				free(array), free(nul), free(del);
-				fail(*S, rc, "dbgk_export_host_table");
+				fail(*S, DBGK_ERR_NOMEM, "host table allocation");
 			} else {
-				result = adopt_kmerset(use_size, hashLoadFactor, st.count, st.count_conflict, array, nul, del);
+				rc = dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
+				if (rc != DBGK_OK) {
+					free(array), free(nul), free(del);
+					fail(*S, rc, "dbgk_export_host_table");
+				} else {
+					result = adopt_kmerset(use_size, hashLoadFactor, st.count, st.count_conflict, array, nul, del);
+				}
 			}
 		}
 	}

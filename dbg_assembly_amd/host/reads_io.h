@@ -13,9 +13,11 @@
 #include <string>
 #include <vector>
 
-// calls cb(sequence pointer, length) for every record; false if the file cannot be opened
+// calls cb(sequence pointer, length) for every record; false if the file cannot be opened.  When `stop`
+// is given and set by the callback, the rest of the file is not read (the reference abandons a file at
+// its -e memory cap, DBG_contig/DBGgraph.cpp:346-350).
 template <class Callback>
-bool for_each_read_in_file(const std::string &path, int format, Callback cb)
+bool for_each_read_in_file(const std::string &path, int format, Callback cb, const bool *stop = nullptr)
 {
 	gzFile fp = gzopen(path.c_str(), "rb");
 	if (!fp) return false;
@@ -26,13 +28,13 @@ bool for_each_read_in_file(const std::string &path, int format, Callback cb)
 	size_t have = 0;  // bytes of an unfinished line carried over
 	int state = 0;    // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
 	bool eof = false;
-	while (!eof) {
+	while (!eof && !(stop && *stop)) {
 		if (buf.size() < have + CHUNK) buf.resize(have + CHUNK);
 		const int got = gzread(fp, buf.data() + have, (unsigned)CHUNK);
 		if (got <= 0) eof = true;
 		const size_t end = have + (got > 0 ? (size_t)got : 0);
 		size_t pos = 0;
-		while (pos < end) {
+		while (pos < end && !(stop && *stop)) {
 			const char *nl = static_cast<const char *>(memchr(buf.data() + pos, '\n', end - pos));
 			size_t line_end;
 			if (nl) line_end = (size_t)(nl - buf.data());
@@ -51,7 +53,7 @@ bool for_each_read_in_file(const std::string &path, int format, Callback cb)
 		have = pos < end ? end - pos : 0;
 		if (have) memmove(buf.data(), buf.data() + pos, have);
 	}
-	if (state == 1) cb("", 0);
+	if (state == 1 && !(stop && *stop)) cb("", 0);
 	gzclose(fp);
 	return true;
 }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DBGK_ABI_VERSION 2
+#define DBGK_ABI_VERSION 3
 
 /* status codes */
 #define DBGK_OK               0
@@ -69,9 +69,11 @@ typedef struct dbgk_config {
 	int32_t  engine;           /* DBGK_ENGINE_*                                                    */
 	uint64_t max_batch_bases;  /* capacity of the internal staging buffers used by
 	                              dbgk_push_reads (host buffers); 0 = default (256 MiB)            */
-	uint64_t expected_kmers;   /* PARTITION engine: upper bound on k-mer occurrences that will be
-	                              pushed INTO THIS HANDLE before finalize (sizes the record store);
-	                              0 = derive from table_slots                                      */
+	uint64_t expected_kmers;   /* PARTITION engine: k-mer occurrences the record store is sized for
+	                              (8 bytes each, twice).  Input of unknown size streams through it:
+	                              a push that would not fit is preceded by a flush (dbgk_flush), which
+	                              merges the stored records into the table.  A job that fits is built
+	                              in one go at finalize (fastest).  0 = derive from table_slots      */
 	uint32_t shard_count;      /* > 1: this handle is one of shard_count handles (one per GPU) that
 	                              together hold ONE table of table_slots slots, each a contiguous
 	                              slot range; 0 = unsharded (1 = a single shard that still follows
@@ -167,8 +169,20 @@ int dbgk_sync(dbgk_handle *h);
 
 /* replaces enlarge_kmerset_parallel (kmerSet.cpp:132-189) for the DEVICE table: allocates a table
  * of new_slots, re-seats every node, frees the old one.  Content (the node multiset) is unchanged.
- * Allowed between pushes (it synchronises first).                                               */
+ * Allowed between pushes (it synchronises first; a PARTITION handle flushes its records first and
+ * re-plans its bucket geometry for the new size, which must again be in the engine's range).      */
 int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots);
+
+/* PARTITION engine, input of unknown size (the block loop of parse_one_reads_file, DBGgraph.cpp:226-356,
+ * never knows how much is still to come): turn the records pushed so far into table nodes NOW.  Regions
+ * that already hold nodes of an earlier flush are loaded back into LDS, the new records inserted, the
+ * region written out again; the record store is empty afterwards and dbgk_refresh_stats is exact (between
+ * flushes its counts exclude what still sits in the store).  Pushes do this on their own when the store
+ * is full.  No-op for the other engines (their table is always current).                           */
+int dbgk_flush(dbgk_handle *h);
+/* PARTITION engine: upper bound of the k-mer occurrences waiting in the record store, and what the
+ * store was sized for (0, 0 for the other engines)                                                 */
+int dbgk_store_room(dbgk_handle *h, uint64_t *pending_kmers, uint64_t *capacity_kmers);
 
 /* ---- results ----------------------------------------------------------------------------------- */
 

@@ -66,13 +66,17 @@ def pack(reads):
     return bases, offs
 
 
-def push_in_batches(g, reads, rng):
+def push_in_batches(g, reads, rng, may_flush=False):
+    """may_flush: unsharded PARTITION handle -- now and then the records are flushed into the table between
+    pushes (the streaming mode: later region builds load the nodes back into LDS)"""
     cuts = sorted(rng.sample(range(len(reads)), min(len(reads), rng.randint(0, 3))))
     for a, b in zip([0] + cuts, cuts + [len(reads)]):
         if b > a:
             if os.environ.get("FUZZ_VERBOSE"):
                 print("   push reads [%d, %d) of %d, %d bases" % (a, b, len(reads), sum(len(r) for r in reads[a:b])), flush=True)
             g.push_reads(*pack(reads[a:b]))
+            if may_flush and rng.random() < 0.4:
+                g.flush()
 
 
 def pick_expected(rng, actual):
@@ -179,7 +183,7 @@ def main():
           if n_shards == 0:
             with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=pick_expected(rng, want[2]),
                             max_read_len=max_read_len) as g:
-                push_in_batches(g, reads, rng)
+                push_in_batches(g, reads, rng, may_flush=True)
                 st = g.finalize()
                 got = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
           else:
@@ -200,7 +204,7 @@ def main():
             # only as far as the overflow stores reach, then dbgk_finalize reports DBGK_ERR_CAPACITY)
             for expected in (0, max(1, want[2]) * rng.choice([1, 2, 50])):
                 with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=max_read_len, expected_kmers=expected) as g:
-                    push_in_batches(g, reads, rng)
+                    push_in_batches(g, reads, rng, may_flush=expected > 0)
                     st = g.finalize()
                     tabs.append((int(st.count), int(st.stored_kmers), g.kfreq_counts().tobytes()))
             if tabs[0] != tabs[1] or tabs[0][1] != want[2]:

@@ -31,3 +31,35 @@ def case_reads(case, oracle):
         P = oracle.synth_params(s["genome_len"], s["read_len"], s["sub_rate"], s["n_rate"], s["cfg"])
         return [oracle.synth_reads(P, 0, s["n_reads"])]
     return [oracle.read_sequences(p, case["params"]["fmt"]) for p in case_files(case)]
+
+
+def push_with_reference_schedule(g, files, params, capi):
+    """Drive a Graph the way the reference's block loop would (DBG_contig/DBGgraph.cpp:226-356): blocks of
+    buffer_num reads; after every FULL block `count > max` leads to one enlarge while doublings are left
+    (kmerSet.cpp:132-145), otherwise the rest of the file is dropped.  Returns the table size the reference
+    ends with.  (Host logic restated for the library-level tests; the C++ host layer has its own.)"""
+    lf = np.float32(params["load_factor"])
+    lf = np.float32(0.25) if lf <= 0 else (np.float32(0.75) if lf >= 1 else lf)
+    want = int(params["init_hash_size"] * 1000000000)
+    size = 3 if want < 3 else capi.find_next_prime_ref(want)
+    cutoff = lambda sz: int(np.float32(sz) * lf)
+    doublings, B = 0, params["buffer_num"]
+    for bases, offsets in files:
+        n = len(offsets) - 1
+        for r0 in range(0, n, B):
+            r1 = min(r0 + B, n)
+            lo, hi = int(offsets[r0]), int(offsets[r1])
+            g.push_reads(bases[lo:hi], offsets[r0:r1 + 1] - offsets[r0])
+            if r1 - r0 < B:
+                break
+            g.flush()
+            count = int(g.refresh_stats().count) - 1
+            if count > cutoff(size):
+                if doublings >= params["max_double"]:
+                    break
+                while True:
+                    size = capi.find_next_prime_ref(size * 2)
+                    if np.float32(size) * lf >= np.float32(count + 1):
+                        break
+                doublings += 1
+    return size

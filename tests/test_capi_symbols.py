@@ -25,7 +25,8 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_errors():
     L = capi.lib()
-    assert L.dbgk_abi_version() == 2
+    want = int(re.search(r"#define\s+DBGK_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "dbgk.h")).read()).group(1))
+    assert L.dbgk_abi_version() == want
     assert L.dbgk_strerror(capi.ERR_TABLE_FULL) == b"k-mer table full"
     # argument validation happens before any device work
     cfg = capi.Config(0, 250, 1009, 0, 0, 0, 0)

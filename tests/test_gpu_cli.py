@@ -35,17 +35,19 @@ def run_cli(tmp_path, case, extra_env=None):
     return r, dump, prefix
 
 
+@pytest.mark.parametrize("engine", [2, 1], ids=["partition", "direct"])
 @pytest.mark.parametrize("case", FILE_CASES, ids=[c["name"] for c in FILE_CASES])
-def test_cli_matches_reference(tmp_path, oracle, case):
+def test_cli_matches_reference(tmp_path, oracle, case, engine):
+    """build_debruijn_graph() behind the reference's command line, both engines (PARTITION is what the
+    CLI runs by default: records streamed through the record store, regions built in LDS).  Includes the
+    reference's block schedule: enlarges decided after every full -b block, and the rest of a file dropped
+    at the -e cap (enlarge_cap_e1, DBGgraph.cpp:337-351)."""
     assert os.path.exists(CLI), "debruijn_contig not built (python -c 'import __graft_entry__ as g; g.build()')"
-    r, dump, prefix = run_cli(tmp_path, case)
+    r, dump, prefix = run_cli(tmp_path, case, {"DBGK_ENGINE": str(engine)})
     ref = case["ref"]
     log = r.stderr
     if case["name"] == "enlarge_cap_e1":
-        # documented deviation: the reference drops the rest of the file at the -e cap
-        # (DBGgraph.cpp:346-350); this build keeps every read and says so
-        assert "Memory reach the maximum allowed" in log
-        return
+        assert "Alert message: Memory reach the maximum allowed, program have loaded" in log
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert re.search(r"^count:\t%d$" % ref["count"], log, re.M)
     assert re.search(r"^array_size:\t%d$" % ref["size"], log, re.M)       # same doubling chain as the reference
@@ -63,11 +65,20 @@ def test_cli_matches_reference(tmp_path, oracle, case):
 
 
 def test_cli_small_batches_and_device_resize(tmp_path):
-    """1 MiB host batches + a tiny initial table force several device-side enlarges"""
+    """DIRECT engine: 1 MiB host batches + a tiny initial table force several device-side enlarges"""
     case = [c for c in golden_cases() if c["name"] == "enlarge_b50"][0]
-    r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_MB": "1"})
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_MB": "1", "DBGK_ENGINE": "1"})
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert "Enlarge device hash array size" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["mixed150_k31", "enlarge_b50", "polyA_k31", "saturate_k31", "fastq_gz_k31"])
+def test_cli_streams_through_a_small_record_store(tmp_path, name):
+    """PARTITION engine with a record store far smaller than the input and 4 KiB host batches: the input
+    goes through many flush rounds (regions loaded back into LDS, new records merged, written out again)."""
+    case = [c for c in golden_cases() if c["name"] == name][0]
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_BYTES": "4096", "DBGK_ENGINE": "2", "DBGK_STORE_KMERS": "3000"})
+    assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
 
 
 LAYOUT_CASES = [c for c in FILE_CASES if c["name"] in ("mixed150_k31", "enlarge_b50", "block_b7", "polyA_k31", "fastq_gz_k31",

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases, golden_case_ids
-from helpers import case_reads, dump_sha256
+from helpers import case_reads, dump_sha256, push_with_reference_schedule
 
 pytestmark = pytest.mark.gpu
 
@@ -75,9 +75,12 @@ def test_golden_cases(capi, oracle, case):
     host-layout table."""
     p, ref = case["params"], case["ref"]
     files = case_reads(case, oracle)
-    if case["name"] == "enlarge_cap_e1":
-        pytest.skip("reference drops reads after hitting -e (DBGgraph.cpp:346-350); covered by the host layer test")
-    g, st = _build(capi, files, p["k"], p["max_read_len"], ref["size"])
+    if case["name"] == "enlarge_cap_e1":  # the reference drops the rest of a file at the -e cap (DBGgraph.cpp:346-350)
+        g = capi.Graph(k=p["k"], table_slots=ref["size"], max_read_len=p["max_read_len"])
+        assert push_with_reference_schedule(g, files, p, capi) == ref["size"]
+        st = g.finalize()
+    else:
+        g, st = _build(capi, files, p["k"], p["max_read_len"], ref["size"])
     try:
         assert (st.total_reads, st.total_kmers, st.count) == (ref["reads"], ref["kmers"], ref["count"])
         nodes = g.export_sorted()
@@ -256,16 +259,17 @@ PART_SLOTS = 70000000  # the engine needs >= 2^26 slots (8-byte records, DESIGN.
 @pytest.mark.parametrize("case", golden_cases(), ids=golden_case_ids())
 def test_partition_engine_golden_cases(capi, oracle, case):
     p, ref = case["params"], case["ref"]
-    if case["name"] == "enlarge_cap_e1":
-        pytest.skip("reference drops reads at the -e cap")
     files = case_reads(case, oracle)
     size = capi.find_next_prime_ref(PART_SLOTS)
     n_bases = sum(int(o[-1]) for _, o in files)
     g = capi.Graph(k=p["k"], table_slots=size, max_read_len=p["max_read_len"], engine=capi.ENGINE_PARTITION,
                    expected_kmers=max(n_bases, 1))
     try:
-        for bases, offsets in files:
-            g.push_reads(bases, offsets)
+        if case["name"] == "enlarge_cap_e1":  # block by block with a flush after each: the reference's -e cap schedule
+            assert push_with_reference_schedule(g, files, p, capi) == ref["size"]
+        else:
+            for bases, offsets in files:
+                g.push_reads(bases, offsets)
         st = g.finalize()
         assert (st.total_reads, st.total_kmers, st.count) == (ref["reads"], ref["kmers"], ref["count"])
         nodes = g.export_sorted()
@@ -304,6 +308,61 @@ def test_partition_engine_equals_direct_and_oracle(capi, oracle):
     assert np.array_equal(nodes, ref.nodes)
     assert dig == oracle.nodes_digest(ref.nodes)
     assert list(ls.depth_stat) == list(oracle.link_stats(ref.nodes, 2).depth_stat)
+
+
+@pytest.mark.parametrize("store,explicit_flush", [(50000, False), (1 << 22, True), (7, False)])
+def test_partition_engine_streams_input_of_unknown_size(capi, oracle, store, explicit_flush):
+    """Record store much smaller than the input (expected_kmers = store): pushes flush on their own when the
+    store is full -- regions that already hold nodes are loaded back into LDS, the new records merged in and
+    the region written out again.  Explicit dbgk_flush between pushes, exact counts in between, a device-side
+    resize half way (new bucket geometry), heavy poly-A / repeat content (key-0 side node, saturation)."""
+    rng = random.Random(store)
+    reads = rand_reads(rng, 6000, G=40000) + [b"A" * 150] * 300 + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 400
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=store, max_batch_bases=1 << 16) as g:
+        n = len(reads)
+        cuts = [0, n // 5, n // 2, n // 2 + 1, (4 * n) // 5, n]
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            lo, hi = int(offsets[a]), int(offsets[b])
+            g.push_reads(bases[lo:hi], offsets[a:b + 1] - offsets[a])
+            if explicit_flush:
+                g.flush()
+                assert g.store_room()[0] == 0
+                part = oracle.build_graph(files_mem=[(bases[:hi], offsets[:b + 1])], k=31, init_hash_size=0.001)
+                assert g.refresh_stats().count == part.count  # exact after a flush
+            if i == 2:
+                g.resize_table(capi.find_next_prime_ref(2 * PART_SLOTS + 12345))
+        st = g.finalize()
+        nodes = g.export_sorted()
+        array, flags = g.export_host_table()
+        assert oracle.check_host_table(array, flags, g.table_slots, st.count) == 0
+    assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+    assert np.array_equal(nodes, ref.nodes)
+
+
+def test_partition_engine_streaming_device_pushes_equal_one_shot(capi):
+    """cfg2-shaped reads pushed from device memory in 8 pieces through a store that holds 3 of them:
+    digest and counts equal the one-shot build (records of all pieces resident)."""
+    n_reads, G, pieces = 800000, 4000000, 8
+    P = capi.synth_params(G, 150, cfg=2)
+    size = capi.find_next_prime_ref(100000000)
+    res = []
+    for store in (n_reads * 150, 3 * (n_reads // pieces) * 150):
+        with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=store) as g:
+            bufs = []
+            per = n_reads // pieces
+            for i in range(pieces):
+                d_bases, d_off, nb = g.synth_reads_device(P, i * per, per)
+                g.push_reads_device(d_bases.ptr, d_off.ptr, per, nb)
+                bufs += [d_bases, d_off]
+            st = g.finalize()
+            res.append((int(st.count), int(st.stored_kmers), int(st.total_kmers), g.digest(), list(g.link_stats(2).depth_stat)))
+            for b in bufs:
+                b.free()
+    assert res[0] == res[1]
 
 
 def test_partition_engine_bucket_overflow_goes_through_direct_path(capi, oracle):
