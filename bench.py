@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_ALG = 33.25          # algorithmic bytes per k-mer, k=31 L=150: 1.25 B bases + 16 B node read + 16 B node write
+H2D_STEPS = 3          # extra steps timed from the first host-to-device copy (SURVEY 8(d) timed region), after the main loop
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -75,36 +76,69 @@ def measured_traffic(args, size, kernel):
     return best
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, genome_len):
     """Time the reference's own pthreaded CPU path (oracle/_ref/ref_dbg) on the first
-    --cpu-sample-reads reads of rank 0's workload; fall back to the oracle port when the binary
-    did not travel.  Checker code: used here only as the thing timed NEXT TO the GPU path."""
+    --cpu-sample-reads reads of rank 0's workload, at -t = the box's cores and at the reference's default
+    -t 10, and the oracle port with the same reads pre-loaded in memory (no file parsing); falls back to the
+    port alone when the binary did not travel.  Checker code: used here only as the thing timed NEXT TO the
+    GPU path.  Returns (main record, list of variants)."""
     import tempfile
     from oracle import oracle_py as O
     import ctypes as C
     # threads actually used: the box's CPU share for one GPU (16), never more than the cores visible
-    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
+    visible = len(os.sched_getaffinity(0))
+    cores = min(visible, args.cpu_threads)
     n = args.cpu_sample_reads
     P = O.synth_params(genome_len, 150, cfg=2)
     init = max(2.2 * n * (150 - args.kmer + 1) / 1e9 * 0.75, 0.001)  # distinct <= kmers; load <= ~0.6
-    sample = "first %d reads of the N=1 workload (%d k-mers), -t %d -i %.3f -b 10000" % (
-        n, n * (150 - args.kmer + 1), cores, init)
-    if O.have_ref():
-        with tempfile.TemporaryDirectory() as tmp:
-            fa = os.path.join(tmp, "sample.fa")
-            O.lib().orc_synth_write_file(C.byref(P), 0, n, os.fsencode(fa), 2, 0)
-            libf = os.path.join(tmp, "reads.lib")
-            open(libf, "w").write(fa + "\n")
-            js = O.ref_build(libf, k=args.kmer, max_read_len=250, threads=cores, init_hash_size=init,
+    host = "%s, %d logical CPUs on the box, %d visible to this process" % (cpu_model(), os.cpu_count() or 0, visible)
+    sample = "first %d reads of the N=1 workload (%d k-mers), -i %.3f -b 10000" % (n, n * (150 - args.kmer + 1), init)
+
+    def port(threads):
+        bases, offsets = O.synth_reads(P, 0, n)
+        t0 = time.perf_counter()
+        res = O.build_graph(files_mem=[(bases, offsets)], k=args.kmer, threads=threads, init_hash_size=init)
+        dt = time.perf_counter() - t0
+        return {"value": res.total_kmers / dt / 1e6, "unit": "M k-mers/s", "cores": threads, "kind": "port", "host": host,
+                "sample": sample + ", -t %d, reads pre-loaded in memory (no file parsing), wall %.2f s" % (threads, dt)}
+
+    if not O.have_ref():
+        return port(cores), []
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, "sample.fa")
+        O.lib().orc_synth_write_file(C.byref(P), 0, n, os.fsencode(fa), 2, 0)
+        libf = os.path.join(tmp, "reads.lib")
+        open(libf, "w").write(fa + "\n")
+        for threads in dict.fromkeys([cores, min(10, visible)]):  # the box's share, and the reference's default -t 10
+            js = O.ref_build(libf, k=args.kmer, max_read_len=250, threads=threads, init_hash_size=init,
                              buffer_num=10000, fmt=2, timeout=900)
-        return {"value": js["kmers"] / js["wall_s"] / 1e6, "unit": "M k-mers/s", "cores": cores,
-                "kind": "reference", "sample": sample + ", one-line FASTA from local disk, wall %.2f s" % js["wall_s"]}
-    bases, offsets = O.synth_reads(P, 0, n)
-    t0 = time.perf_counter()
-    res = O.build_graph(files_mem=[(bases, offsets)], k=args.kmer, threads=cores, init_hash_size=init)
-    dt = time.perf_counter() - t0
-    return {"value": res.total_kmers / dt / 1e6, "unit": "M k-mers/s", "cores": cores, "kind": "port",
-            "sample": sample + ", reads pre-loaded in memory, wall %.2f s" % dt}
+            out.append({"value": js["kmers"] / js["wall_s"] / 1e6, "unit": "M k-mers/s", "cores": threads, "kind": "reference", "host": host,
+                        "sample": sample + ", -t %d, one-line FASTA from local disk, wall %.2f s" % (threads, js["wall_s"])})
+    out.append(port(cores))
+    return out[0], out[1:]
+
+
+def golden_cfg2(args, world, n_reads, genome_len):
+    """tests/golden/cfg2_full.json (made by the CPU oracle at FULL size) when this run is that workload"""
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_full.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        gold = json.load(fh)
+    if (gold["n_reads"], gold["genome_len"], gold["k"]) != (n_reads, genome_len, args.kmer):
+        return None
+    return gold
 
 
 def main():
@@ -208,28 +242,68 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_kmers / (dt / args.steps) / 1e6
 
+    # ---- after the timed region: correctness of what was just measured, the H2D-inclusive rate ------
+    verified = None
+    gold = golden_cfg2(args, world, n_reads, genome_len) if not (debug_mode or debug_l2) else None
+    if gold is not None and not multi:
+        got = (int(res["count"]), int(res["stored_kmers"]), g.digest(), [int(x) for x in g.link_stats(2).depth_stat])
+        want = (gold["count"], gold["total_kmers"], gold["digest"], gold["depth_stat"])
+        if got != want:
+            sys.exit("bench.py: the graph built in the timed loop differs from tests/golden/cfg2_full.json "
+                     "(count/kmers/digest %r, expected %r)" % (got[:3], want[:3]))
+        verified = "count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (CPU oracle, full size)"
+    value_incl_h2d = None
+    if world == 1 and not multi and not (debug_mode or debug_l2):
+        import numpy as np
+        h_bases = d_bases.to_host(np.uint8, nb)
+        h_off = d_off.to_host(np.uint64)
+        t1 = time.perf_counter()
+        for _ in range(H2D_STEPS):
+            g.reset()
+            g.push_reads(h_bases, h_off)   # pageable host buffers -> pinned staging -> H2D -> kernels (what the CLI does)
+            st2 = g.finalize()
+        g.sync()
+        dt2 = (time.perf_counter() - t1) / H2D_STEPS
+        assert int(st2.count) == int(res["count"])
+        value_incl_h2d = {"value": n_reads * kpr / dt2 / 1e6, "unit": "M k-mers/s", "ms_per_step": dt2 * 1e3, "steps": H2D_STEPS,
+                          "note": "timed from the first host-to-device copy of the read bytes (SURVEY 8(d)); never `value`"}
+
     if rank == 0:
         launches = max(int(tm.insert_launches), 1)
-        kmers_per_launch = n_reads * kpr
-        # Per-launch average of every kernel that touches all k-mers of the step (HIP events on the
-        # library's streams).  The level-2 scatter and the region build run CONCURRENTLY in chunks of
-        # buckets on two streams: their launch durations overlap (each is stretched by the other), so
-        # the window they share is attributed pro rata when the dominant kernel is chosen; the
-        # figures printed per kernel stay the measured launch durations, which is what rocprofv3 shows.
+        kmers_step = n_reads * kpr
+        # Per-kernel figures (HIP events on the library's own streams), each kernel with ITS OWN bytes:
+        # level 1 reads the bases and writes one 8-byte record per k-mer, level 2 reads and writes every
+        # record, the region build reads every record and writes every 16-byte table slot once.
         l1_name = "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else \
                   ("k_extract_scatter_uniform" if tm.uniform_launches else "k_extract_scatter")  # equal-length reads take the former
+        l1_ms = tm.insert_ms / args.steps
         l2_ms, build_ms, wall_ms = tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
-        phase_kernels = {l1_name: tm.insert_ms / launches, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
-        share = wall_ms / (l2_ms + build_ms) if (l2_ms + build_ms) > 0 else 1.0   # < 1 when the two overlap
-        exclusive = {l1_name: phase_kernels[l1_name], "k_scatter_l2": l2_ms * min(share, 1.0), "k_build_regions": build_ms * min(share, 1.0)}
-        dom_kernel = max(exclusive, key=exclusive.get)
+        slots_local = size // world if sharded else size
+        if args.engine == capi.ENGINE_PARTITION:
+            own_bytes = {l1_name: kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * 16.0,
+                         "k_build_regions": kmers_step * 8.0 + slots_local * 16.0}
+            kernel_ms = {l1_name: l1_ms, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
+        else:
+            own_bytes = {l1_name: kmers_step * B_ALG}
+            kernel_ms = {l1_name: l1_ms}
+        kernels = {}
+        for kname, ms in kernel_ms.items():
+            traffic = measured_traffic(args, size, kname)
+            kernels[kname] = {"ms_per_step": ms, "own_bytes_per_step": own_bytes[kname],
+                              "own_GBs": own_bytes[kname] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                              "pmc_traffic_bytes_per_step": traffic,
+                              "pmc_GBs": traffic / (ms * 1e-3) / 1e9 if (traffic and ms > 0) else None}
         chunks = max(int(tm.partition_launches) // max(args.steps, 1), 1)
-        # kernel_ms and kmers_per_launch are PER LAUNCH: the level-2 / build kernels are launched once per bucket chunk
-        per_launch_div = 1 if dom_kernel == l1_name else chunks
-        kern_ms = phase_kernels[dom_kernel] / per_launch_div
-        kmers_per_launch = kmers_per_launch / per_launch_div
-        pipeline_ms = phase_kernels[l1_name] + (wall_ms if wall_ms > 0 else l2_ms + build_ms)
-        achieved = kmers_per_launch * B_ALG / (kern_ms * 1e-3) / 1e9
+        pipeline_ms = l1_ms + (wall_ms if wall_ms > 0 else l2_ms + build_ms)   # kernels only: the concurrent pair at its wall time
+        # THE roofline figure of this path: algorithmic bytes of one step (33.25 B per k-mer) over
+        # the WHOLE step time (ms_per_step: reset, mark, all kernels, finalize), against the 8 TB/s spec peak
+        achieved = kmers_step * B_ALG / (ms_per_step * 1e-3) / 1e9   # per GPU (every rank processes kmers_step per step)
+        copy_bw = None
+        if world == 1:
+            try:
+                copy_bw = g.copy_bandwidth(1 << 30, 10)
+            except Exception as e:  # noqa: BLE001
+                print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
         out = {
             "metric": "M k-mers/s hashed (k=31, 150 bp)", "value": value, "unit": "M k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -242,28 +316,23 @@ def main():
                                        "(all-to-all of level-1 record buckets)" % world) if sharded else
                                       ("reads sharded by record x%d, keys owned by hash (aggregated nodes exchanged)" % world
                                        if world > 1 else "single GPU")},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "whole step: " + " -> ".join(kernel_ms), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else
-                         (lambda t: None if t is None else t / per_launch_div)(measured_traffic(args, size, dom_kernel)),
-                         "traffic_all_kernels": measured_traffic(args, size, None),
-                         "kernel_ms": kern_ms, "bytes_per_kmer": B_ALG,
-                         "kmers_per_launch": kmers_per_launch,
-                         "all_kernels_ms": phase_kernels, "l2_build_wall_ms": wall_ms, "l2_build_chunks": chunks,
-                         "pipeline_frac": n_reads * kpr * B_ALG / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
+                         "bytes_per_kmer": B_ALG, "kmers_per_step": kmers_step, "step_ms": ms_per_step,
+                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, None),
+                         "kernels_only_ms": pipeline_ms, "kernels_only_frac": kmers_step * B_ALG / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "l2_build_wall_ms": wall_ms, "l2_build_chunks": chunks, "kernels": kernels},
             "phases_ms_per_step": {"mark": tm.mark_ms / args.steps, "insert": tm.insert_ms / args.steps,
                                    "partition": tm.partition_ms / args.steps, "build": tm.build_ms / args.steps,
                                    "partition_and_build_wall": tm.l2_build_wall_ms / args.steps,
                                    "merge": tm.fixup_ms / args.steps},
+            "verified": verified, "value_incl_h2d": value_incl_h2d,
         }
         if world == 1:
-            try:
-                out["copy_bandwidth_GBs"] = g.copy_bandwidth(1 << 30, 10)
-            except Exception as e:  # noqa: BLE001
-                out["copy_bandwidth_GBs"] = None
-                print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
+            out["copy_bandwidth_GBs"] = copy_bw
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(args, genome_len)
+                out["cpu_baseline"], out["cpu_baseline_variants"] = cpu_baseline(args, genome_len)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
 

@@ -430,6 +430,33 @@ def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle
     assert res[1][0] == ref.count and np.array_equal(nodes, ref.nodes)
 
 
+def test_full_size_cfg2_bench_workload_equals_the_cpu_oracle(capi):
+    """The FULL BASELINE cfg2 workload with bench.py's exact handle parameters (10 M x 150 bp reads, k = 31,
+    600 000 001-slot table, expected_kmers = 120 per read): node count, k-mer totals, order-independent
+    digest of the node multiset and DepthStat of both engines == tests/golden/cfg2_full.json, which the CPU
+    oracle computed at full size (tests/golden/make_cfg2_full.py)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_full.json")
+    gold = json.load(open(path))
+    n_reads, G = gold["n_reads"], gold["genome_len"]
+    P = capi.synth_params(G, 150, cfg=2)
+    size = capi.find_next_prime_ref(600000000)
+    for engine in (capi.ENGINE_PARTITION, capi.ENGINE_DIRECT):
+        with capi.Graph(k=gold["k"], table_slots=size, max_read_len=250, engine=engine,
+                        expected_kmers=n_reads * 120 if engine == capi.ENGINE_PARTITION else 0) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st = g.finalize()
+            if engine == capi.ENGINE_PARTITION:
+                assert g.timings().uniform_launches == 1  # the kernel the bench times
+            got = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers), int(st.count), g.digest(),
+                   [int(x) for x in g.link_stats(2).depth_stat])
+            d_bases.free()
+            d_off.free()
+        assert got == (gold["total_reads"], gold["total_kmers"], gold["total_kmers"], gold["count"], gold["digest"], gold["depth_stat"]), engine
+
+
 # ------------------------------------------------------------------------------------------------
 # sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
 # device copies.  Validates slot-range ownership end to end on real hardware.
