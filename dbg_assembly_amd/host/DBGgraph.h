@@ -15,6 +15,7 @@
 #include <cmath>
 #include <ctime>
 #include <iostream>
+#include <zlib.h>   // the reference's DBGgraph.h:18 pulls in gzstream.h -> <zlib.h> (-> <unistd.h>: main.cpp's getopt relies on it)
 #include "kmerSet.h"
 #include "seqKmer.h"
 

@@ -1,7 +1,7 @@
 // debruijn_contig -- command line of the graph-construction stage on MI355X.
 //
 // Same options, defaults and positional argument as the reference's DBG_contig/main.cpp:97-124,
-// 166-193 (getopt string "k:r:f:o:t:i:l:e:b:D:T:I:P:W:C:G:B:U:L:E:M:h").  The graph stage
+// 166-193 (getopt string "k:r:f:o:t:i:l:e:b:D:T:I:P:W:C:G:B:U:L:E:M:h"); the help wording is this build's own.  The graph stage
 // (build_debruijn_graph) runs on the GPU.  The contig stage (tip/bubble removal, contig read-out:
 // DBG_contig/contig.cpp) is the reference's unchanged host code and is NOT part of this repository;
 // when this program is linked together with it build_contig_sequence() is
@@ -32,39 +32,42 @@ void build_contig_sequence() __attribute__((weak));  // DBG_contig/contig.h:67, 
 
 static void print_options(ostream &os, bool with_k_max)
 {
-	os << "   -k <int>   set kmer size" << (with_k_max ? ", max 31" : "") << ", default=" << KmerSize << endl
-	   << "   -r <int>   set maximum allowed read length, trimmed if longer, default=" << maxReadLen << endl
-	   << "   -f <int>   set the input file format: 1: fq|gz(one-line), 2: fa|gz(one-line), default=" << Input_file_format << endl
-	   << "   -o <str>   set the output file prefix, default = " << Output_prefix << endl
-	   << "   -t <int>   thread number to run in parallel, default=" << threadNum << endl
-	   << "   -i <float>  set initialization size (uint:G) of the kmer-hash, memory consumption ( * 16 G bytes ), default=" << initHashSize << endl
-	   << "   -l <float>  set loading factor of the kmer hash, default=" << hashLoadFactor << endl
-	   << "   -e <int>  max doubling times of hash size allowed to enlarge memory consumption, default=" << maxDoubleHashTimes << endl
-	   << "   -b <int>  buffer size: number of reads loading into the buffer memory, default=" << BufferNum << endl
-	   << "   -D <int>   delete kmer-links with frequency no larger than, default=" << KmerFreqCutoff << endl
-	   << "   -T <int>   whether cut off tip-branch, 1:yes; 0:no; default=" << is_remove_tip << endl
-	   << "   -I <int>   set the max allowed tip-branch length, default=" << Tip_len_cutoff << endl
-	   << "   -P <float>  set the max allowed tip-branch depth, default=" << Tip_depth_cutoff << endl
-	   << "   -W <int>   wheter cut off low-coverage branch between two branching nodes, 1:yes; 0:no; default=" << is_remove_lowedge << endl
-	   << "   -C <int>    set the max allowed length for low-coverage branch, default=" << LowCovEdge_len_cutoff << endl
-	   << "   -G <float>  set the max allowed depth for low-coverage branch, default=" << LowCovEdge_depth_cutoff << endl
-	   << "   -B <int>   whether cut off the low-coverage branch for pairs of bubble branches, 1:yes; 0:no; default=" << is_remove_bubble << endl
-	   << "   -U <int>   set the max allowed bubble-branch length, default=" << Bubble_len_cutoff << endl
-	   << "   -L <float>   set the max allowed length difference rate between the two bubble-branchess, default=" << Bubble_len_diff_rate_cutoff << endl
-	   << "   -E <float>  set the max allowed base difference rate between the two bubble-branches, default=" << Bubble_base_diff_rate_cutoff << endl
-	   << "   -M <int>    set the minimum length for contig to output, default=" << Contig_len_cutoff << endl;
+	// option letters, argument kinds, defaults and order follow the reference (DBG_contig/main.cpp:97-124); the wording is ours
+	os << "   -k <int>    k-mer length" << (with_k_max ? " (at most 31)" : "") << " [" << KmerSize << "]" << endl
+	   << "   -r <int>    longest read length used; longer reads are cut to this [" << maxReadLen << "]" << endl
+	   << "   -f <int>    input format: 1 = FASTQ, 2 = FASTA, one sequence per line, plain or .gz [" << Input_file_format << "]" << endl
+	   << "   -o <str>    prefix of the output files [" << Output_prefix << "]" << endl
+	   << "   -t <int>    host threads (table zeroing, contig stage; the k-mer work runs on the GPU) [" << threadNum << "]" << endl
+	   << "   -i <float>  initial size of the k-mer hash table in units of 1e9 entries, 16 bytes each [" << initHashSize << "]" << endl
+	   << "   -l <float>  load factor at which the hash table is enlarged [" << hashLoadFactor << "]" << endl
+	   << "   -e <int>    how many times the hash table may double before further input is dropped [" << maxDoubleHashTimes << "]" << endl
+	   << "   -b <int>    reads per block; the table is checked for enlarging after every full block [" << BufferNum << "]" << endl
+	   << "   -D <int>    drop k-mer links seen at most this many times [" << KmerFreqCutoff << "]" << endl
+	   << "   -T <int>    remove tips: 1 = yes, 0 = no [" << is_remove_tip << "]" << endl
+	   << "   -I <int>    longest tip that is removed [" << Tip_len_cutoff << "]" << endl
+	   << "   -P <float>  highest depth of a tip that is removed [" << Tip_depth_cutoff << "]" << endl
+	   << "   -W <int>    remove low-coverage edges between two branching nodes: 1 = yes, 0 = no [" << is_remove_lowedge << "]" << endl
+	   << "   -C <int>    longest low-coverage edge that is removed [" << LowCovEdge_len_cutoff << "]" << endl
+	   << "   -G <float>  highest depth of a low-coverage edge that is removed [" << LowCovEdge_depth_cutoff << "]" << endl
+	   << "   -B <int>    merge bubbles (drop the lower-coverage branch of a pair): 1 = yes, 0 = no [" << is_remove_bubble << "]" << endl
+	   << "   -U <int>    longest bubble branch considered [" << Bubble_len_cutoff << "]" << endl
+	   << "   -L <float>  largest relative length difference of the two branches of a bubble [" << Bubble_len_diff_rate_cutoff << "]" << endl
+	   << "   -E <float>  largest relative base difference of the two branches of a bubble [" << Bubble_base_diff_rate_cutoff << "]" << endl
+	   << "   -M <int>    shortest contig that is written [" << Contig_len_cutoff << "]" << endl;
 }
 
 static void usage()
 {
 	cout << "\ndebruijn_contig   <reads_file.lib>\n"
-	     << "   \nFunction: build the k-mer de Bruijn graph of the reads on an AMD MI355X GPU (graph stage of the\n"
-	     << "   DBG_assembly contig builder) and hand it to the contig stage\n" << endl
-	     << "   Verion: 1.0 (gfx950)\n" << endl;
+	     << "   \nBuilds the k-mer de Bruijn graph of the reads listed in <reads_file.lib> (one path per line) on an\n"
+	     << "   AMD MI355X GPU -- the graph stage of the DBG_assembly contig builder -- and passes it to the contig stage\n" << endl
+	     << "   Version: 1.0 (gfx950)\n" << endl;
 	print_options(cout, true);
-	cout << "   -h         get the help information" << endl << endl
+	cout << "   -h          this help" << endl << endl
 	     << "   environment: DBGK_DEVICE=<gpu ordinal>  DBGK_BATCH_MB=<host batch size>  DBGK_DUMP=<file: sorted node dump>" << endl
-	     << "                DBGK_LAYOUT=ref  lay the hash table out slot for slot like `debruijn_contig -t 1` of the reference" << endl
+	     << "                DBGK_ENGINE=1|2   1 = global-atomic insert, 2 = partitioned records + LDS-built table regions (default)" << endl
+	     << "                DBGK_STORE_KMERS=<n>  k-mer occurrences the partitioned engine holds before merging them into the table" << endl
+	     << "                DBGK_LAYOUT=ref   lay the hash table out slot for slot like `debruijn_contig -t 1` of the reference" << endl
 	     << "\nExample: \ndebruijn_contig  -k 31 -r 250  -t 10  -i 0.1  -M 125 -o Ecoli reads_files.lib   2> reads_files.debruijn_contig.log \n" << endl;
 	exit(0);
 }

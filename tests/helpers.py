@@ -7,6 +7,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# `<prefix>.contig.kmer.freq` (DBG_contig/contig.cpp:199-202): header line, then DepthStat[1..255]
+KMER_FREQ_HEADER = "Kmer_depth\tAppear_times"
+KMER_FREQ_ROWS = 255
+
 
 def dump_text(nodes, total_reads, total_kmers, count):
     """Render the canonical dump exactly as oracle/ref_driver.cpp prints it."""
