@@ -16,7 +16,7 @@
 // Counting runs on the GPU (KFREQ engine of include/dbgk.h): every k-mer window of every read, N
 // counted as A (correct_error/ReadMe.txt), canonical = min(forward, reverse complement).
 //
-// usage: kmerfreq [-k 17] [-f 1|2] [-b 1|8] [-m cutoff] [-t threads] [-o prefix] <reads.lib>
+// usage: kmerfreq [-k 17] [-f 1|2] [-b 1|8] [-m cutoff] [-t threads] [-o prefix] [-e store size | -a] <reads.lib>
 //        output: <prefix>.kmer.freq.cz, <prefix>.kmer.freq.cz.len   (prefix defaults to <reads.lib>)
 #include <unistd.h>
 #include <zlib.h>
@@ -53,7 +53,8 @@ int main(int argc, char **argv)
 	string prefix;
 	int c;
 	unsigned long long expected = 0;
-	while ((c = getopt(argc, argv, "k:f:b:m:t:o:q:r:e:h")) != -1) {
+	bool atomics = false;
+	while ((c = getopt(argc, argv, "k:f:b:m:t:o:q:r:e:ah")) != -1) {
 		switch (c) {
 			case 'k': k = atoi(optarg); break;
 			case 'f': fmt = atoi(optarg); break;
@@ -63,11 +64,13 @@ int main(int argc, char **argv)
 			case 'o': prefix = optarg; break;
 			case 'r': max_read_len = atoi(optarg); break;
 			case 'e': expected = strtoull(optarg, NULL, 10); break;
+			case 'a': atomics = true; break;
 			case 'q': break;  // quality cutoff of the original tool: accepted, sequences carry no qualities here
 			default:
 				cout << "\nkmerfreq [-k 17] [-f 1:fq|2:fa] [-b 1|8 bit table] [-m cutoff, 1-bit: mark k-mers seen more than this, default 1]"
-				     << " [-t threads] [-o prefix] [-e expected number of k-mers: counts through the partitioned engine,"
-				     << " 2.6x faster, all occurrences (8 bytes each) must fit the GPU's memory] <reads.lib>\n" << endl;
+				     << " [-t threads] [-o prefix] [-e k-mer occurrences the partitioned counting engine holds before it merges"
+				     << " them into the table (default: the input size, at most 2^30)] [-a count with atomics on the table instead]"
+				     << " <reads.lib>\n" << endl;
 				return 0;
 		}
 	}
@@ -83,7 +86,27 @@ int main(int argc, char **argv)
 	cfg.engine = DBGK_ENGINE_KFREQ;
 	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
 	cfg.max_batch_bases = (128ull << 20) + 65536;
-	cfg.expected_kmers = expected; // 0: atomics on the byte table, any input size
+	// partitioned counting (occurrences radix-partitioned by hash, aggregated per key in LDS; input of any size
+	// streams through the record store in rounds) unless -a asks for atomics on the byte table
+	if (!atomics && expected == 0) {
+		uint64_t bound = 0;
+		bool known = true;
+		ifstream probe(lib.c_str());
+		for (string path; getline(probe, path);) {
+			if (path.empty()) continue;
+			FILE *fp = fopen(path.c_str(), "rb");
+			if (!fp) continue;
+			unsigned char magic[2] = {0, 0};
+			const bool gz = fread(magic, 1, 2, fp) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+			fseek(fp, 0, SEEK_END);
+			const long sz = ftell(fp);
+			fclose(fp);
+			if (gz || sz < 0) known = false; else bound += (uint64_t)sz;
+		}
+		expected = known && bound ? min<uint64_t>(bound, 1ull << 30) : (1ull << 30);
+		if (expected < 1024) expected = 1024;
+	}
+	cfg.expected_kmers = atomics ? 0 : expected;
 	dbgk_handle *h = nullptr;
 	int rc = dbgk_create(&cfg, &h);
 	if (rc) die("dbgk_create", rc);

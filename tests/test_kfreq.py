@@ -108,7 +108,7 @@ def test_kmerfreq_tool_files_load_like_the_reference(oracle, tmp_path, k, fmt):
     rc = oracle.revcomp_values(idx, k).astype(np.int64)
     for bits_fmt, cutoff in ((1, 1), (8, 10)):
         prefix = str(tmp_path / ("out%d" % bits_fmt))
-        extra = ["-e", "300000"] if bits_fmt == 8 else []  # the 8-bit run counts through the partitioned engine
+        extra = ["-e", "30000"] if bits_fmt == 8 else ["-a"]  # 8-bit run: partitioned counting through a small store (many rounds); 1-bit: atomics
         r = subprocess.run([TOOL, "-k", str(k), "-f", str(fmt), "-b", str(bits_fmt), "-m", str(cutoff), "-t", "4", "-o", prefix] + extra + [lib],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
@@ -128,3 +128,104 @@ def test_kmerfreq_tool_files_load_like_the_reference(oracle, tmp_path, k, fmt):
         if oracle.have_ref_kfreq():  # and through the real reference loader (the binary travels with the repo)
             got_ref, _ = oracle.ref_kfreq_load(cz, k, one_bit=(bits_fmt == 1), threads_or_cutoff=(3 if bits_fmt == 1 else cutoff))
             assert np.array_equal(got_ref, got)
+
+
+# ---- BASELINE cfg4 at its stated size: k = 17, 4^17 = 17 179 869 184 counters (16 GiB) --------------------
+# Counting semantics are THIS BUILD'S (the reference's producer, `kmerfreq`, is not in its repository:
+# "counting parity unpinned"): every window of every read, N as A, canonical = min(forward,
+# reverse complement), saturating byte.  What is checked: the device table against a SPARSE restatement built
+# from the pinned extraction (oracle.parse_read), and the files against the reference's REAL loaders.
+K17 = 17
+
+
+def _sparse_counts(oracle, bases, offsets, k):
+    """-> (sorted distinct canonical k-mers, min(255, occurrences)) from the oracle's per-read extraction"""
+    raw = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+    parts = []
+    for i in range(len(offsets) - 1):
+        km, _, _ = oracle.parse_read(raw[int(offsets[i]):int(offsets[i + 1])], k, 1000)   # (reads are 150 bases: never trimmed)
+        parts.append(km)
+    allk = np.concatenate(parts)
+    uniq, cnt = np.unique(allk, return_counts=True)
+    return uniq.astype(np.uint64), np.minimum(cnt, 255).astype(np.uint8), len(allk)
+
+
+@pytest.fixture(scope="module")
+def cfg4_sample(oracle):
+    n_reads = 120000   # first reads of the cfg2/cfg4 generator workload: 16.1 M windows at k = 17
+    PO = oracle.synth_params(50_000_000, 150, cfg=2)
+    bases, offsets = oracle.synth_reads(PO, 0, n_reads)
+    uniq, cnt, total = _sparse_counts(oracle, bases, offsets, K17)
+    return n_reads, bases, offsets, uniq, cnt, total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["atomics", "partitioned", "partitioned_small_store"])
+def test_kfreq_engine_k17_16GiB_table_equals_sparse_restatement(oracle, cfg4_sample, mode):
+    from dbg_assembly_amd import capi
+    n_reads, bases, offsets, uniq, cnt, total = cfg4_sample
+    expected = {"atomics": 0, "partitioned": total, "partitioned_small_store": total // 5}[mode]
+    P = capi.synth_params(50_000_000, 150, cfg=2)
+    with capi.Graph(k=K17, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=expected) as g:
+        pieces = 4   # several device pushes: the small store flushes in between
+        per = n_reads // pieces
+        bufs = []
+        for i in range(pieces):
+            d_bases, d_off, nb = g.synth_reads_device(P, i * per, per)
+            if i == 0:
+                assert np.array_equal(d_bases.to_host(np.uint8, nb), bases[:nb])
+            g.push_reads_device(d_bases.ptr, d_off.ptr, per, nb)
+            bufs += [d_bases, d_off]
+        st = g.finalize()
+        assert (int(st.count), int(st.stored_kmers)) == (len(uniq), total)
+        span = 1 << 30   # the 16 GiB table is read back and checked in 1 GiB slices (indices above 2^32 included)
+        for first in range(0, 4 ** K17, span):
+            got = g.kfreq_counts(first, span)
+            lo, hi = np.searchsorted(uniq, [first, first + span])
+            assert int(np.count_nonzero(got)) == hi - lo, first
+            assert np.array_equal(got[(uniq[lo:hi] - np.uint64(first)).astype(np.int64)], cnt[lo:hi]), first
+        # the bit table of the 1-bit format, last eighth (byte offsets beyond 2^31)
+        fb = 7 * (4 ** K17 // 8) // 8
+        bits = g.kfreq_bits(1, fb, 4 ** K17 // 8 - fb)
+        lo = np.searchsorted(uniq, fb * 8)
+        want_pos = uniq[lo:][cnt[lo:] > 1] - np.uint64(fb * 8)
+        assert int(np.bitwise_count(bits).sum()) == len(want_pos)
+        assert np.all(bits[(want_pos >> np.uint64(3)).astype(np.int64)] & (np.uint8(128) >> (want_pos & np.uint64(7)).astype(np.uint8)))
+        for b in bufs:
+            b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits_fmt,cutoff", [(1, 1), (8, 2)])
+def test_kmerfreq_tool_k17_2048_blocks_through_the_reference_loaders(oracle, cfg4_sample, tmp_path, bits_fmt, cutoff):
+    """`kmerfreq -k 17`: 2048 blocks like test/01.clean_correct/clean_reads.lib.kmer.freq.cz.len, loaded by the
+    reference's own loaders (correct_error/main_parallel_senior.cpp:334-408, main.cpp:161-220) to exactly the
+    bit table the sparse restatement predicts (v and rc(v) set for every k-mer above the cutoff)."""
+    if not oracle.have_ref_kfreq():
+        pytest.skip("oracle/_ref loaders did not travel")
+    n_reads, bases, offsets, uniq, cnt, total = cfg4_sample
+    fa = str(tmp_path / "reads.fa")
+    n_used = 40000
+    raw = np.ascontiguousarray(bases[:int(offsets[n_used])]).tobytes()
+    with open(fa, "wb") as fh:
+        for i in range(n_used):
+            fh.write(b">r\n" + raw[int(offsets[i]):int(offsets[i + 1])] + b"\n")
+    lib = str(tmp_path / "reads.lib")
+    open(lib, "w").write(fa + "\n")
+    uniq, cnt, total = _sparse_counts(oracle, bases[:int(offsets[n_used])], offsets[:n_used + 1], K17)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([TOOL, "-k", str(K17), "-f", "2", "-b", str(bits_fmt), "-m", str(cutoff), "-t", "16", "-o", prefix, lib],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    cz = prefix + ".kmer.freq.cz"
+    assert len(open(cz + ".len").read().split()) == 2048
+    got, js = oracle.ref_kfreq_load(cz, K17, one_bit=(bits_fmt == 1), threads_or_cutoff=(8 if bits_fmt == 1 else cutoff), timeout=900)
+    hi = uniq[cnt > cutoff]
+    want_pos = np.unique(np.concatenate([hi, oracle.revcomp_values(hi, K17)]))
+    assert len(got) == 4 ** K17 // 8
+    assert int(np.bitwise_count(got).sum()) == len(want_pos)
+    assert np.all(got[(want_pos >> np.uint64(3)).astype(np.int64)] & (np.uint8(128) >> (want_pos & np.uint64(7)).astype(np.uint8)))
+    if bits_fmt == 1:
+        assert js["hifreq"] == len(hi)   # the file marks canonical k-mers only; the loader mirrors them
+    else:
+        assert (js["kmers"], js["effect"]) == (int(cnt.astype(np.int64).sum()), len(uniq))
