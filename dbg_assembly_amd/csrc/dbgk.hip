@@ -356,10 +356,12 @@ static int plan_partition(dbgk_handle *h)
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
 	while (r > 20 && qbits + (int)r + 6 > 64 && ((h->size + (1ull << (r - 1)) - 1) >> (r - 1)) <= (uint64_t)kMaxBuckets) r--; // small tables: q needs the bits
-	const bool feasible = (r - kRegionBits) <= 10 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26) && h->size < (1ull << 32);
+	// level 1 fans out to <= 1024 buckets, level 2 to 2^(r-12) <= 4096 final buckets per level-1 bucket: 2^34 slots
+	const bool feasible = (1u << (r - kRegionBits)) <= (uint32_t)kMaxBucketsL2 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26) &&
+	                      h->size < (1ull << 34);
 	if (!feasible || (want_shard && want == DBGK_ENGINE_DIRECT)) {
 		if (want == DBGK_ENGINE_PARTITION || want_shard) {
-			g_last_error = "PARTITION engine (and any sharded handle) needs 2^26 <= table_slots < 2^32";
+			g_last_error = "PARTITION engine (and any sharded handle) needs 2^26 <= table_slots < 2^34";
 			return DBGK_ERR_ARG;
 		}
 		return DBGK_OK;
@@ -373,7 +375,7 @@ static int plan_partition(dbgk_handle *h)
 	PartGeom &G = h->geom;
 	G.size = h->size;
 	G.magic = h->magic;
-	G.div = make_div32_magic((uint32_t)h->size);
+	if (h->size < (1ull << 32)) G.div = make_div32_magic((uint32_t)h->size);
 	G.r = r;
 	G.n1 = (uint32_t)((h->size + (1ull << r) - 1) >> r);
 	G.n2 = 1u << (r - kRegionBits);
@@ -440,25 +442,28 @@ static int setup_partition(dbgk_handle *h)
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	h->store_capacity = expected;
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, false, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter_uniform<0, true, 15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(UniformLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_extract_scatter<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter_l2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLdsL2)));
+#define DBGK_LDS_ATTR(KERNEL, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+#define DBGK_UNIFORM_ATTRS(W)                                                  \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true>), sizeof(UniformLds));  \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, true>), sizeof(UniformLds));  \
+	DBGK_LDS_ATTR((k_extract_scatter<true, 0, W>), sizeof(ScatterLds));              \
+	DBGK_LDS_ATTR((k_extract_scatter<false, 0, W>), sizeof(ScatterLds))
+	DBGK_UNIFORM_ATTRS(0);
+	DBGK_UNIFORM_ATTRS(1);
+	DBGK_UNIFORM_ATTRS(2);
+#undef DBGK_UNIFORM_ATTRS
+	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_extract_scatter<false, 3>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_scatter_l2<0>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<1>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<2>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<0, 2048>), sizeof(ScatterLdsL2T<2048>));
+	DBGK_LDS_ATTR((k_scatter_l2<0, 4096>), sizeof(ScatterLdsL2T<4096>));
+#undef DBGK_LDS_ATTR
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
@@ -832,28 +837,36 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
-		const bool wide = h->geom.size >= (1ull << 31), ragged = umode == 2;
+		const int wide = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
+		const bool ragged = umode == 2;
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-		if (wide && c15 && ragged) DBGK_LAUNCH_UNIFORM(true, 15, true);
-		else if (wide && c15) DBGK_LAUNCH_UNIFORM(true, 15, false);
-		else if (wide && ragged) DBGK_LAUNCH_UNIFORM(true, 16, true);
-		else if (wide) DBGK_LAUNCH_UNIFORM(true, 16, false);
-		else if (c15 && ragged) DBGK_LAUNCH_UNIFORM(false, 15, true);
-		else if (c15) DBGK_LAUNCH_UNIFORM(false, 15, false);
-		else if (ragged) DBGK_LAUNCH_UNIFORM(false, 16, true);
-		else DBGK_LAUNCH_UNIFORM(false, 16, false);
+#define DBGK_LAUNCH_UNIFORM_W(WIDE)                                    \
+	do {                                                               \
+		if (c15 && ragged) DBGK_LAUNCH_UNIFORM(WIDE, 15, true);        \
+		else if (c15) DBGK_LAUNCH_UNIFORM(WIDE, 15, false);            \
+		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);          \
+		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
+	} while (0)
+		if (wide == 2) DBGK_LAUNCH_UNIFORM_W(2);
+		else if (wide == 1) DBGK_LAUNCH_UNIFORM_W(1);
+		else DBGK_LAUNCH_UNIFORM_W(0);
+#undef DBGK_LAUNCH_UNIFORM_W
 #undef DBGK_LAUNCH_UNIFORM
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-		const bool wide_d = h->geom.size >= (1ull << 31); // divisor needs the 2-by-1 division steps
-		if (wide_d && has_long)
-			hipLaunchKernelGGL((k_extract_scatter<true, 0, true>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		const int wide_d = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
+		if (wide_d == 2 && has_long)
+			hipLaunchKernelGGL((k_extract_scatter<true, 0, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (wide_d == 2)
+			hipLaunchKernelGGL((k_extract_scatter<false, 0, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+		else if (wide_d && has_long)
+			hipLaunchKernelGGL((k_extract_scatter<true, 0, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (wide_d)
-			hipLaunchKernelGGL((k_extract_scatter<false, 0, true>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+			hipLaunchKernelGGL((k_extract_scatter<false, 0, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode == 1)
 			hipLaunchKernelGGL((k_extract_scatter<false, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode == 2)
@@ -1064,7 +1077,12 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 template <int DBG>
 static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 {
-	hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+	if (h->geom.n2 > 2048u) // tables of 2^33 slots and more
+		hipLaunchKernelGGL((k_scatter_l2<0, 4096>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<4096>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+	else if (h->geom.n2 > (uint32_t)kMaxBuckets) // 2^32 .. 2^33 slots
+		hipLaunchKernelGGL((k_scatter_l2<0, 2048>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<2048>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+	else
+		hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 }
 
 template <int DBG>

@@ -20,6 +20,8 @@
 // is not stored: it is recomputed from (q, slot) once per DISTINCT node when the region is emitted.
 #pragma once
 
+#include <type_traits>
+
 #include "dbgk_kernels.h"
 
 namespace dbgk {
@@ -64,11 +66,11 @@ struct PartGeom {
 	ModMagic magic;
 	uint32_t r;          // level-1 bucket = slot >> r
 	uint32_t n1;         // ceil(size / 2^r)            <= kMaxBuckets
-	uint32_t n2;         // 2^(r - 12)                  <= kMaxBuckets
+	uint32_t n2;         // 2^(r - 12)                  <= kMaxBucketsL2
 	uint32_t n_final;    // ceil(size / 4096)
 	uint64_t cap1;       // records per level-1 bucket
 	uint64_t cap2;       // records per final bucket
-	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h)
+	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h); larger tables divide by `magic`
 	// sharding (multi-GPU): `size` is the GLOBAL table; this handle owns the level-1 buckets
 	// [b_lo, b_lo + nb_own) = the contiguous slot range [slot_lo, slot_hi) and holds only that
 	// part of the table.  n_ranks == 1: b_lo = 0, nb_own = n1, the whole table.
@@ -158,15 +160,21 @@ __device__ __forceinline__ uint32_t fresh_tid()
 }
 
 // ---- workgroup-wide bucket scatter of up to 16 records per thread ------------------------------
-template <int THREADS>
+// MAXB: fan-out limit of the level (histogram size).  Level 1 always has <= 1024 buckets; level 2 has
+// n2 = 2^(r - 12) <= 1024 for tables below 2^32 slots and 2048 / 4096 for tables up to 2^33 / 2^34 slots
+// (kernels instantiated per MAXB, chosen at launch).  FLAT (level 2): the copy-out needs only the global
+// base of a bucket (32 bits); the wave-per-bucket copy-out of level 1 reads a 64-bit descriptor.
+template <int THREADS, int MAXB = kMaxBuckets, bool FLAT_DESC = false>
 struct ScatterLdsT {
 	static constexpr int kThreads = THREADS;           // workgroup size
 	static constexpr int kRecords = THREADS * 16;      // records staged per tile
-	static constexpr int kBpt = kMaxBuckets / THREADS; // histogram entries owned by one thread
+	static constexpr int kMaxB = MAXB;
+	static constexpr int kBpt = MAXB / THREADS;        // histogram entries owned by one thread
+	using Desc = typename std::conditional<FLAT_DESC, uint32_t, uint64_t>::type;
 	uint64_t stage[kRecords];
-	uint32_t hist[kMaxBuckets + 64]; // + one dummy bin per lane (level 1: positions that yield no record)
-	uint32_t lbase[kMaxBuckets];
-	uint64_t desc[kMaxBuckets];      // copy-out descriptor per bucket (scatter_stage_copy)
+	uint32_t hist[MAXB + 64];        // + one dummy bin per lane (level 1: positions that yield no record)
+	uint32_t lbase[MAXB];
+	Desc desc[MAXB];                 // copy-out descriptor per bucket (scatter_stage_copy)
 	uint32_t wave_tot[THREADS / 64];
 };
 using ScatterLds = ScatterLdsT<kTileThreads>;   // level 1: 16384-record tiles, one workgroup per CU
@@ -174,7 +182,10 @@ using ScatterLds = ScatterLdsT<kTileThreads>;   // level 1: 16384-record tiles, 
 #define DBGK_L2_THREADS 512
 #endif
 constexpr int kL2Threads = DBGK_L2_THREADS;
-using ScatterLdsL2 = ScatterLdsT<kL2Threads>;
+constexpr int kL2Records = kL2Threads * 16;
+template <int MAXB> using ScatterLdsL2T = ScatterLdsT<kL2Threads, MAXB, true>;
+using ScatterLdsL2 = ScatterLdsL2T<kMaxBuckets>;
+constexpr int kMaxBucketsL2 = 4096;             // largest level-2 fan-out (tables below 2^34 slots)
 
 // exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries LDS::kBpt*t .. LDS::kBpt*t+LDS::kBpt-1
 template <class LDS>
@@ -237,14 +248,16 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 	const int t = (int)fresh_tid();
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) {
-		if ((br[u] >> 16) < (uint32_t)kMaxBuckets) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
+		if ((br[u] >> 16) < (uint32_t)LDS::kMaxB) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
 		if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four lbase reads in flight are enough; more costs VGPRs the callers do not have
 	}
 	// one descriptor per bucket for the copy-out: global offset | records in this tile | first staged index
+	// (FLAT: the global offset alone; lbase is read next to it)
 #pragma unroll
 	for (int j = 0; j < LDS::kBpt; j++) {
 		const uint32_t b = LDS::kBpt * t + j;
-		L.desc[b] = ((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b];
+		if (FLAT) L.desc[b] = (typename LDS::Desc)my_gbase[j];
+		else L.desc[b] = (typename LDS::Desc)(((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b]);
 	}
 	lds_barrier();
 	if (FLAT) {
@@ -256,8 +269,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				if (p >= total) continue;
 				const uint64_t rcd = L.stage[p];
 				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits)) & (n_buckets - 1u);
-				const uint64_t d = L.desc[b];
-				const uint64_t off = (d >> 32) + (p - ((uint32_t)d & 0xFFFFu));
+				const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
 				if (DBG == 3) {
 					out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + off) & 4095ull)] = rcd;
 				} else if (off < cap) {
@@ -278,7 +290,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 	constexpr uint32_t kWaves = LDS::kThreads / 64;
 	const uint32_t per_wave = (DBG == 2) ? 0u : (n_buckets + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * k < n_buckets
 	const uint32_t mine = wave + kWaves * lane;
-	const uint64_t d = (lane < per_wave) ? L.desc[mine] : 0ull; // per_wave <= kMaxBuckets / kWaves = 64
+	const uint64_t d = (lane < per_wave) ? (uint64_t)L.desc[mine] : 0ull; // per_wave <= kMaxBuckets / kWaves = 64
 	const uint32_t d_lo = (uint32_t)d, d_hi = (uint32_t)(d >> 32);
 	// (Unrolling this loop by four so that the staged runs are read back to back was measured slower:
 	// 7.2 / 6.9 ms against 7.1 / 6.4 ms for level 1 / level 2.)
@@ -483,7 +495,9 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // parked in the (still unused) stage buffer, column i of this thread, and ranked right away with an LDS
 // histogram atomic (bkt[i] = (bucket << 16) | rank).  Returns true when some canonical k-mer of the lane
 // is 0 (poly-A / poly-T): rare, the caller then feeds the key-0 side node.
-template <bool WIDE_D, int NPOS = 16>
+// WIDE_D: how hash / size is computed -- 0: size < 2^31 (one multiply-high with a 32-bit remainder fix-up), 1: size < 2^32
+// (two 2-by-1 division steps), 2: any size (64-bit multiply-high by floor(2^64 / size), 64-bit remainder)
+template <int WIDE_D, int NPOS = 16>
 __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
 {
@@ -509,8 +523,15 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 		rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit NPOS - 1 - i
 		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 		uint64_t q;
-		const uint32_t slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q)
-		                             : divmod_magic_small(hash_code(key), G.magic.m, (uint32_t)G.magic.d, q);
+		uint32_t slot, bucket; // slot: its low 32 bits (r <= 24 of them are recorded); bucket = slot >> r
+		if (WIDE_D == 2) {
+			const uint64_t s64 = fast_divmod(hash_code(key), G.magic, q);
+			slot = (uint32_t)s64;
+			bucket = (uint32_t)(s64 >> G.r);
+		} else {
+			slot = WIDE_D ? divmod_u64_u32(hash_code(key), G.div, q) : divmod_magic_small(hash_code(key), G.magic.m, (uint32_t)G.magic.d, q);
+			bucket = slot >> G.r;
+		}
 		// only one packed register per position stays live across the tile
 		const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
 		const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
@@ -519,7 +540,7 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 		const bool valid = (c.valid >> i) & 1u;
 		const bool zero = key == 0ull;
 		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
-		const uint32_t b = (valid && !zero) ? (slot >> G.r) : (uint32_t)kMaxBuckets + (tid & 63u);
+		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kMaxBuckets + (tid & 63u);
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 		// roll to the next position (DBGgraph.cpp:71-73)
 		c.kbit = ((c.kbit << 2) | right) & head_mask;
@@ -555,7 +576,7 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 }
 
-template <bool HAS_DEAD, int DBG = 0, bool WIDE_D = false>
+template <bool HAS_DEAD, int DBG = 0, int WIDE_D = 0>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -665,7 +686,7 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // longest read of the batch, L holds its length), a read's own offset and length come from `offsets`, and
 // the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
 // length -- the host compares n_reads * Q * C lane slots with the n_bases positions of the flat kernel.
-template <int DBG = 0, bool WIDE_D = false, int C = 16, bool RAGGED = false>
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
@@ -815,7 +836,7 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 		const uint32_t entry = e < n_entries ? flat_to_entry(G, e, own_j) : 0u;
 		if (e < n_entries && own_j < G.nb_own) {
 			const uint64_t filled = P.inbox_cnt[entry] < G.cap1 ? P.inbox_cnt[entry] : G.cap1;
-			v = (uint32_t)((filled + ScatterLdsL2::kRecords - 1) / ScatterLdsL2::kRecords);
+			v = (uint32_t)((filled + kL2Records - 1) / kL2Records);
 		}
 		uint32_t inc = v;
 #pragma unroll
@@ -854,7 +875,7 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	const uint32_t e = flat_to_entry(G, lo, own_j);
 	b1_out = own_j; // own bucket index j
 	const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
-	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * ScatterLdsL2::kRecords;
+	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records;
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
 #pragma unroll
@@ -864,12 +885,12 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	}
 }
 
-template <int DBG = 0>
+template <int DBG = 0, int MAXB = kMaxBuckets>
 __global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
                                                              Counters *__restrict__ ctr, uint32_t j0, uint32_t j1)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	ScatterLdsL2 &L = *reinterpret_cast<ScatterLdsL2 *>(lds_raw);
+	ScatterLdsL2T<MAXB> &L = *reinterpret_cast<ScatterLdsL2T<MAXB> *>(lds_raw);
 	const uint32_t first_tile = tile_prefix[j0 * G.n_ranks * G.n_sub], n_tiles = tile_prefix[j1 * G.n_ranks * G.n_sub]; // tiles of the own buckets [j0, j1)
 	// XCD-aware tile order: workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
 	// correctness), so XCD x takes the x-th eighth of the tile range -- whole level-1 buckets -- and every

@@ -51,7 +51,7 @@ int DbgkLastStatus = 0;
 namespace {
 
 const uint64_t kPartitionMinSlots = 67108879;   // smallest table the PARTITION engine takes (2^26 slots), a prime above it
-const uint64_t kPartitionMaxSlots = 4290772992ull; // 2^32 - 2^22
+const uint64_t kPartitionMaxSlots = (1ull << 34) - (1ull << 24); // the engine's geometry: < 2^34 slots
 
 struct Session {
 	dbgk_handle *h = nullptr;

@@ -586,6 +586,36 @@ def test_tables_of_2_31_slots_and_more_use_the_wide_divisor_path(capi, oracle):
     assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
 
 
+@pytest.mark.parametrize("slots,n_shards", [(4_400_000_000, 0), (8_700_000_000, 0), (8_700_000_000, 2), (4_400_000_000, 3)])
+def test_tables_of_2_32_slots_and_more(capi, oracle, slots, n_shards):
+    """BASELINE cfg3 needs one table of ~2^33 slots (5.6 G nodes); the reference's KmerSet.size is a
+    uint64_t that doubles up to 2^10 times (kmerSet.h:90, DBGgraph.cpp:337-343).  Above 2^32 slots hash / size is a
+    64-bit multiply-high, slot indices need more than 32 bits and level 2 fans out to 2048 / 4096 final buckets
+    per level-1 bucket (up to 2^34 slots).  Single handle (70 and 139 GB tables: level-2 fan-out 2048 and 4096) and two shards of one 2^33-slot
+    table on one GPU; streaming flush in between (the incremental region build at the wide geometry)."""
+    rng = random.Random(slots % 1000)
+    reads = rand_reads(rng, 6000, G=40000) + [b"A" * 150] * 100
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.002)
+    size = capi.find_next_prime_ref(slots)
+    assert size >= 1 << 32
+    if n_shards == 0:
+        with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=1_000_000) as g:
+            half = len(reads) // 2
+            g.push_reads(bases[:int(offsets[half])], offsets[:half + 1])
+            g.flush()
+            g.push_reads(bases[int(offsets[half]):], offsets[half:] - offsets[half])
+            st = g.finalize()
+            assert st.count == ref.count and st.total_kmers == ref.total_kmers
+            assert np.array_equal(g.export_sorted(), ref.nodes)
+            assert g.digest() == oracle.nodes_digest(ref.nodes)
+    else:
+        final, stats, nodes, infos, _, _, size2 = _sharded_build(capi, oracle, reads, n_shards, 600000, slots=slots, want_tables=False)
+        assert size2 == size and infos[-1].slot_hi == size and infos[1].slot_lo >= 1 << 32
+        assert sum(int(s.count) for s in final) == ref.count
+        assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
+
+
 def test_sharded_table_with_overflow_and_heavy_repeats(capi, oracle):
     """tiny bucket capacities force overflow observations; a heavily repeated read saturates counters
     across shards"""
