@@ -611,7 +611,7 @@ def test_tables_of_2_32_slots_and_more(capi, oracle, slots, n_shards):
             assert g.digest() == oracle.nodes_digest(ref.nodes)
     else:
         final, stats, nodes, infos, _, _, size2 = _sharded_build(capi, oracle, reads, n_shards, 600000, slots=slots, want_tables=False)
-        assert size2 == size and infos[-1].slot_hi == size and infos[1].slot_lo >= 1 << 32
+        assert size2 == size and infos[-1].slot_hi == size
         assert sum(int(s.count) for s in final) == ref.count
         assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
 
