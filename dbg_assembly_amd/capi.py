@@ -108,9 +108,21 @@ SYMBOLS = [
     ("dbgk_shard_build_range", _i, [_vp, C.c_uint32, C.c_uint32]),
     ("dbgk_shard_outgoing", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("dbgk_shard_overflow", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("dbgk_shard_heavy", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("dbgk_shard_merge", _i, [_vp, _vp, _u64, _i, _i]),
     ("dbgk_add_polyA", _i, [_vp, C.c_uint32, C.c_uint32]),
     ("dbgk_memcpy_d2d", _i, [_vp, _vp, _vp, C.c_size_t]),
+    ("dbgk_comm_create", _i, [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
+    ("dbgk_comm_destroy", _i, [_vp]),
+    ("dbgk_comm_size", C.c_uint32, [_vp]),
+    ("dbgk_comm_handle", _vp, [_vp, C.c_uint32]),
+    ("dbgk_comm_push_reads", _i, [_vp, _vp, _vp, _u64]),
+    ("dbgk_comm_flush", _i, [_vp]),
+    ("dbgk_comm_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_comm_finalize", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_comm_digest", _i, [_vp, C.POINTER(_u64)]),
+    ("dbgk_comm_link_stats", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
+    ("dbgk_comm_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_synth_reads_device", _i, [_vp, C.POINTER(SynthParams), _u64, _u64, _vp, _vp]),
     ("dbgk_device_malloc", _i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("dbgk_device_free", _i, [_vp, _vp]),
@@ -363,6 +375,11 @@ class Graph:
         _chk(lib().dbgk_shard_overflow(self._h, C.byref(p), C.byref(n)), "dbgk_shard_overflow")
         return p.value, n.value
 
+    def shard_heavy(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().dbgk_shard_heavy(self._h, C.byref(p), C.byref(n)), "dbgk_shard_heavy")
+        return p.value, n.value
+
     def shard_merge(self, d_nodes, n, is_triple=False, from_previous_shard=False):
         _chk(lib().dbgk_shard_merge(self._h, d_nodes, n, int(is_triple), int(from_previous_shard)), "dbgk_shard_merge")
 
@@ -397,6 +414,68 @@ class Graph:
         g = C.c_double()
         _chk(lib().dbgk_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "dbgk_measure_copy_bandwidth")
         return g.value
+
+
+class Comm:
+    """N sharded handles of one table inside this process (dbgk_comm_*): the C++ host layer's multi-GPU path."""
+
+    def __init__(self, k, table_slots, devices, max_read_len=250, expected_kmers=0, max_batch_bases=0):
+        self._c = None
+        cfg = Config(k, max_read_len, table_slots, 0, ENGINE_PARTITION, max_batch_bases, expected_kmers, 0, 0, 0)
+        dev = (C.c_int32 * len(devices))(*devices)
+        c = C.c_void_p()
+        _chk(lib().dbgk_comm_create(C.byref(cfg), dev, len(devices), C.byref(c)), "dbgk_comm_create")
+        self._c = c
+        self.k = k
+        self.table_slots = table_slots
+        self.stats = None
+
+    def close(self):
+        if self._c:
+            lib().dbgk_comm_destroy(self._c)
+            self._c = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def push_reads(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(lib().dbgk_comm_push_reads(self._c, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "dbgk_comm_push_reads")
+
+    def flush(self):
+        _chk(lib().dbgk_comm_flush(self._c), "dbgk_comm_flush")
+
+    def refresh_stats(self):
+        st = Stats()
+        _chk(lib().dbgk_comm_refresh_stats(self._c, C.byref(st)), "dbgk_comm_refresh_stats")
+        return st
+
+    def finalize(self):
+        st = Stats()
+        _chk(lib().dbgk_comm_finalize(self._c, C.byref(st)), "dbgk_comm_finalize")
+        self.stats = st
+        return st
+
+    def digest(self):
+        d = C.c_uint64()
+        _chk(lib().dbgk_comm_digest(self._c, C.byref(d)), "dbgk_comm_digest")
+        return d.value
+
+    def link_stats(self, cutoff=2):
+        st = LinkStats()
+        _chk(lib().dbgk_comm_link_stats(self._c, cutoff, C.byref(st)), "dbgk_comm_link_stats")
+        return st
+
+    def export_host_table(self, host_size=None):
+        size = self.table_slots if host_size is None else host_size
+        array = np.zeros(size, dtype=NODE_DTYPE)
+        flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+        _chk(lib().dbgk_comm_export_host_table(self._c, size, array.ctypes.data, flags.ctypes.data), "dbgk_comm_export_host_table")
+        return array, flags
 
 
 # ---- host helpers mirrored from the reference (kmerSet.cpp:72-95), needed to size tables ---------

@@ -432,13 +432,11 @@ static int setup_partition(dbgk_handle *h)
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		return DBGK_ERR_NOMEM;
 	}
-	P.hh = nullptr;
-	P.hh_size = 0;
-	if (!h->sharded) {
-		if (hipMalloc(&P.hh, kHeavyHitterSlots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
-		P.hh_size = kHeavyHitterSlots;
-		P.hh_magic = make_mod_magic(kHeavyHitterSlots);
-	}
+	// side table for the surplus of heavy hitters; on a sharded handle it may hold keys of any shard and is
+	// offered to every rank after the build (dbgk_shard_heavy), like the overflow list
+	if (hipMalloc(&P.hh, kHeavyHitterSlots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	P.hh_size = kHeavyHitterSlots;
+	P.hh_magic = make_mod_magic(kHeavyHitterSlots);
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	h->store_capacity = expected;
@@ -1893,6 +1891,7 @@ static int shard_list(dbgk_handle *h, Node *list, unsigned long long *d_n, uint6
 	HIPCHK(hipStreamSynchronize(h->stream));
 	*d_nodes = reinterpret_cast<dbgk_node *>(list);
 	*n = v < cap ? v : cap;
+	if (list == h->store.ovf) return DBGK_OK; // the surplus beyond the list was aggregated in the side table (dbgk_shard_heavy)
 	return v > cap ? DBGK_ERR_CAPACITY : DBGK_OK;
 }
 
@@ -1906,6 +1905,20 @@ extern "C" int dbgk_shard_overflow(dbgk_handle *h, dbgk_node **d_triples, uint64
 {
 	if (!h) return DBGK_ERR_ARG;
 	return shard_list(h, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, d_triples, n);
+}
+
+extern "C" int dbgk_shard_heavy(dbgk_handle *h, dbgk_node **d_table, uint64_t *n_slots)
+{
+	if (!h || !d_table || !n_slots) return DBGK_ERR_ARG;
+	if (!h->part || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, &h->store.ovf_n[0], 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	*d_table = reinterpret_cast<dbgk_node *>(h->store.hh);
+	*n_slots = (h->store.hh && v > h->store.ovf_cap) ? h->store.hh_size : 0; // unused unless the overflow list ran full
+	return DBGK_OK;
 }
 
 extern "C" int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n, int is_triple, int from_previous_shard)
@@ -2078,3 +2091,8 @@ extern "C" int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int ite
 	*gbps = (2.0 * (double)bytes * iters) / (ms * 1e-3) / 1e9; // bytes read + bytes written
 	return DBGK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// several GPUs in one process
+// ---------------------------------------------------------------------------------------------
+#include "dbgk_comm.h"

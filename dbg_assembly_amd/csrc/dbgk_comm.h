@@ -1,0 +1,453 @@
+// dbgk_comm.h -- several GPUs inside ONE process: N sharded handles of one global table, the exchange done with
+// peer copies over xGMI (hipMemcpyPeerAsync), driven by a single host thread.  Included at the end of dbgk.hip.
+//
+// This is what the C++ host layer uses for DBGK_GPUS=N (host/DBGgraph.cpp); bench.py's one-process-per-GPU flow
+// over RCCL (dbg_assembly_amd/multigpu.py: sharded_finalize) follows the same protocol with collectives.  The
+// ownership rule is the reference's per-thread one (`kmer % threadNum`, DBG_contig/DBGgraph.cpp:148) turned into
+// slot ranges: reads shard by record, every rank level-1-partitions its k-mer records by GLOBAL slot range,
+// rank d owns the level-1 buckets [d*B, (d+1)*B) and builds only that part of the table.
+//
+//   flush / finalize:
+//     1. bucket fill counts  s -> d              (tiny)
+//     2. level-1 record buckets of d's slot range, from every s, in pieces of buckets: the copy of piece j+1
+//        (copy stream of d) overlaps level 2 + region build of piece j (the handle's two streams)
+//     3. every shard builds its slot range (incremental when the table already holds nodes)
+//     4. hand-offs, normally empty: overflow observations and the heavy-hitter side tables are offered to every
+//        shard, nodes that probed past the end of a shard continue at the start of the next one
+//     5. finalize only: key-0 links folded onto shard 0, totals summed
+#pragma once
+
+struct dbgk_comm {
+	std::vector<dbgk_handle *> h;
+	std::vector<hipStream_t> copy_stream;      // per destination handle
+	std::vector<std::vector<hipEvent_t>> ev;   // per destination handle: piece arrived
+	std::vector<hipEvent_t> cnt_ev;            // per destination handle: fill counts arrived
+	std::vector<uint64_t> delivered;           // per handle: outgoing nodes already handed to the next shard
+	uint32_t next_push = 0;
+	uint32_t pieces = 8;
+	bool finalized = false;
+};
+
+static int comm_copy(dbgk_handle *dst, void *d_dst, dbgk_handle *src, const void *d_src, size_t bytes, hipStream_t stream)
+{
+	if (bytes == 0) return DBGK_OK;
+	if (dst->device == src->device) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, stream));
+	else HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, stream));
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_destroy(dbgk_comm *c)
+{
+	if (!c) return DBGK_ERR_ARG;
+	for (size_t i = 0; i < c->h.size(); i++) {
+		if (!c->h[i]) continue;
+		(void)hipSetDevice(c->h[i]->device);
+		if (i < c->copy_stream.size() && c->copy_stream[i]) {
+			(void)hipStreamSynchronize(c->copy_stream[i]);
+			(void)hipStreamDestroy(c->copy_stream[i]);
+		}
+		if (i < c->ev.size())
+			for (hipEvent_t e : c->ev[i]) (void)hipEventDestroy(e);
+		if (i < c->cnt_ev.size() && c->cnt_ev[i]) (void)hipEventDestroy(c->cnt_ev[i]);
+		free_handle(c->h[i]);
+	}
+	delete c;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, uint32_t n, dbgk_comm **out)
+{
+	if (!cfg || !devices || !out || n < 1 || n > 64) return DBGK_ERR_ARG;
+	*out = nullptr;
+	dbgk_comm *c = new (std::nothrow) dbgk_comm();
+	if (!c) return DBGK_ERR_NOMEM;
+	c->h.assign(n, nullptr);
+	c->copy_stream.assign(n, nullptr);
+	c->ev.assign(n, {});
+	c->cnt_ev.assign(n, nullptr);
+	c->delivered.assign(n, 0);
+	if (const char *e = getenv("DBGK_COMM_PIECES")) c->pieces = (uint32_t)std::max(1, atoi(e));
+	for (uint32_t i = 0; i < n; i++) {
+		dbgk_config one = *cfg;
+		one.device_id = devices[i];
+		one.engine = DBGK_ENGINE_PARTITION;
+		one.shard_count = n;
+		one.shard_index = i;
+		int rc = dbgk_create(&one, &c->h[i]);
+		if (rc == DBGK_OK && hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking) != hipSuccess) rc = DBGK_ERR_HIP;
+		if (rc == DBGK_OK && hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess) rc = DBGK_ERR_HIP;
+		if (rc != DBGK_OK) {
+			dbgk_comm_destroy(c);
+			return rc;
+		}
+	}
+	for (uint32_t i = 0; i < n; i++) // peer access between distinct devices (already enabled is fine)
+		for (uint32_t j = 0; j < n; j++)
+			if (devices[i] != devices[j]) {
+				(void)hipSetDevice(devices[i]);
+				const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+					(void)hipGetLastError();
+					g_last_error = "hipDeviceEnablePeerAccess failed: the GPUs of a communicator must be peers";
+					dbgk_comm_destroy(c);
+					return DBGK_ERR_HIP;
+				}
+				(void)hipGetLastError();
+			}
+	*out = c;
+	return DBGK_OK;
+}
+
+extern "C" uint32_t dbgk_comm_size(const dbgk_comm *c) { return c ? (uint32_t)c->h.size() : 0; }
+extern "C" dbgk_handle *dbgk_comm_handle(dbgk_comm *c, uint32_t i) { return (c && i < c->h.size()) ? c->h[i] : nullptr; }
+
+// steps 1-4 of the header comment on every shard
+static int comm_exchange_and_build(dbgk_comm *c)
+{
+	const uint32_t n = (uint32_t)c->h.size();
+	int rc;
+	for (dbgk_handle *h : c->h) { // every rank's level-1 store is complete
+		rc = dbgk_sync(h);
+		if (rc) return rc;
+	}
+	const PartGeom &G0 = c->h[0]->geom;
+	const uint64_t bucket_bytes = (uint64_t)G0.n_sub * G0.cap1 * 8, chunk_bytes = (uint64_t)G0.B * bucket_bytes;
+	const uint64_t cnt_chunk_bytes = (uint64_t)G0.B * G0.n_sub * 4;
+	for (dbgk_handle *h : c->h)
+		if (h->geom.cap1 != G0.cap1 || h->geom.B != G0.B || h->geom.size != G0.size) {
+			g_last_error = "dbgk_comm: the shards do not share one bucket geometry";
+			return DBGK_ERR_STATE;
+		}
+	// 1. fill counts
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		rc = use_device(D);
+		if (rc) return rc;
+		for (uint32_t s = 0; s < n; s++) {
+			dbgk_handle *S = c->h[s];
+			rc = comm_copy(D, reinterpret_cast<char *>(D->inbox_cnt) + s * cnt_chunk_bytes, S,
+			               reinterpret_cast<const char *>(S->store.cnt1) + d * cnt_chunk_bytes, cnt_chunk_bytes, c->copy_stream[d]);
+			if (rc) return rc;
+		}
+		HIPCHK(hipEventRecord(c->cnt_ev[d], c->copy_stream[d]));
+	}
+	// 2. the record buckets, piece by piece; all copies are queued up front
+	const uint32_t pieces = std::max(1u, std::min(c->pieces, G0.B));
+	const uint32_t per = (G0.B + pieces - 1) / pieces;
+	std::vector<std::pair<uint32_t, uint32_t>> ranges;
+	for (uint32_t j0 = 0; j0 < G0.B; j0 += per) ranges.push_back({j0, std::min(j0 + per, G0.B)});
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		rc = use_device(D);
+		if (rc) return rc;
+		while (c->ev[d].size() < ranges.size()) {
+			hipEvent_t e;
+			HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			c->ev[d].push_back(e);
+		}
+		for (size_t p = 0; p < ranges.size(); p++) {
+			const uint64_t off = (uint64_t)ranges[p].first * bucket_bytes, len = (uint64_t)(ranges[p].second - ranges[p].first) * bucket_bytes;
+			for (uint32_t s = 0; s < n; s++) {
+				dbgk_handle *S = c->h[s];
+				rc = comm_copy(D, reinterpret_cast<char *>(D->inbox) + s * chunk_bytes + off, S,
+				               reinterpret_cast<const char *>(S->store.l1) + d * chunk_bytes + off, len, c->copy_stream[d]);
+				if (rc) return rc;
+			}
+			HIPCHK(hipEventRecord(c->ev[d][p], c->copy_stream[d]));
+		}
+	}
+	// 3. plan + build, piece by piece as the records arrive
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		rc = use_device(D);
+		if (rc) return rc;
+		HIPCHK(hipStreamWaitEvent(D->stream, c->cnt_ev[d], 0));
+		rc = part_plan(D);
+		if (rc) return rc;
+	}
+	for (size_t p = 0; p < ranges.size(); p++)
+		for (uint32_t d = 0; d < n; d++) {
+			dbgk_handle *D = c->h[d];
+			rc = use_device(D);
+			if (rc) return rc;
+			HIPCHK(hipStreamWaitEvent(D->stream, c->ev[d][p], 0));
+			const uint32_t own0 = std::min(ranges[p].first, D->geom.nb_own), own1 = std::min(ranges[p].second, D->geom.nb_own);
+			if (own1 > own0) {
+				rc = part_build_range(D, own0, own1, true);
+				if (rc) return rc;
+			}
+		}
+	for (dbgk_handle *D : c->h) {
+		rc = use_device(D);
+		if (rc) return rc;
+		D->exchanged = true;
+		rc = build_from_records(D); // joins the streams, merges the shard's own spill nodes
+		if (rc) return rc;
+	}
+	for (uint32_t d = 0; d < n; d++) {
+		rc = use_device(c->h[d]);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(c->h[d]->stream));
+		HIPCHK(hipStreamSynchronize(c->copy_stream[d]));
+	}
+	// 4. hand-offs.  A list of rank s is merged straight from s's memory when s and d share a device, through a
+	// scratch copy otherwise.
+	auto offer = [&](dbgk_handle *S, const Node *list, uint64_t count, int is_triple, int from_prev, dbgk_handle *D) -> int {
+		if (count == 0) return DBGK_OK;
+		int r = use_device(D);
+		if (r) return r;
+		const Node *src = list;
+		Node *scratch = nullptr;
+		if (S->device != D->device) {
+			if (hipMalloc(&scratch, count * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+			r = comm_copy(D, scratch, S, list, count * sizeof(Node), D->stream);
+			src = scratch;
+		}
+		if (r == DBGK_OK) {
+			hipLaunchKernelGGL(k_merge_sharded, dim3(grid_for(D, count)), dim3(kBlock), 0, D->stream, src, (const unsigned long long *)nullptr, count, count,
+			                   is_triple, from_prev, D->geom, D->store, D->table, D->d_ctr);
+			if (hipGetLastError() != hipSuccess) r = DBGK_ERR_HIP;
+		}
+		if (hipStreamSynchronize(D->stream) != hipSuccess) r = DBGK_ERR_HIP;
+		if (scratch) (void)hipFree(scratch);
+		return r;
+	};
+	auto read_u64 = [&](dbgk_handle *H, const unsigned long long *d_ptr, uint64_t &v) -> int {
+		int r = use_device(H);
+		if (r) return r;
+		unsigned long long x = 0;
+		HIPCHK(hipMemcpyAsync(&x, d_ptr, 8, hipMemcpyDeviceToHost, H->stream));
+		HIPCHK(hipStreamSynchronize(H->stream));
+		v = x;
+		return DBGK_OK;
+	};
+	for (uint32_t s = 0; s < n; s++) { // overflow observations (and, beyond the list, the side table) of rank s: every rank keeps its own
+		dbgk_handle *S = c->h[s];
+		uint64_t v = 0;
+		rc = read_u64(S, &S->store.ovf_n[0], v);
+		if (rc) return rc;
+		const uint64_t n_list = std::min<uint64_t>(v, S->store.ovf_cap);
+		for (uint32_t d = 0; d < n; d++) {
+			rc = offer(S, S->store.ovf, n_list, 1, 0, c->h[d]);
+			if (rc) return rc;
+			if (v > S->store.ovf_cap && S->store.hh) {
+				rc = offer(S, S->store.hh, S->store.hh_size, 0, 0, c->h[d]);
+				if (rc) return rc;
+			}
+		}
+	}
+	std::fill(c->delivered.begin(), c->delivered.end(), 0);
+	for (uint32_t round = 0; round <= n; round++) { // nodes that ran off the end of shard s continue in shard s+1 (and, rarely, further)
+		bool any = false;
+		for (uint32_t s = 0; s < n; s++) {
+			dbgk_handle *S = c->h[s];
+			uint64_t v = 0;
+			rc = read_u64(S, S->store.outgoing_n, v);
+			if (rc) return rc;
+			if (v > S->store.outgoing_cap) {
+				g_last_error = "dbgk_comm: more nodes left a shard than its hand-over list holds (table nearly full?)";
+				return DBGK_ERR_CAPACITY;
+			}
+			if (v > c->delivered[s]) {
+				rc = offer(S, S->store.outgoing + c->delivered[s], v - c->delivered[s], 0, 1, c->h[(s + 1) % n]);
+				if (rc) return rc;
+				c->delivered[s] = v;
+				any = true;
+			}
+		}
+		if (!any) break;
+		if (round == n) {
+			g_last_error = "dbgk_comm: handed-over nodes went round all shards without finding a slot (table full)";
+			return DBGK_ERR_TABLE_FULL;
+		}
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_flush(dbgk_comm *c)
+{
+	if (!c || c->finalized) return DBGK_ERR_STATE;
+	bool pending = false;
+	for (dbgk_handle *h : c->h) pending = pending || h->pending_kmers > 0;
+	if (!pending) return DBGK_OK;
+	int rc = comm_exchange_and_build(c);
+	if (rc) return rc;
+	for (dbgk_handle *h : c->h) {
+		rc = use_device(h);
+		if (rc) return rc;
+		rc = read_counters(h); // surfaces capacity / table-full conditions of this round
+		if (rc) return rc;
+		if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+		if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY;
+		h->incr = true;
+		rc = clear_record_store(h);
+		if (rc) return rc;
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+	if (!c || !offsets) return DBGK_ERR_ARG;
+	if (c->finalized) return DBGK_ERR_STATE;
+	dbgk_handle *h = c->h[c->next_push];
+	uint64_t windows = 0;
+	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
+	for (uint64_t i = 0; i < n_reads; i++) {
+		const uint64_t len = offsets[i + 1] - offsets[i], rl = len > max_len ? max_len : len;
+		if (rl >= K) windows += rl - K + 1;
+	}
+	if (h->pending_kmers > 0 && h->pending_kmers + windows > h->store_capacity) { // this rank's store is full: everybody exchanges and builds
+		int rc = dbgk_comm_flush(c);
+		if (rc) return rc;
+	}
+	c->next_push = (c->next_push + 1) % (uint32_t)c->h.size();
+	return dbgk_push_reads(h, bases, offsets, n_reads);
+}
+
+static void comm_sum_stats(dbgk_comm *c, dbgk_stats *out)
+{
+	memset(out, 0, sizeof *out);
+	for (dbgk_handle *h : c->h) {
+		dbgk_stats st;
+		fill_stats(h, &st);
+		out->total_reads += st.total_reads;
+		out->total_kmers += st.total_kmers;
+		out->stored_kmers += st.stored_kmers;
+		out->count += st.count; // only shard 0 counts the key-0 node
+		out->count_conflict += st.count_conflict;
+	}
+	out->table_slots = c->h[0]->size;
+	const Counters &c0 = *c->h[0]->h_ctr;
+	out->polyA_l_link = (uint32_t)(c0.polyA_links & 0xFFFFFFFFu);
+	out->polyA_r_link = (uint32_t)(c0.polyA_links >> 32);
+}
+
+extern "C" int dbgk_comm_refresh_stats(dbgk_comm *c, dbgk_stats *out)
+{
+	if (!c || !out) return DBGK_ERR_ARG;
+	for (dbgk_handle *h : c->h) {
+		int rc = use_device(h);
+		if (rc) return rc;
+		rc = read_counters(h);
+		if (rc) return rc;
+	}
+	comm_sum_stats(c, out);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_finalize(dbgk_comm *c, dbgk_stats *out)
+{
+	if (!c) return DBGK_ERR_ARG;
+	if (c->finalized) return DBGK_ERR_STATE;
+	int rc = comm_exchange_and_build(c);
+	if (rc) return rc;
+	for (dbgk_handle *h : c->h) {
+		rc = use_device(h);
+		if (rc) return rc;
+		rc = read_counters(h);
+		if (rc) return rc;
+		h->finalized = true;
+		h->pending_kmers = 0;
+		if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+		if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY;
+	}
+	// 5. the key-0 node lives on shard 0
+	for (size_t s = 1; s < c->h.size(); s++) {
+		const unsigned long long links = c->h[s]->h_ctr->polyA_links;
+		if (links) {
+			rc = dbgk_add_polyA(c->h[0], (uint32_t)(links & 0xFFFFFFFFu), (uint32_t)(links >> 32));
+			if (rc) return rc;
+		}
+	}
+	rc = use_device(c->h[0]);
+	if (rc) return rc;
+	rc = read_counters(c->h[0]);
+	if (rc) return rc;
+	c->finalized = true;
+	if (out) comm_sum_stats(c, out);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_digest(dbgk_comm *c, uint64_t *digest)
+{
+	if (!c || !digest) return DBGK_ERR_ARG;
+	if (!c->finalized) return DBGK_ERR_STATE;
+	uint64_t sum = 0;
+	for (dbgk_handle *h : c->h) {
+		uint64_t d = 0;
+		int rc = dbgk_digest(h, &d);
+		if (rc) return rc;
+		sum += d;
+	}
+	*digest = sum;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_link_stats(dbgk_comm *c, int32_t cutoff, dbgk_link_stats *out)
+{
+	if (!c || !out) return DBGK_ERR_ARG;
+	if (!c->finalized) return DBGK_ERR_STATE;
+	memset(out, 0, sizeof *out);
+	for (dbgk_handle *h : c->h) {
+		dbgk_link_stats one;
+		int rc = dbgk_link_stats_device(h, cutoff, &one);
+		if (rc) return rc;
+		for (int i = 0; i < 256; i++) out->depth_stat[i] += one.depth_stat[i];
+		out->total_nodes += one.total_nodes;
+		out->deleted_lowfreq += one.deleted_lowfreq;
+		out->linear_nodes += one.linear_nodes;
+		out->tip_nodes += one.tip_nodes;
+		out->branch_nodes += one.branch_nodes;
+	}
+	return DBGK_OK;
+}
+
+// The host KmerSet of the whole job.  host_size == the global table size: the shards ARE pieces of that table,
+// their slices are copied side by side (slot ranges start at multiples of 2^r >= 2^20: byte-aligned in nul_flag) and
+// the key-0 node is put on key 0's probe chain (add_node_to_kmerset, kmerSet.cpp:253-273).  Any other size: every
+// node is re-seated on the host by linear probing (the reference's own insert rule, DBGgraph.cpp:167-205).
+extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
+{
+	if (!c || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
+	if (!c->finalized) return DBGK_ERR_STATE;
+	dbgk_stats tot;
+	comm_sum_stats(c, &tot);
+	if (tot.count > host_size) return DBGK_ERR_TABLE_FULL;
+	auto set_flag = [&](uint64_t i) { nul_flag[i >> 3] |= (uint8_t)(128u >> (i & 7u)); };
+	auto flag_set = [&](uint64_t i) { return (nul_flag[i >> 3] & (uint8_t)(128u >> (i & 7u))) != 0; };
+	const uint64_t global = c->h[0]->size;
+	if (host_size == global) {
+		for (dbgk_handle *h : c->h) {
+			const uint64_t lo = h->geom.slot_lo, len = h->tslots;
+			std::vector<uint8_t> fl(len / 8 + 1);
+			int rc = dbgk_export_host_table(h, len, array + lo, fl.data());
+			if (rc) return rc;
+			memcpy(nul_flag + lo / 8, fl.data(), (len + 7) / 8); // the last shard ends the table: its spare bits are zero
+		}
+	} else {
+		memset(array, 0, host_size * sizeof(dbgk_node));
+		memset(nul_flag, 0, host_size / 8 + 1);
+		for (dbgk_handle *h : c->h) {
+			const uint64_t len = h->tslots;
+			std::vector<dbgk_node> part(len);
+			std::vector<uint8_t> fl(len / 8 + 1);
+			int rc = dbgk_export_host_table(h, len, part.data(), fl.data());
+			if (rc) return rc;
+			for (uint64_t i = 0; i < len; i++) {
+				if (part[i].kmer == 0) continue;
+				uint64_t hc = hash_code(part[i].kmer) % host_size;
+				while (flag_set(hc)) hc = (hc + 1 == host_size) ? 0 : hc + 1;
+				array[hc] = part[i];
+				set_flag(hc);
+			}
+		}
+	}
+	uint64_t hc = hash_code(0ull) % host_size; // the key-0 node: first slot without a flag on key 0's chain
+	while (flag_set(hc)) hc = (hc + 1 == host_size) ? 0 : hc + 1;
+	array[hc].kmer = 0;
+	array[hc].l_link = tot.polyA_l_link;
+	array[hc].r_link = tot.polyA_r_link;
+	set_flag(hc);
+	return DBGK_OK;
+}

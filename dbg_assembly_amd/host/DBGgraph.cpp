@@ -54,7 +54,8 @@ const uint64_t kPartitionMinSlots = 67108879;   // smallest table the PARTITION 
 const uint64_t kPartitionMaxSlots = (1ull << 34) - (1ull << 24); // the engine's geometry: < 2^34 slots
 
 struct Session {
-	dbgk_handle *h = nullptr;
+	dbgk_handle *h = nullptr;              // one GPU
+	dbgk_comm *comm = nullptr;             // DBGK_GPUS=N / DBGK_GPU_LIST: N sharded handles of one table (always PARTITION)
 	std::vector<char> bases;          // sequences of the pending batch, back to back
 	std::vector<uint64_t> offsets;    // offsets.size() == reads in batch + 1
 	uint64_t batch_limit = 128ull << 20;
@@ -103,10 +104,10 @@ inline float clamped_load_factor()
 void exact_count(Session &S)
 {
 	if (S.status != DBGK_OK) return;
-	int rc = S.partition ? dbgk_flush(S.h) : DBGK_OK;
+	int rc = S.comm ? dbgk_comm_flush(S.comm) : (S.partition ? dbgk_flush(S.h) : DBGK_OK);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_flush");
 	dbgk_stats st;
-	rc = dbgk_refresh_stats(S.h, &st);
+	rc = S.comm ? dbgk_comm_refresh_stats(S.comm, &st) : dbgk_refresh_stats(S.h, &st);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_refresh_stats");
 	S.count_known = st.count - 1;   // st.count includes the key-0 node, which the reference adds last (DBGgraph.cpp:418)
 	S.bound_since = 0;
@@ -123,6 +124,10 @@ void reserve_device_slots(Session &S)
 	if (S.status != DBGK_OK) return;
 	const double need = (double)S.count_known + (double)S.bound_since;
 	if (need <= 0.80 * (double)S.device_slots) return;
+	if (S.comm) { // the global table of a communicator is sized once, from the input size
+		cerr << "\nAlert message: the device table of " << S.device_slots << " entries is too small for this input; use a larger -i" << endl;
+		return fail(S, DBGK_ERR_TABLE_FULL, "multi-GPU table");
+	}
 	const uint64_t target = find_next_prime((uint64_t)(need / 0.55) + 16);
 	int rc = dbgk_resize_table(S.h, target);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_resize_table");
@@ -140,7 +145,8 @@ void flush_batch(Session &S)
 	}
 	reserve_device_slots(S);
 	if (S.status == DBGK_OK) {
-		int rc = dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
+		int rc = S.comm ? dbgk_comm_push_reads(S.comm, S.bases.data(), S.offsets.data(), n_reads)
+		                : dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
 		if (rc != DBGK_OK) fail(S, rc, "dbgk_push_reads");
 	}
 	Total_reads_num += n_reads;
@@ -265,6 +271,7 @@ static void release_session()
 {
 	if (!g_session) return;
 	if (g_session->h) dbgk_destroy(g_session->h);
+	if (g_session->comm) dbgk_comm_destroy(g_session->comm);
 	delete g_session;
 	g_session = nullptr;
 }
@@ -340,8 +347,32 @@ void build_debruijn_graph(vector<string> &reads_files)
 	}
 	if (S->ref_layout) cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
-	int rc = dbgk_create(&cfg, &S->h);
-	if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
+	// several GPUs: DBGK_GPUS=N (devices 0..N-1) or DBGK_GPU_LIST=a,b,c (ordinals, repeats allowed)
+	std::vector<int32_t> devices;
+	if (const char *lst = getenv("DBGK_GPU_LIST")) {
+		for (const char *p = lst; *p;) {
+			devices.push_back((int32_t)strtol(p, const_cast<char **>(&p), 10));
+			while (*p == ',' || *p == ' ') p++;
+		}
+	} else if (const char *ng = getenv("DBGK_GPUS")) {
+		for (int i = 0; i < atoi(ng); i++) devices.push_back(i);
+	}
+	int rc;
+	if (devices.size() > 1 && S->partition) {
+		// ONE table over all GPUs, sized once: every k-mer window could be a new node (plain files: their size
+		// bounds the windows; compressed input: 2^32 entries unless -i asks for more)
+		const uint64_t bound = input_size_bound(reads_files);
+		const uint64_t want_slots = bound ? (uint64_t)((double)bound / 0.75) : (1ull << 32);
+		S->device_slots = find_next_prime(std::min(std::max(S->device_slots, want_slots), kPartitionMaxSlots));
+		cfg.table_slots = S->device_slots;
+		cfg.expected_kmers = std::max<uint64_t>(cfg.expected_kmers / devices.size(), 1024); // per handle
+		rc = dbgk_comm_create(&cfg, devices.data(), (uint32_t)devices.size(), &S->comm);
+		if (rc != DBGK_OK) fail(*S, rc, "dbgk_comm_create");
+		else cerr << "k-mer table of " << S->device_slots << " entries over " << devices.size() << " GPU shards" << endl;
+	} else {
+		rc = dbgk_create(&cfg, &S->h);
+		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
+	}
 
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
 	cerr << "The initialization memory used:  " << initHashSize * 16 << " G" << endl;
@@ -353,7 +384,8 @@ void build_debruijn_graph(vector<string> &reads_files)
 		cerr << "\nStart to parse reads file: " << reads_files[i] << endl;
 		if (S->status == DBGK_OK) parse_one_reads_file(reads_files[i]);
 		dbgk_stats st;
-		if (S->status == DBGK_OK && dbgk_refresh_stats(S->h, &st) == DBGK_OK) Kmer_total_num = st.total_kmers;
+		if (S->status == DBGK_OK && (S->comm ? dbgk_comm_refresh_stats(S->comm, &st) : dbgk_refresh_stats(S->h, &st)) == DBGK_OK)
+			Kmer_total_num = st.total_kmers;
 		cerr << "\nTotal number of reads loaded into memory: " << Total_reads_num << endl;
 		cerr << "Total number of kmers loaded into memory: " << Kmer_total_num << endl;
 		time_end = clock();
@@ -364,7 +396,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 	dbgk_stats st;
 	memset(&st, 0, sizeof st);
 	if (S->status == DBGK_OK) {
-		rc = dbgk_finalize(S->h, &st);
+		rc = S->comm ? dbgk_comm_finalize(S->comm, &st) : dbgk_finalize(S->h, &st);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
 	}
 	KmerSet *result = NULL;
@@ -401,7 +433,8 @@ void build_debruijn_graph(vector<string> &reads_files)
 				free(array), free(nul), free(del);
 				fail(*S, DBGK_ERR_NOMEM, "host table allocation");
 			} else {
-				rc = dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
+				rc = S->comm ? dbgk_comm_export_host_table(S->comm, use_size, reinterpret_cast<dbgk_node *>(array), nul)
+				             : dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
 				if (rc != DBGK_OK) {
 					free(array), free(nul), free(del);
 					fail(*S, rc, "dbgk_export_host_table");
@@ -427,9 +460,10 @@ int write_kmer_freq_file(const string &path, int kmer_freq_cutoff)
 {
 	// `<prefix>.contig.kmer.freq` of the consumer's first pass (contig.cpp:186-203): header, then
 	// rows 1..255 of DepthStat (row 0 is not written).  Computed on the device table.
-	if (!g_session || !g_session->h || g_session->status != DBGK_OK) return DBGK_ERR_STATE;
+	if (!g_session || (!g_session->h && !g_session->comm) || g_session->status != DBGK_OK) return DBGK_ERR_STATE;
 	dbgk_link_stats ls;
-	int rc = dbgk_link_stats_device(g_session->h, kmer_freq_cutoff, &ls);
+	int rc = g_session->comm ? dbgk_comm_link_stats(g_session->comm, kmer_freq_cutoff, &ls)
+	                         : dbgk_link_stats_device(g_session->h, kmer_freq_cutoff, &ls);
 	if (rc != DBGK_OK) return rc;
 	ofstream out(path.c_str());
 	if (!out) {

@@ -278,6 +278,21 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
             if ovf_sizes[src]:
                 g.shard_merge(lists[src].data_ptr(), int(ovf_sizes[src]), is_triple=True)
         g.sync()
+    # the surplus of heavy hitters (beyond a rank's overflow list) sits aggregated in its side table: rare, broadcast whole
+    p_hh, n_hh = g.shard_heavy()
+    sizes = torch.tensor([n_hh], dtype=torch.int64, device=device)
+    hh_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(hh_sizes, sizes, group=group)
+    hh_sizes = torch.stack(hh_sizes).cpu().numpy()[:, 0]
+    for src in range(world):
+        if hh_sizes[src]:
+            nbytes = int(hh_sizes[src]) * NODE_BYTES
+            buf = wrap_device_memory(p_hh, nbytes, device).clone() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
+            dist.broadcast(buf, src=src, group=group)
+            if on_gpu:
+                torch.cuda.synchronize()
+            g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))
+            g.sync()
     p_out, n_out = g.shard_outgoing()
     sizes = torch.tensor([n_out], dtype=torch.int64, device=device)
     out_sizes = [torch.zeros_like(sizes) for _ in range(world)]

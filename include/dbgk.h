@@ -308,6 +308,10 @@ int dbgk_shard_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1);
  * {kmer, lb | rb << 8}; the lists stay valid until the next dbgk_reset                            */
 int dbgk_shard_outgoing(dbgk_handle *h, dbgk_node **d_nodes, uint64_t *n);
 int dbgk_shard_overflow(dbgk_handle *h, dbgk_node **d_triples, uint64_t *n);
+/* once the overflow list is full, further observations are aggregated in a side table of n_slots nodes
+ * (empty slots are all-zero); n_slots = 0 when it was not needed.  Like the overflow list it may hold keys
+ * of any shard: offer it to every rank with dbgk_shard_merge(..., is_triple = 0, from_previous_shard = 0)   */
+int dbgk_shard_heavy(dbgk_handle *h, dbgk_node **d_table, uint64_t *n_slots);
 /* merge nodes (is_triple = 0) or observations (is_triple = 1) held in device memory of this GPU:
  * entries whose home slot lies in another shard are ignored unless from_previous_shard is set,
  * in which case they continue their probe at this shard's first slot                            */
@@ -315,6 +319,34 @@ int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n, int i
 /* fold another handle's key-0 node into this one (per-byte saturating add)                      */
 int dbgk_add_polyA(dbgk_handle *h, uint32_t l_link, uint32_t r_link);
 int dbgk_memcpy_d2d(dbgk_handle *h, void *d_dst, const void *d_src, size_t bytes);
+
+/* ---- several GPUs inside one process (the C++ host layer with DBGK_GPUS=N) ------------------------
+ * A communicator owns n sharded handles of ONE table of cfg->table_slots slots (shard i on devices[i]; the
+ * same device may appear more than once -- n shards on one GPU, which is how the tests exercise the path).
+ * cfg->expected_kmers sizes the record store of EACH handle; engine, shard_count and shard_index of cfg are
+ * set by the call.  Reads shard by record (dbgk_comm_push_reads deals batches round robin), k-mers are owned
+ * by slot range -- the device analogue of the reference's `kmer % threadNum` ownership
+ * (DBG_contig/DBGgraph.cpp:148).  flush / finalize move every level-1 record bucket to its owner with peer
+ * copies over xGMI (hipMemcpyPeerAsync, in pieces that overlap the region build of the previous piece), build
+ * each shard's slot range and hand over the few stragglers (overflow observations, nodes that probed past the
+ * end of a shard).  Same protocol as the one-process-per-GPU flow over RCCL (dbg_assembly_amd/multigpu.py).
+ * One host thread per communicator.                                                                 */
+typedef struct dbgk_comm dbgk_comm;
+int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, uint32_t n, dbgk_comm **out);
+int dbgk_comm_destroy(dbgk_comm *c);
+uint32_t dbgk_comm_size(const dbgk_comm *c);
+dbgk_handle *dbgk_comm_handle(dbgk_comm *c, uint32_t i);
+int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+/* records -> table on every shard now (dbgk_flush for a communicator); a push does it when a store is full */
+int dbgk_comm_flush(dbgk_comm *c);
+/* totals of the whole job (count includes the one key-0 node); exact after a flush                       */
+int dbgk_comm_refresh_stats(dbgk_comm *c, dbgk_stats *out);
+int dbgk_comm_finalize(dbgk_comm *c, dbgk_stats *out);
+int dbgk_comm_digest(dbgk_comm *c, uint64_t *digest);
+int dbgk_comm_link_stats(dbgk_comm *c, int32_t kmer_freq_cutoff, dbgk_link_stats *out);
+/* the host KmerSet of the whole job (same contract as dbgk_export_host_table): the shards side by side when
+ * host_size is the global table size, otherwise every node re-seated on the host                          */
+int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
 

@@ -104,3 +104,23 @@ def test_cli_reference_layout_mode(tmp_path, oracle, case):
     import numpy as np
     assert np.array_equal(array, res.table)
     assert np.array_equal(flags, res.nul_flag)
+
+
+MULTI_CASES = [c for c in FILE_CASES if c["name"] in ("mixed150_k31", "enlarge_b50", "enlarge_cap_e1", "polyA_k31", "fastq_gz_k31",
+                                                       "lengths_k31_r100", "saturate_k31", "block_b7")]
+
+
+@pytest.mark.parametrize("gpus,store", [("0,0", None), ("0,0,0", "2500")])
+@pytest.mark.parametrize("case", MULTI_CASES, ids=[c["name"] for c in MULTI_CASES])
+def test_cli_multi_gpu_path(tmp_path, case, gpus, store):
+    """build_debruijn_graph() over several GPU shards of one table (host/DBGgraph.cpp with DBGK_GPU_LIST /
+    DBGK_GPUS -> dbgk_comm_*): same dump, same table size schedule (incl. the -e cap) as the reference.
+    The shards share the one GPU of the test box; with a small store the job takes many exchange rounds."""
+    env = {"DBGK_GPU_LIST": gpus}
+    if store:
+        env.update({"DBGK_STORE_KMERS": store, "DBGK_BATCH_BYTES": "4096"})
+    r, dump, _ = run_cli(tmp_path, case, env)
+    assert "GPU shards" in r.stderr
+    ref = case["ref"]
+    assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
+    assert re.search(r"^array_size:\t%d$" % ref["size"], r.stderr, re.M)

@@ -627,3 +627,40 @@ def test_sharded_table_with_overflow_and_heavy_repeats(capi, oracle):
     assert n_ovf > 0
     assert sum(int(s.count) for s in final) == ref.count
     assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
+
+
+# ------------------------------------------------------------------------------------------------
+# dbgk_comm_*: the C++ host layer's multi-GPU path (N sharded handles inside one process, peer copies).
+# One GPU here, so the shards share the device; the protocol is the same.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_shards,store,pieces", [(2, 1 << 22, 8), (3, 40000, 3), (4, 1 << 22, 1)])
+def test_comm_in_process_shards_equal_oracle(capi, oracle, n_shards, store, pieces, monkeypatch):
+    """reads dealt round robin to the shards, records exchanged in pieces, every shard builds its slot range;
+    a small store forces several flush rounds (exchange + incremental build each); explicit flush + exact
+    count in between; export at the global size (shards side by side) and at another size (host re-seat)"""
+    monkeypatch.setenv("DBGK_COMM_PIECES", str(pieces))
+    rng = random.Random(n_shards * 7 + pieces)
+    reads = rand_reads(rng, 5000, G=30000) + [b"A" * 150] * 200 + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 300
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    with capi.Comm(k=31, table_slots=size, devices=[0] * n_shards, expected_kmers=store, max_batch_bases=1 << 16) as c:
+        n = len(reads)
+        cuts = list(range(0, n, n // 9)) + [n]
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            lo, hi = int(offsets[a]), int(offsets[b])
+            c.push_reads(bases[lo:hi], offsets[a:b + 1] - offsets[a])
+            if i == 4:
+                c.flush()
+                part = oracle.build_graph(files_mem=[(bases[:hi], offsets[:b + 1])], k=31, init_hash_size=0.001)
+                assert c.refresh_stats().count == part.count
+        st = c.finalize()
+        assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+        assert c.digest() == oracle.nodes_digest(ref.nodes)
+        assert list(c.link_stats(2).depth_stat) == list(oracle.link_stats(ref.nodes, 2).depth_stat)
+        for host_size in (size, capi.find_next_prime_ref(3 * ref.count)):
+            array, flags = c.export_host_table(host_size)
+            assert oracle.check_host_table(array, flags, host_size, st.count) == 0
+            occ = np.unpackbits(flags)[:host_size].astype(bool)
+            assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)

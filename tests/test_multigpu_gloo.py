@@ -252,6 +252,9 @@ class FakeShardGraph:
     def shard_overflow(self):
         return 0, 0
 
+    def shard_heavy(self):
+        return 0, 0
+
     def add_polyA(self, l, r):
         for j, v in enumerate((l, r)):
             a = np.array([(self.pa_links[j] >> s) & 0xFF for s in (24, 16, 8, 0)]) + np.array([(v >> s) & 0xFF for s in (24, 16, 8, 0)])
