@@ -9,14 +9,21 @@ resident in HBM: reset (init_kmerset_parallel), mark read boundaries, extract + 
 hash every k-mer into 8-byte records partitioned by final table slot range, second-level
 partition, build every 4096-slot region of the reference-layout table in LDS and write it out,
 finalize (counters, key-0 node) -- the PARTITION engine; --engine 1 selects the DIRECT engine
-(fused extract + global-atomic insert).  For N > 1 additionally the owner exchange of SURVEY.md section 8(e) (bucket-count all-reduce, all-to-all of
-aggregated nodes over RCCL/xGMI, owner merge).  Workload at every N: BASELINE.json configs[1]
-per GPU (10 M x 150 bp reads, k = 31, 30x of a 50 Mb genome per GPU => weak scaling).
+(fused extract + global-atomic insert).  For N > 1 additionally the exchange of SURVEY.md section
+8(e): all-reduce of the per-bucket record counts, all-to-all of the level-1 record buckets over
+RCCL/xGMI to the ranks that own their slot range, every rank builds its part of ONE global table.
+Workload (--config): cfg2 (default) = BASELINE.json configs[1] PER GPU at every N (10 M x 150 bp
+reads, k = 31, 30x of a 50 Mb genome per GPU => weak scaling); cfg3 = configs[2], 200 M reads of a
+1 Gb genome into one table of 8.6 G slots at N = 8 (25 M reads per GPU; fewer GPUs run their share).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
-dominant kernel (timed with HIP events on the library's own stream) and `cpu_baseline` (the real
-reference, oracle/_ref, on a bounded sample of the same reads; the oracle port if that binary is
-absent) -- the CPU baseline is a reported number, not something the GPU path calls.
+Prints ONE JSON line on rank 0 (contract in the task description).  `roofline` is the WHOLE step:
+algorithmic bytes of the step (33.25 B per k-mer) / ms_per_step against the 8 TB/s
+spec peak (`frac`) and against the copy bandwidth measured in the same run (`frac_of_measured`);
+per kernel: its measured time (HIP events on the library's own streams), its OWN bytes and its PMC
+traffic.  After the timed loop the graph of the last step is checked against the full-size golden
+record of the CPU oracle (`verified`), the same workload is timed from its first host-to-device copy
+(`value_incl_h2d`), and `cpu_baseline` times the real reference (oracle/_ref; the oracle port if
+that binary is absent) on a bounded sample -- a reported number, not something the GPU path calls.
 """
 import argparse
 import json
@@ -32,15 +39,27 @@ H2D_STEPS = 3          # extra steps timed from the first host-to-device copy (S
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+CONFIGS = {"cfg2": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, table_slots=600_000_000, synth_cfg=2,
+                        workload="cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31"),
+           "cfg3": dict(reads_per_gpu=25_000_000, genome_per_gpu=125_000_000, table_slots=1_075_000_000, synth_cfg=3,
+                        workload="cfg3: synthetic 200 M x 150 bp reads of a 1 Gb genome at N=8 (25 M reads, 125 Mb, 1.075 G slots per GPU; "
+                                 "fewer GPUs run that share of it), 0.5% subst, 0.01% N, k=31, ONE table over all GPUs")}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-gpu", type=int, default=10_000_000)
-    ap.add_argument("--genome-per-gpu", type=int, default=50_000_000)
+    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 (default, the weak-scaling line): BASELINE configs[1] PER GPU -- 10 M x 150 bp reads, 50 Mb of genome "
+                         "and 600 M table slots per GPU; cfg3: BASELINE configs[2] split over the GPUs that are there -- 25 M reads, "
+                         "125 Mb of genome and 1.075 G slots per GPU, i.e. at N = 8 the stated job: 200 M reads of a 1 Gb genome "
+                         "into ONE table of 8.6 G slots (~5.6 G nodes)")
+    ap.add_argument("--reads-per-gpu", type=int, default=None)
+    ap.add_argument("--genome-per-gpu", type=int, default=None)
     ap.add_argument("--kmer", type=int, default=31)
-    ap.add_argument("--table-slots", type=int, default=600_000_000, help="rounded up by find_next_prime")
+    ap.add_argument("--table-slots", type=int, default=None, help="per GPU; rounded up by find_next_prime")
     ap.add_argument("--engine", type=int, default=2, help="1 = DIRECT (global atomics), 2 = PARTITION (default)")
     ap.add_argument("--exchange", choices=["records", "nodes"], default="records",
                     help="N > 1: 'records' = slot-range ownership, level-1 buckets exchanged (default); "
@@ -56,7 +75,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc run")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for key in ("reads_per_gpu", "genome_per_gpu", "table_slots"):
+        if getattr(args, key) is None:
+            setattr(args, key, CONFIGS[args.config][key])
+    return args
 
 
 def measured_traffic(args, size, kernel):
@@ -99,7 +122,7 @@ def cpu_baseline(args, genome_len):
     visible = len(os.sched_getaffinity(0))
     cores = min(visible, args.cpu_threads)
     n = args.cpu_sample_reads
-    P = O.synth_params(genome_len, 150, cfg=2)
+    P = O.synth_params(genome_len, 150, cfg=CONFIGS[args.config]["synth_cfg"])
     init = max(2.2 * n * (150 - args.kmer + 1) / 1e9 * 0.75, 0.001)  # distinct <= kmers; load <= ~0.6
     host = "%s, %d logical CPUs on the box, %d visible to this process" % (cpu_model(), os.cpu_count() or 0, visible)
     sample = "first %d reads of the N=1 workload (%d k-mers), -i %.3f -b 10000" % (n, n * (150 - args.kmer + 1), init)
@@ -136,7 +159,7 @@ def golden_cfg2(args, world, n_reads, genome_len):
         return None
     with open(path) as fh:
         gold = json.load(fh)
-    if (gold["n_reads"], gold["genome_len"], gold["k"]) != (n_reads, genome_len, args.kmer):
+    if args.config != "cfg2" or (gold["n_reads"], gold["genome_len"], gold["k"]) != (n_reads, genome_len, args.kmer):
         return None
     return gold
 
@@ -177,12 +200,12 @@ def main():
     n_reads = args.reads_per_gpu
     genome_len = args.genome_per_gpu * world
     kpr = 150 - args.kmer + 1
-    P = capi.synth_params(genome_len, 150, cfg=2)
+    P = capi.synth_params(genome_len, 150, cfg=CONFIGS[args.config]["synth_cfg"])
     # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
-    # (PARTITION engine, slot-range ownership; needs < 2^32 slots in total).  --exchange nodes selects
+    # (PARTITION engine, slot-range ownership; up to 2^34 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
     sharded = multi and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
-    per_gpu_slots = args.table_slots if world == 1 else min(args.table_slots, (2 ** 32 - 2 ** 22) // world)
+    per_gpu_slots = args.table_slots
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
@@ -309,7 +332,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31",
+            "config": {"workload": CONFIGS[args.config]["workload"],
                        "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
                        "nodes": res["count"], "engine": "partition" if args.engine == capi.ENGINE_PARTITION else "direct",
                        "parallelism": ("reads sharded by record x%d, k-mers owned by slot range of one global table "
