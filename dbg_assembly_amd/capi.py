@@ -13,9 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libdbgk.so")
 
 NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
+NODE32_DTYPE = np.dtype([("kmer_hi", "<u8"), ("kmer_lo", "<u8"), ("l_link", "<u4"), ("r_link", "<u4"), ("reserved", "<u8")])  # dbgk_node32
 
 OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
-ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ, ENGINE_SEEDIDX = 0, 1, 2, 3, 4
+ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ, ENGINE_SEEDIDX, ENGINE_WIDE = 0, 1, 2, 3, 4, 5
 FLAG_TRACK_FIRST_SEEN = 1
 
 
@@ -93,6 +94,8 @@ SYMBOLS = [
     ("dbgk_export_first_seen_order", _i, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
+    ("dbgk_wide_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_seed_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_seed_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -320,6 +323,22 @@ class Graph:
         _chk(lib().dbgk_refresh_stats(self._h, C.byref(st)), "dbgk_refresh_stats")
         self.stats = st
         return st
+
+    # ---- WIDE engine (128-bit keys)
+    def wide_export_sorted(self):
+        n = int(self.stats.count)
+        out = np.zeros(n, dtype=NODE32_DTYPE)
+        got = C.c_uint64()
+        _chk(lib().dbgk_wide_export_sorted(self._h, out.ctypes.data, n, C.byref(got)), "dbgk_wide_export_sorted")
+        assert got.value == n, (got.value, n)
+        return out
+
+    def wide_export_host_table(self):
+        size = self.table_slots
+        array = np.zeros(size, dtype=NODE32_DTYPE)
+        flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+        _chk(lib().dbgk_wide_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_wide_export_host_table")
+        return array, flags
 
     # ---- SEEDIDX engine
     SEED_DTYPE = np.dtype([("kmer", "<u8"), ("payload", "<u8")])  # payload = {id:32, pos:30, freq:1, direct:1}

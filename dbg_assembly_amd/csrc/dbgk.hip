@@ -16,6 +16,7 @@
 #include "dbgk.h"
 #include "dbgk_kernels.h"
 #include "dbgk_partition.h"
+#include "dbgk_wide_kernels.h"
 
 // dbgk_sort.hip
 extern "C" int dbgk_internal_sort_pairs(uint64_t *d_keys, uint64_t *d_vals, uint64_t n, hipStream_t stream);
@@ -103,6 +104,9 @@ struct dbgk_handle {
 	unsigned long long *first_pos = nullptr; // [tslots]
 	uint64_t pos_base = 0;                   // bases pushed so far
 
+	bool wide = false;            // WIDE engine: 128-bit keys, 32-byte nodes (dbgk_wide_kernels.h)
+	WNode *wnodes = nullptr;      // [size]
+	WNode *wside = nullptr;       // [kWideSideSlots]
 	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
@@ -142,6 +146,7 @@ struct dbgk_handle {
 	uint32_t uniform_launches = 0;
 
 	TableRef tref() const { return TableRef{table, size, magic}; }
+	WTable wref() const { return WTable{wnodes, size, magic, wside}; }
 };
 
 static int use_device(dbgk_handle *h)
@@ -267,6 +272,8 @@ static void free_handle(dbgk_handle *h)
 		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
 		if (h->stream2) (void)hipStreamDestroy(h->stream2);
 	}
+	if (h->wnodes) (void)hipFree(h->wnodes);
+	if (h->wside) (void)hipFree(h->wside);
 	if (h->table) (void)hipFree(h->table);
 	if (h->counts) (void)hipFree(h->counts);
 	if (h->first_pos) (void)hipFree(h->first_pos);
@@ -307,7 +314,10 @@ static int clear_record_store(dbgk_handle *h)
 static int reset_state(dbgk_handle *h)
 {
 	if (h->kfreq) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
-	if (h->kfreq && !h->part) {
+	if (h->wide) {
+		HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+		HIPCHK(hipMemsetAsync(h->wside, 0, kWideSideSlots * sizeof(WNode), h->stream));
+	} else if (h->kfreq && !h->part) {
 	} else if (h->part) {
 		// the region build of finalize overwrites every slot, so the 16 B/slot memset is only needed
 		// if a direct-path write (merge) happens first
@@ -476,13 +486,15 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 {
 	if (!cfg || !out) return DBGK_ERR_ARG;
 	*out = nullptr;
-	if (cfg->kmer_size < 1 || cfg->kmer_size > 32) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100)
+	const bool wide = cfg->engine == DBGK_ENGINE_WIDE;
+	if (cfg->kmer_size < 1 || cfg->kmer_size > (wide ? 63 : 32)) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100); WIDE: 128-bit keys
+	if (wide && (cfg->shard_count || cfg->flags)) return DBGK_ERR_ARG;
 	if (cfg->max_read_len < cfg->kmer_size) return DBGK_ERR_ARG;
 	const bool kfreq = cfg->engine == DBGK_ENGINE_KFREQ;
 	if (kfreq && cfg->kmer_size > 18) return DBGK_ERR_ARG; // 4^18 bytes = 64 GiB
 	if (!kfreq && cfg->table_slots < 3) return DBGK_ERR_ARG;
 	const bool seed = cfg->engine == DBGK_ENGINE_SEEDIDX;
-	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION && !kfreq && !seed)
+	if (cfg->engine != DBGK_ENGINE_AUTO && cfg->engine != DBGK_ENGINE_DIRECT && cfg->engine != DBGK_ENGINE_PARTITION && !kfreq && !seed && !wide)
 		return DBGK_ERR_ARG;
 	if (seed && (cfg->shard_count || (cfg->flags & DBGK_FLAG_TRACK_FIRST_SEEN))) return DBGK_ERR_ARG;
 
@@ -500,6 +512,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->device = cfg->device_id;
 	h->kfreq = kfreq;
 	h->seed = seed;
+	h->wide = wide;
 	if (seed) h->cfg.max_read_len = 0x7FFFFFFF; // contigs are never trimmed (the pos field bounds them, see push)
 	h->size = kfreq ? 3 : cfg->table_slots;
 	// KFREQ with a known input size runs through the PARTITION engine: occurrences are partitioned by
@@ -514,7 +527,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	}
 	h->magic = make_mod_magic(h->size);
 	h->tslots = h->size;
-	if (!kfreq || kf_part) {
+	if ((!kfreq || kf_part) && !wide) {
 		const int prc = plan_partition(h); // geometry first: a sharded handle holds only its slot range
 		if (prc != DBGK_OK) {
 			delete h;
@@ -550,6 +563,11 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 		if (h->n_counts < 64) h->n_counts = 64; // whole dwords / 8-byte groups for the scan kernels (k < 3)
 		if (hipMalloc(&h->counts, h->n_counts) != hipSuccess) {
 			g_last_error = "hipMalloc of the 4^k count table failed";
+			return fail(DBGK_ERR_NOMEM);
+		}
+	} else if (wide) {
+		if (hipMalloc(&h->wnodes, h->size * sizeof(WNode)) != hipSuccess || hipMalloc(&h->wside, kWideSideSlots * sizeof(WNode)) != hipSuccess) {
+			g_last_error = "hipMalloc of the wide k-mer table failed";
 			return fail(DBGK_ERR_NOMEM);
 		}
 	} else if (hipMalloc(&h->table, h->tslots * sizeof(Node)) != hipSuccess) {
@@ -690,6 +708,7 @@ static int resize_partition_table(dbgk_handle *h, uint64_t new_slots)
 
 extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 {
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || new_slots < 3) return DBGK_ERR_ARG;
 	int rc = use_device(h);
@@ -826,6 +845,11 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (rc) return rc;
 	if (h->seed) {
 		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
+	} else if (h->wide) {
+		if (has_long)
+			hipLaunchKernelGGL(k_wide_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->wref(), h->d_ctr);
+		else
+			hipLaunchKernelGGL(k_wide_extract_insert<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->wref(), h->d_ctr);
 	} else if (h->kfreq && !h->part) {
 		if (has_long)
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
@@ -1330,6 +1354,7 @@ __global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restri
 extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -1385,6 +1410,7 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out || !n_out) return DBGK_ERR_ARG;
 	if (!h->finalized) return DBGK_ERR_STATE;
@@ -1499,7 +1525,10 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 	unsigned long long res[2] = {0, 0};
 	hipError_t e = hipMemsetAsync(d_out, 0, 16, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_out);
+		if (h->wide)
+			hipLaunchKernelGGL(k_wide_digest, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, d_out);
+		else
+			hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, 16, hipMemcpyDeviceToHost, h->stream);
@@ -1524,8 +1553,12 @@ extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_
 	unsigned long long res[261];
 	hipError_t e = hipMemsetAsync(d_out, 0, bytes, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, (int)cutoff,
-		                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->geom.rank != 0) ? 0 : 1, d_out);
+		if (h->wide)
+			hipLaunchKernelGGL(k_wide_link_stats, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, (int)cutoff,
+			                   (uint64_t)h->h_ctr->polyA_links, d_out);
+		else
+			hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, (int)cutoff,
+			                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->geom.rank != 0) ? 0 : 1, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, bytes, hipMemcpyDeviceToHost, h->stream);
@@ -1631,6 +1664,92 @@ extern "C" int dbgk_seed_export_host_table(dbgk_handle *h, uint64_t host_size, d
 }
 
 // ---------------------------------------------------------------------------------------------
+// WIDE exports (128-bit keys, include/dbgk_wide.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_wide_export_sorted(dbgk_handle *h, dbgk_node32 *out, uint64_t capacity, uint64_t *n_out)
+{
+	if (!h || !out || !n_out) return DBGK_ERR_ARG;
+	if (!h->wide || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t n = h->h_ctr->n_new; // non-zero keys (main + side table)
+	*n_out = n + 1;
+	if (capacity < n + 1) return DBGK_ERR_CAPACITY;
+	out[0] = dbgk_node32{0, 0, (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu), (uint32_t)(h->h_ctr->polyA_links >> 32), 0}; // key 0 sorts first
+	if (n == 0) return DBGK_OK;
+	dbgk_node32 *d_out = nullptr;
+	unsigned long long *d_cursor = nullptr;
+	if (hipMalloc(&d_out, n * sizeof(dbgk_node32)) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&d_cursor, 8) != hipSuccess) {
+		(void)hipFree(d_out);
+		return DBGK_ERR_NOMEM;
+	}
+	unsigned long long found = 0;
+	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_wide_compact, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, d_out, d_cursor, n);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(out + 1, d_out, n * sizeof(dbgk_node32), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_out);
+	(void)hipFree(d_cursor);
+	if (e != hipSuccess) return hip_fail(e, "wide_export_sorted", __LINE__);
+	if (found != n) {
+		g_last_error = "wide_export_sorted: occupied slots != counted keys";
+		return DBGK_ERR_STATE;
+	}
+	std::sort(out + 1, out + 1 + n, [](const dbgk_node32 &a, const dbgk_node32 &b) {
+		return a.kmer_hi < b.kmer_hi || (a.kmer_hi == b.kmer_hi && a.kmer_lo < b.kmer_lo);
+	});
+	return DBGK_OK;
+}
+
+// host-layout table of host_size == table_slots 32-byte nodes + nul_flag: every key reachable by linear probing from
+// hash128(key) % size without crossing a clear flag.  The few nodes that live outside the main table on the
+// device (keys whose low word is 0, the key-0 node) are put on their probe chains here, on the host.
+extern "C" int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node32 *array, uint8_t *nul_flag)
+{
+	if (!h || !array || !nul_flag) return DBGK_ERR_ARG;
+	if (!h->wide || !h->finalized) return DBGK_ERR_STATE;
+	if (host_size != h->size) {
+		g_last_error = "dbgk_wide_export_host_table: host_size must be the handle's table_slots";
+		return DBGK_ERR_ARG;
+	}
+	if (h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
+	int rc = use_device(h);
+	if (rc) return rc;
+	dbgk_node32 *d_img = nullptr;
+	uint8_t *d_flags = nullptr;
+	std::vector<WNode> side(kWideSideSlots);
+	if (hipMalloc(&d_img, host_size * sizeof(dbgk_node32)) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&d_flags, host_size / 8 + 1) != hipSuccess) {
+		(void)hipFree(d_img);
+		return DBGK_ERR_NOMEM;
+	}
+	hipLaunchKernelGGL(k_wide_image, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, d_img, d_flags);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(array, d_img, host_size * sizeof(dbgk_node32), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(side.data(), h->wside, kWideSideSlots * sizeof(WNode), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_img);
+	(void)hipFree(d_flags);
+	if (e != hipSuccess) return hip_fail(e, "wide_export_host_table", __LINE__);
+	auto place = [&](dbgk_node32 nd) { // add_node_to_kmerset's rule (kmerSet.cpp:253-273): first slot without a flag on the key's chain
+		uint64_t hc = dbgk_wide::hash128(dbgk_wide::Key128{nd.kmer_hi, nd.kmer_lo}) % host_size;
+		while (nul_flag[hc >> 3] & (uint8_t)(128u >> (hc & 7u))) hc = (hc + 1 == host_size) ? 0 : hc + 1;
+		array[hc] = nd;
+		nul_flag[hc >> 3] |= (uint8_t)(128u >> (hc & 7u));
+	};
+	for (const WNode &s : side)
+		if (s.hi1) place(dbgk_node32{s.hi1 - 1ull, 0ull, (uint32_t)s.links, (uint32_t)(s.links >> 32), 0});
+	place(dbgk_node32{0, 0, (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu), (uint32_t)(h->h_ctr->polyA_links >> 32), 0}); // DBGgraph.cpp:418
+	return DBGK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // KFREQ exports
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_kfreq_export_counts(dbgk_handle *h, uint64_t first_kmer, uint64_t n, uint8_t *host_out)
@@ -1674,6 +1793,7 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
                                   uint64_t *kmer, uint8_t *left, uint8_t *right, uint8_t *valid)
 {
 	if (!h || !offsets || !kmer || !left || !right || !valid) return DBGK_ERR_ARG;
+	if (h->wide) return DBGK_ERR_STATE; // 64-bit keys only
 	if (offsets[0] != 0) return DBGK_ERR_ARG;
 	int rc = use_device(h);
 	if (rc) return rc;
@@ -1729,6 +1849,7 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
 extern "C" int dbgk_partition_counts(dbgk_handle *h, uint32_t n_parts, uint64_t *counts)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE; // a sharded table is already owned by slot range
@@ -1761,6 +1882,7 @@ __global__ void k_write_polyA_node(Node *out, uint64_t index, const Counters *ct
 extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node *d_nodes, uint64_t capacity)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !d_nodes || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
 	if (!h->finalized || h->sharded) return DBGK_ERR_STATE;
@@ -1793,6 +1915,7 @@ extern "C" int dbgk_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node
 extern "C" int dbgk_merge_nodes(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
 	if ((uintptr_t)d_nodes & 15u) return DBGK_ERR_ARG;
@@ -1831,6 +1954,7 @@ extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_han
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 {
+	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out) return DBGK_ERR_ARG;
 	if (!h->part) return DBGK_ERR_STATE;
@@ -1941,6 +2065,7 @@ extern "C" int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64
 extern "C" int dbgk_add_polyA(dbgk_handle *h, uint32_t l_link, uint32_t r_link)
 {
 	if (!h) return DBGK_ERR_ARG;
+	if (h->wide || h->kfreq || h->seed) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
 	Node nd;

@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "dbgk_synth.h"
+#include "dbgk_wide.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -53,6 +54,10 @@ typedef struct dbgk_handle dbgk_handle;
 #define DBGK_ENGINE_PARTITION  2  /* extract -> radix-partitioned records -> LDS-built table regions */
 #define DBGK_ENGINE_SEEDIDX    4  /* link_scaffold's seed index: every k-mer of the pushed CONTIGS -> (contig
                                      index, position, strand) of its first occurrence + uniqueness flag   */
+#define DBGK_ENGINE_WIDE       5  /* k-mers of up to 63 bases: 128-bit keys, 32-byte nodes (include/dbgk_wide.h; the reference
+                                     stops at k = 31, so this path is this build's own definition: parity unpinned for
+                                     k > 32, identical to the reference's rules for k <= 32).  Fused extract + atomic insert;
+                                     results through dbgk_wide_export_*, dbgk_digest, dbgk_link_stats_device            */
 #define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
                                      canonical k-mers (the correct_error module's frequency table);
                                      table_slots is ignored, k <= 18.  expected_kmers > 0: the occurrences
@@ -60,7 +65,7 @@ typedef struct dbgk_handle dbgk_handle;
                                      occurrence must fit the device), 0: atomics on the table, any size */
 
 typedef struct dbgk_config {
-	int32_t  kmer_size;        /* KmerSize   (DBGgraph.cpp:10), 1..32                              */
+	int32_t  kmer_size;        /* KmerSize   (DBGgraph.cpp:10), 1..32 (1..63 with DBGK_ENGINE_WIDE)     */
 	int32_t  max_read_len;     /* maxReadLen (DBGgraph.cpp:11): longer reads are trimmed           */
 	uint64_t table_slots;      /* number of 16-byte slots of the device table == kset->size the
 	                              host wants (a "prime" from find_next_prime, kmerSet.cpp:85-95);
@@ -210,6 +215,14 @@ int dbgk_digest(dbgk_handle *h, uint64_t *digest);
 
 /* calculate_kmer_links first pass (contig.cpp:119-181) on the device table                      */
 int dbgk_link_stats_device(dbgk_handle *h, int32_t kmer_freq_cutoff, dbgk_link_stats *out);
+
+/* ---- WIDE engine (k <= 63, 128-bit keys): results as 32-byte nodes, include/dbgk_wide.h ------------
+ * canonical dump sorted by (kmer_hi, kmer_lo), the key-0 node first; `capacity` >= stats.count             */
+int dbgk_wide_export_sorted(dbgk_handle *h, dbgk_node32 *out, uint64_t capacity, uint64_t *n_out);
+/* host-layout table of host_size == table_slots nodes + nul_flag (bit i = byte i/8, mask 128 >> (i%8)): every key
+ * reachable by linear probing from hash128(key) % host_size without crossing a clear flag, unused slots all-zero,
+ * the key-0 node on key 0's chain -- the invariants of SURVEY 8(b) with the 128-bit hash                      */
+int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node32 *array, uint8_t *nul_flag);
 
 /* ---- KFREQ engine: the k-mer frequency table of the correct_error module --------
  * The reference only CONSUMES this table (its producer, `kmerfreq`, is not part of the repository):

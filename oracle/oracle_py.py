@@ -486,3 +486,54 @@ def ref_seed(fasta, k, dump, hash_size=0, load_factor=0.5, timeout=600):
     subprocess.run([REF_SEED, fasta, str(k), str(hash_size), str(load_factor), dump], check=True, timeout=timeout,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return parse_seed_dump(dump)
+
+
+# ------------------------------------------------------------------------------------------------
+# WIDE key path (k <= 63, 128-bit keys): oracle/wide_oracle.cpp.  PARITY UNPINNED for k > 32 (the reference
+# stops at k = 31); anchored by equality with the pinned oracle above at k <= 31 (tests/test_wide.py).
+# ------------------------------------------------------------------------------------------------
+NODE32_DTYPE = np.dtype([("kmer_hi", "<u8"), ("kmer_lo", "<u8"), ("l_link", "<u4"), ("r_link", "<u4"), ("reserved", "<u8")])
+WIDE_LIB_PATH = os.path.join(HERE, "_build", "liboracle_wide.so")
+_wide = None
+
+
+def wide_lib():
+    global _wide
+    if _wide is None:
+        if not os.path.exists(WIDE_LIB_PATH):
+            build(force=True)
+        L = C.CDLL(WIDE_LIB_PATH)
+        L.orcw_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64)]
+        L.orcw_free.argtypes = [C.c_void_p]
+        L.orcw_digest.restype = C.c_uint64
+        L.orcw_digest.argtypes = [C.c_void_p, C.c_uint64]
+        L.orcw_check_host_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        _wide = L
+    return _wide
+
+
+def wide_build(bases, offsets, k, max_read_len=250):
+    """-> (nodes sorted by (kmer_hi, kmer_lo) with the key-0 node first, Kmer_total_num)"""
+    L = wide_lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    p, n, tot = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = L.orcw_build(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, max_read_len, C.byref(p), C.byref(n), C.byref(tot))
+    assert rc == 0, rc
+    try:
+        nodes = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value * 32,)).view(NODE32_DTYPE).copy()
+    finally:
+        L.orcw_free(p)
+    return nodes, tot.value
+
+
+def wide_digest(nodes):
+    nodes = np.ascontiguousarray(nodes, dtype=NODE32_DTYPE)
+    return wide_lib().orcw_digest(nodes.ctypes.data, len(nodes))
+
+
+def wide_check_host_table(array, nul_flag, size, expect_count):
+    array = np.ascontiguousarray(array, dtype=NODE32_DTYPE)
+    nul_flag = np.ascontiguousarray(nul_flag, dtype=np.uint8)
+    return wide_lib().orcw_check_host_table(array.ctypes.data, nul_flag.ctypes.data, size, expect_count)

@@ -1,0 +1,173 @@
+"""WIDE key path: k-mers of up to 63 bases, 128-bit keys, 32-byte nodes (BASELINE cfg5; include/dbgk_wide.h).
+
+The reference stops at k = 31, so for k > 32 there is nothing to pin against: those tests say PARITY UNPINNED
+in their names and compare the HIP kernels with this build's own CPU restatement (oracle/wide_oracle.cpp), which
+shares the rule definitions (include/dbgk_wide.h) but not the extraction code.  What anchors the path is the
+k <= 32 half: there every wide rule reduces to the reference's 64-bit one, and
+
+  CPU: the wide restatement == the pinned oracle (dbg_oracle.c, itself pinned to the real reference) on every
+       golden fixture, node for node, and == the real reference's dump hash;
+  GPU: the WIDE engine == the golden dumps of the real reference at k <= 32, and its digest / host-table layout
+       coincide with the 64-bit engines' (same hash, same slot).
+"""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, golden_case_ids
+from helpers import case_reads, dump_sha256
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def as_narrow(nodes32, oracle):
+    """wide nodes whose high word is 0 -> the 16-byte node type"""
+    assert not nodes32["kmer_hi"].any()
+    out = np.zeros(len(nodes32), dtype=oracle.NODE_DTYPE)
+    out["kmer"], out["l_link"], out["r_link"] = nodes32["kmer_lo"], nodes32["l_link"], nodes32["r_link"]
+    return out
+
+
+@pytest.mark.parametrize("case", golden_cases(), ids=golden_case_ids())
+def test_wide_restatement_at_k_le_32_equals_pinned_oracle_and_reference_dump(oracle, case):
+    p, ref = case["params"], case["ref"]
+    if case["name"] == "enlarge_cap_e1":
+        pytest.skip("the reference drops reads at the -e cap: a property of the block loop, not of the key path")
+    files = case_reads(case, oracle)
+    bases = np.concatenate([b for b, _ in files]) if files else np.zeros(0, np.uint8)
+    offs = [np.zeros(1, np.uint64)]
+    for _, o in files:
+        offs.append(o[1:] + offs[-1][-1])
+    offsets = np.concatenate(offs)
+    nodes32, total = oracle.wide_build(bases, offsets, p["k"], p["max_read_len"])
+    narrow = as_narrow(nodes32, oracle)
+    want = oracle.build_graph(files_mem=files, k=p["k"], max_read_len=p["max_read_len"], init_hash_size=max(p["init_hash_size"], 0.001))
+    assert total == want.total_kmers == ref["kmers"]
+    assert np.array_equal(narrow, want.nodes)
+    assert dump_sha256(narrow, ref["reads"], ref["kmers"], ref["count"]) == case["dump_sha256"]   # the real reference's dump
+    assert oracle.wide_digest(nodes32) == oracle.nodes_digest(want.nodes)
+
+
+def test_wide_core_known_answers(oracle):
+    """KATs of the reference (tests/golden/kat.txt: seq2bit / get_rev_com_kbit) through the 128-bit code path, and
+    the 63-mer analogues by construction (reverse complement of a string, computed independently in Python)"""
+    rng = random.Random(63)
+    for k in (1, 2, 31, 32, 33, 47, 62, 63):
+        for _ in range(50):
+            s = "".join(rng.choice("ACGT") for _ in range(k))
+            rc = "".join(COMP[c] for c in reversed(s))
+            val = lambda t: sum("ACGT".index(c) << (2 * (len(t) - 1 - i)) for i, c in enumerate(t))
+            canon = min(val(s), val(rc))
+            nodes, total = oracle.wide_build(np.frombuffer(s.encode(), np.uint8), np.array([0, k], np.uint64), k, 250)
+            assert total == 1
+            key = [(int(n["kmer_hi"]) << 64) | int(n["kmer_lo"]) for n in nodes if n["kmer_hi"] or n["kmer_lo"]]
+            assert key == ([canon] if canon else [])
+    line = [l.split("\t") for l in open(__file__.replace("test_wide.py", "golden/kat.txt")) if l.startswith("seq2bit\tACGTACGTACGTACGTACGTACGTACGTACG\t")][0]
+    fwd, rc = int(line[2]), int(line[4])
+    nodes, _ = oracle.wide_build(np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGTACG", np.uint8), np.array([0, 31], np.uint64), 31, 250)
+    assert int(nodes[1]["kmer_lo"]) == min(fwd, rc)
+
+
+def _reads(rng, n, G=6000, L=150):
+    g = "".join(rng.choice("ACGT") for _ in range(G))
+    out = []
+    for _ in range(n):
+        ln = L if rng.random() < 0.7 else rng.randint(0, L + 150)
+        s = rng.randint(0, G - min(ln, G))
+        r = list(g[s:s + ln])
+        if rng.random() < 0.5:
+            r = [COMP[c] for c in reversed(r)]
+        for j in range(len(r)):
+            x = rng.random()
+            if x < 0.01:
+                r[j] = rng.choice("ACGT")
+            elif x < 0.013:
+                r[j] = "N"
+        r = "".join(r)
+        out.append((r.lower() if rng.random() < 0.1 else r).encode())
+    # poly-A / poly-T (key 0), runs of A after other bases (keys whose low word is 0 at k > 32), short and empty reads
+    out += [b"A" * 200, b"T" * 177, b"", b"ACGT", b"C" + b"A" * 120, b"GT" + b"A" * 90 + b"C", b"T" * 64 + b"G", b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 4] * 3
+    out += [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGATACGTTGCATGCAAGCTTAGCTAGGATC"] * 300   # saturation
+    return out
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dbg_assembly_amd import capi as c
+    assert c.lib().dbgk_device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback exists)"
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in golden_cases() if c["name"] != "enlarge_cap_e1"],
+                         ids=[c["name"] for c in golden_cases() if c["name"] != "enlarge_cap_e1"])
+def test_wide_engine_at_k_le_32_equals_the_reference_goldens(capi, oracle, case):
+    p, ref = case["params"], case["ref"]
+    files = case_reads(case, oracle)
+    with capi.Graph(k=p["k"], table_slots=ref["size"], max_read_len=p["max_read_len"], engine=capi.ENGINE_WIDE) as g:
+        for bases, offsets in files:
+            g.push_reads(bases, offsets)
+        st = g.finalize()
+        assert (st.total_reads, st.total_kmers, st.count) == (ref["reads"], ref["kmers"], ref["count"])
+        narrow = as_narrow(g.wide_export_sorted(), oracle)
+        assert dump_sha256(narrow, st.total_reads, st.total_kmers, st.count) == case["dump_sha256"]
+        assert g.digest() == oracle.nodes_digest(narrow)   # the 64-bit engines' digest
+        array, flags = g.wide_export_host_table()
+        assert oracle.wide_check_host_table(array, flags, ref["size"], st.count) == 0
+        # with every high word 0 the layout is a valid REFERENCE table (slot = hash_code(kmer) % size)
+        assert oracle.check_host_table(as_narrow(array, oracle), flags, ref["size"], st.count) == 0
+        assert list(g.link_stats(2).depth_stat) == list(oracle.link_stats(narrow, 2).depth_stat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,r", [(63, 250), (33, 250), (47, 100), (62, 64), (63, 63), (32, 250), (17, 100), (1, 250)])
+def test_wide_engine_equals_cpu_restatement_PARITY_UNPINNED_above_k32(capi, oracle, k, r):
+    rng = random.Random(k * 1000 + r)
+    reads = _reads(rng, 1500)
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    want, total = oracle.wide_build(bases, offsets, k, r)
+    size = capi.find_next_prime_ref(max(2 * len(want), 1000))
+    with capi.Graph(k=k, table_slots=size, max_read_len=r, engine=capi.ENGINE_WIDE, max_batch_bases=1 << 16) as g:
+        half = len(reads) // 2
+        g.push_reads(bases[:int(offsets[half])], offsets[:half + 1])
+        g.push_reads(bases[int(offsets[half]):], offsets[half:] - offsets[half])
+        st = g.finalize()
+        assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (len(reads), total, len(want))
+        got = g.wide_export_sorted()
+        assert np.array_equal(got, want)
+        assert g.digest() == oracle.wide_digest(want)
+        array, flags = g.wide_export_host_table()
+        assert oracle.wide_check_host_table(array, flags, size, st.count) == 0
+        occ = np.unpackbits(flags)[:size].astype(bool)
+        assert np.array_equal(np.sort(array[occ], order=["kmer_hi", "kmer_lo"]), want)
+        if k > 32:
+            assert want["kmer_hi"].any() and ((want["kmer_lo"] == 0) & (want["kmer_hi"] != 0)).any()  # the side-table keys are exercised
+        # the handle is reusable; 64-bit-only entry points refuse it
+        with pytest.raises(capi.DbgkError):
+            g.export_sorted()
+        g.reset()
+        g.push_reads(bases, offsets)
+        assert g.finalize().count == len(want)
+        assert g.digest() == oracle.wide_digest(want)
+
+
+@pytest.mark.gpu
+def test_wide_engine_cfg5_shaped_sample_PARITY_UNPINNED(capi, oracle):
+    """BASELINE cfg5's shape at a size the CPU restatement finishes in seconds: 150-base reads at 0.1 % substitutions,
+    k = 63 (88 windows per read); device-generated reads == the oracle's generator"""
+    n_reads, G = 60000, 300000
+    P, PO = capi.synth_params(G, 150, sub_rate=0.001, cfg=5), oracle.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    bases, offsets = oracle.synth_reads(PO, 0, n_reads)
+    want, total = oracle.wide_build(bases, offsets, 63, 250)
+    size = capi.find_next_prime_ref(3 * len(want))
+    with capi.Graph(k=63, table_slots=size, engine=capi.ENGINE_WIDE) as g:
+        d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+        assert np.array_equal(d_bases.to_host(np.uint8, nb), bases)
+        g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        st = g.finalize()
+        assert (int(st.total_kmers), int(st.stored_kmers), int(st.count)) == (total, 88 * n_reads, len(want))
+        assert np.array_equal(g.wide_export_sorted(), want)
+        d_bases.free()
+        d_off.free()
