@@ -1,7 +1,11 @@
 #!/bin/bash
-# level 2 || region build: number of bucket chunks (DBGK_OVERLAP_CHUNKS; 1 = level 2 first, then the build)
-for c in 1 4 8 16; do
-  DBGK_OVERLAP_CHUNKS=$c timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ovl_$c.json 2> gpurun_out/ovl_$c.err || exit 1
-  python -c "
-import json;d=json.load(open('gpurun_out/ovl_$c.json'));print($c, round(d['ms_per_step'],3), d['roofline']['all_kernels_ms'], d['config']['nodes'])"
+# level-2 / build overlap granularity: bucket chunks per step (DBGK_OVERLAP_CHUNKS); the finer the chunks, the sooner
+# the region build reads the records level 2 has just written (Infinity Cache reuse) -- at the price of more launches
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for c in ${CHUNKS:-8 16 32 64 128 287}; do
+  DBGK_OVERLAP_CHUNKS=$c python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.read())
+print('chunks', $c, 'ms_per_step %.3f' % j['ms_per_step'], 'l1 %.2f' % j['phases_ms_per_step']['insert'], 'l2 %.2f build %.2f wall %.2f' % (j['phases_ms_per_step']['partition'], j['phases_ms_per_step']['build'], j['phases_ms_per_step']['partition_and_build_wall']), 'verified' if j['verified'] else 'UNVERIFIED')
+"
 done

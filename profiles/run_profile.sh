@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun):  profiles/run_profile.sh <tag> <bench args...>
-#   1. rocprofv3 --kernel-trace --stats   -> per-kernel average duration
+#   1. rocprofv3 --kernel-trace --stats   -> per-kernel average duration (+ the trace: start/end of every dispatch)
 #   2. separate --pmc passes              -> FETCH_SIZE, WRITE_SIZE, SQ counters (never combined with tracing)
 # Summaries land in gpurun_out/prof_<tag>/; copy what should be judged into profiles/.
 set -u
@@ -10,6 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline "$@" > $OUT/kt.log 2>&1 || echo "kt failed"
+if [ "${PMC:-1}" = "1" ]; then
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_$N.log 2>&1 || echo "pmc $N failed"
@@ -28,6 +29,23 @@ for row in csv.DictReader(open(sys.argv[1])):
 PY
   done
 } > $OUT/pmc_summary.csv
+fi
 cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# timeline of the LAST step of the trace: every dispatch with its start relative to the step's first kernel
+python3 - $OUT/kt/*/*kernel_trace.csv > $OUT/last_step_timeline.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "k_mark" in r["Kernel_Name"] or "k_stats" in r["Kernel_Name"]]
+if marks:
+    rows = rows[marks[-1]:]
+t0 = int(rows[0]["Start_Timestamp"])
+print("kernel,start_us,end_us,dur_us,vgpr,lds")
+for r in rows:
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", ", ";")[:70]
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    print("%s,%.1f,%.1f,%.1f,%s,%s" % (k, s / 1e3, e / 1e3, (e - s) / 1e3, r.get("VGPR_Count", ""), r.get("LDS_Block_Size", "")))
+PY
 cat $OUT/kernel_stats.csv | cut -c1-160
-cat $OUT/pmc_summary.csv
+cat $OUT/last_step_timeline.csv | head -60
+[ -f $OUT/pmc_summary.csv ] && cat $OUT/pmc_summary.csv
