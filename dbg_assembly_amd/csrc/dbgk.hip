@@ -359,7 +359,7 @@ static int plan_partition(dbgk_handle *h)
 		if (want == DBGK_ENGINE_DIRECT) return DBGK_OK;
 		if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
 	}
-	uint32_t r = 21; // measured on cfg2: r = 20 / 21 / 22 -> 23.9 / 23.5 / 24.6 ms per step
+	uint32_t r = 22; // measured on cfg2 (round 2, profiles/r02_r_sweep.txt): r = 20 / 21 / 22 -> 17.3 / 16.5 / 16.3 ms per step
 	if (const char *e = getenv("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(22, atoi(e))); // tuning knob: level-1 bucket = slot >> r
 	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kMaxBuckets) r++;
 	const uint64_t qmax = ~0ull / h->size;
@@ -812,17 +812,33 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	TimedSpan sp;
 	int rc = span_begin(h, PH_MARK, sp);
 	if (rc) return rc;
-	HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
-	if (has_long != 0) HIPCHK(hipMemsetAsync(d_dead, 0, words * 4, h->stream));
 	static_assert(offsetof(Counters, len_max) + sizeof(unsigned long long) - offsetof(Counters, any_dead) == 20, "per-batch fields are contiguous");
 	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream)); // any_dead, len_min_inv, len_max
-	hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
-	                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr);
+	// The read-boundary bitmaps are what the general kernels navigate by; the PARTITION engine's level-1 kernel for
+	// (nearly) equal-length reads does without them, so for such a batch only the statistics are taken.  A device
+	// batch tells its shape only after those statistics: the bitmaps follow in a second pass if they are needed.
+	UniformGeom U{};
+	bool c15 = false;
+	int umode = -1; // not decided yet
+	auto mark_bits = [&](int with_stats) -> int {
+		HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
+		if (has_long != 0) HIPCHK(hipMemsetAsync(d_dead, 0, words * 4, h->stream));
+		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases,
+		                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr, with_stats);
+		return DBGK_OK;
+	};
+	const bool may_skip_bits = h->part && !h->seed;
+	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15);
+	if (may_skip_bits && (umode > 0 || umode < 0)) {
+		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases, h->cfg.kmer_size,
+		                   h->cfg.max_read_len, (uint32_t *)nullptr, (uint32_t *)nullptr, h->d_ctr, 1); // statistics only
+	} else {
+		rc = mark_bits(1);
+		if (rc) return rc;
+	}
 	if (h->seed && n_bases)
 		hipLaunchKernelGGL(k_mark_n, dim3(grid_for(h, (n_bases + 31) >> 5)), dim3(kBlock), 0, h->stream, d_bases, n_bases, d_dead);
 	HIPCHK(hipGetLastError());
-	rc = span_end(h, sp);
-	if (rc) return rc;
 	if (has_long < 0 || (uniform_len < 0 && h->part)) {
 		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, 20, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
@@ -832,14 +848,21 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			len_max = h->h_ctr->len_max;
 		}
 	}
+	if (may_skip_bits && umode < 0) {
+		umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15);
+		if (umode == 0) { // the general kernel after all: it needs the bitmaps
+			rc = mark_bits(0);
+			if (rc) return rc;
+			HIPCHK(hipGetLastError());
+		}
+	}
+	rc = span_end(h, sp);
+	if (rc) return rc;
 	const uint64_t id_base = h->total_reads; // contig index of the batch's first sequence (SEEDIDX)
 	h->total_reads += n_reads;
 	if (n_bases == 0) return DBGK_OK;
 
 	ReadBatch rb{d_bases, n_bases, d_start, has_long ? d_dead : nullptr, h->cfg.kmer_size};
-	UniformGeom U{};
-	bool c15 = false;
-	int umode = 0;
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
@@ -855,7 +878,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
-	} else if (h->part && (umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15)) != 0) {
+	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);

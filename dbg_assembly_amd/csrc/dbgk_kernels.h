@@ -102,10 +102,13 @@ __device__ __forceinline__ unsigned long long block_sum_n(unsigned long long v, 
 //   start bit at offsets[r]; dead bits on [offsets[r]+maxReadLen, offsets[r+1]) (DBGgraph.cpp:63);
 //   Kmer_total_num += len-K+1 for len >= K (untrimmed, :101); Total_reads_num += 1 (:274)
 // ---------------------------------------------------------------------------------------------
+// start_bits == null: statistics only (totals, any_dead, shortest / longest read) -- all a batch of equal-length reads
+// needs, its level-1 kernel finds the read boundaries by arithmetic; with_stats == 0: bitmaps only (the second call for
+// a device batch that turned out to need them)
 __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ offsets, uint64_t n_reads,
                                                  uint64_t n_bases, int k, int max_read_len,
                                                  uint32_t *__restrict__ start_bits, uint32_t *__restrict__ dead_bits,
-                                                 Counters *__restrict__ ctr)
+                                                 Counters *__restrict__ ctr, int with_stats = 1)
 {
 	__shared__ unsigned long long red[kBlock / 64];
 	unsigned long long tot = 0, stored = 0, len_lo = ~0ull, len_hi = 0ull;
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 		const uint64_t len = e - s;
 		len_lo = len < len_lo ? len : len_lo;
 		len_hi = len > len_hi ? len : len_hi;
-		if (s < n_bases) atomicOr(&start_bits[s >> 5], 1u << (s & 31u));
-		if (len >= (uint64_t)k) {
+		if (start_bits && s < n_bases) atomicOr(&start_bits[s >> 5], 1u << (s & 31u));
+		if (with_stats && len >= (uint64_t)k) {
 			tot += len - (uint64_t)k + 1;
 			const uint64_t rl = len > (uint64_t)max_read_len ? (uint64_t)max_read_len : len;
 			if (rl >= (uint64_t)k) stored += rl - (uint64_t)k + 1;
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 			}
 		}
 	}
+	if (!with_stats) return; // (wave-uniform: a kernel argument)
 	unsigned long long a = block_sum(tot, red);
 	unsigned long long b = block_sum(stored, red);
 	if (threadIdx.x == 0) {

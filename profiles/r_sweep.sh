@@ -1,7 +1,10 @@
 #!/bin/bash
-# level-1 bucket width sweep (DBGK_PART_R): n1 = size >> r level-1 buckets, n2 = 2^(r-12) final buckets per level-1 bucket
-for r in 20 21 22; do
-  DBGK_PART_R=$r timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r_$r.json 2> gpurun_out/r_$r.err || exit 1
-  python -c "
-import json;d=json.load(open('gpurun_out/r_$r.json'));print($r, round(d['ms_per_step'],3), d['roofline']['all_kernels_ms'], d['config']['nodes'])"
+# level-1 bucket width r (DBGK_PART_R): level-1 fan-out size >> r, level-2 fan-out 2^(r-12)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for r in ${RS:-20 21 22}; do
+  DBGK_PART_R=$r python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.read())
+print('r', $r, 'ms_per_step %.3f' % j['ms_per_step'], 'l1 %.2f' % j['phases_ms_per_step']['insert'], 'l2 %.2f build %.2f wall %.2f' % (j['phases_ms_per_step']['partition'], j['phases_ms_per_step']['build'], j['phases_ms_per_step']['partition_and_build_wall']), 'verified' if j['verified'] else 'UNVERIFIED')
+"
 done
