@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdbgk.so")
+LIB_PATH = os.environ.get("DBGK_LIB") or os.path.join(HERE, "lib", "libdbgk.so")  # DBGK_LIB: A/B runs of two builds in one session
 
 NODE_DTYPE = np.dtype([("kmer", "<u8"), ("l_link", "<u4"), ("r_link", "<u4")])
 NODE32_DTYPE = np.dtype([("kmer_hi", "<u8"), ("kmer_lo", "<u8"), ("l_link", "<u4"), ("r_link", "<u4"), ("reserved", "<u8")])  # dbgk_node32
