@@ -280,8 +280,10 @@ def main():
         import numpy as np
         h_bases = d_bases.to_host(np.uint8, nb)
         h_off = d_off.to_host(np.uint64)
-        t1 = time.perf_counter()
-        for _ in range(H2D_STEPS):
+        for it in range(H2D_STEPS + 1):    # the first pass (untimed) allocates the pinned staging buffers
+            if it == 1:
+                g.sync()
+                t1 = time.perf_counter()
             g.reset()
             g.push_reads(h_bases, h_off)   # pageable host buffers -> pinned staging -> H2D -> kernels (what the CLI does)
             st2 = g.finalize()

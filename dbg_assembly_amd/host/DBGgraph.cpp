@@ -452,6 +452,13 @@ void build_debruijn_graph(vector<string> &reads_files)
 	if (kset) free_hash(kset);
 	kset = result;
 	DbgkLastStatus = S->status;
+	if (getenv("DBGK_TIMINGS") && S->h) { // device time per phase, summed over the run (HIP events on the library's streams)
+		dbgk_timings tm;
+		if (dbgk_get_timings(S->h, &tm) == DBGK_OK)
+			cerr << "GPU phases (ms): engine " << (S->partition ? "partition" : "direct") << " mark " << tm.mark_ms << " level1/insert " << tm.insert_ms
+			     << " level2 " << tm.partition_ms << " build " << tm.build_ms << " level2+build wall " << tm.l2_build_wall_ms << " fixup "
+			     << tm.fixup_ms << " launches " << tm.insert_launches << endl;
+	}
 
 	print_kmerset_parameter(kset);
 }

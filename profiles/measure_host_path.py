@@ -35,4 +35,27 @@ for engine, name in ((capi.ENGINE_DIRECT, "direct"), (capi.ENGINE_PARTITION, "pa
             best = dt if best is None else min(best, dt)
         out[name] = {"seconds": best, "M_kmers_per_s": st.stored_kmers / best / 1e6, "GB_per_s_host_bytes": nb / best / 1e9,
                      "count": int(st.count)}
+
+# the same workload through the command line (host/DBGgraph.cpp: gz/plain parser -> batches -> dbgk_push_reads -> finalize -> host
+# KmerSet): which engine runs behind build_debruijn_graph(), its device time, and the wall time with the parser in front
+import subprocess
+import tempfile
+import ctypes as C
+from oracle import oracle_py as O  # the generator that writes the reads file (test infrastructure; nothing of it is timed)
+cli = os.path.join(ROOT, "dbg_assembly_amd", "bin", "debruijn_contig")
+with tempfile.TemporaryDirectory() as tmp:
+    fa = os.path.join(tmp, "reads.fa")
+    PO = O.synth_params(50_000_000, 150, cfg=2)
+    O.lib().orc_synth_write_file(C.byref(PO), 0, n_reads, os.fsencode(fa), 2, 0)
+    lib = os.path.join(tmp, "reads.lib")
+    open(lib, "w").write(fa + "\n")
+    for engine, name in (("2", "cli_partition"), ("1", "cli_direct")):
+        env = dict(os.environ, DBGK_ENGINE=engine, DBGK_TIMINGS="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "-k", "31", "-f", "2", "-i", "0.6", "-t", "16", "-o", os.path.join(tmp, "out"), lib], env=env, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        line = [l for l in r.stderr.splitlines() if l.startswith("GPU phases")]
+        count = [l for l in r.stderr.splitlines() if l.startswith("count:")]
+        out[name] = {"rc": r.returncode, "wall_seconds": dt, "M_kmers_per_s_wall": n_reads * 120 / dt / 1e6, "gpu_phases": line[-1] if line else None,
+                     "count_line": count[-1] if count else None}
 print(json.dumps(out))
