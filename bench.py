@@ -73,6 +73,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer steps after the timed loop (profiling passes)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
@@ -276,7 +277,7 @@ def main():
                      "(count/kmers/digest %r, expected %r)" % (got[:3], want[:3]))
         verified = "count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (CPU oracle, full size)"
     value_incl_h2d = None
-    if world == 1 and not multi and not (debug_mode or debug_l2):
+    if world == 1 and not multi and not args.no_h2d and not (debug_mode or debug_l2):
         import numpy as np
         h_bases = d_bases.to_host(np.uint8, nb)
         h_off = d_off.to_host(np.uint64)

@@ -336,12 +336,12 @@ void build_debruijn_graph(vector<string> &reads_files)
 	cfg.table_slots = S->device_slots;
 	cfg.engine = S->partition ? DBGK_ENGINE_PARTITION : DBGK_ENGINE_DIRECT;
 	if (S->partition) {
-		// record store: what the input can hold at most (plain files: one window per byte), at most 2^30
-		// occurrences (~19 GB of stores); more input is flushed into the table in rounds
+		// record store: what the input can hold at most (plain files: one window per byte), at most 2^31
+		// occurrences (~38 GB of stores); more input is flushed into the table in rounds
 		uint64_t store = getenv("DBGK_STORE_KMERS") ? strtoull(getenv("DBGK_STORE_KMERS"), NULL, 10) : 0;
 		if (!store) {
 			const uint64_t bound = input_size_bound(reads_files);
-			store = bound ? std::min<uint64_t>(bound, 1ull << 30) : (1ull << 30);
+			store = bound ? std::min<uint64_t>(bound, 1ull << 31) : (1ull << 31);
 		}
 		cfg.expected_kmers = std::max<uint64_t>(store, 1024);
 	}
