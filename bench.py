@@ -206,7 +206,11 @@ def main():
     # (PARTITION engine, slot-range ownership; up to 2^34 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
     sharded = multi and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
+    # cfg2 (weak scaling): the global table stays below 2^32 slots where that still leaves room (N = 8: 536 M slots per
+    # GPU, load 0.4), because level 2 is fastest with <= 1024 final buckets per level-1 bucket; cfg3 IS the big table
     per_gpu_slots = args.table_slots
+    if sharded and args.config == "cfg2":
+        per_gpu_slots = min(per_gpu_slots, (2 ** 32 - 2 ** 22) // world)
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,

@@ -360,7 +360,7 @@ static int plan_partition(dbgk_handle *h)
 		if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
 	}
 	uint32_t r = 22; // measured on cfg2 (round 2, profiles/r02_r_sweep.txt): r = 20 / 21 / 22 -> 17.3 / 16.5 / 16.3 ms per step
-	if (const char *e = getenv("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(22, atoi(e))); // tuning knob: level-1 bucket = slot >> r
+	if (const char *e = getenv("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(24, atoi(e))); // tuning knob: level-1 bucket = slot >> r
 	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kMaxBuckets) r++;
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
