@@ -418,6 +418,7 @@ extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbg
 	auto flag_set = [&](uint64_t i) { return (nul_flag[i >> 3] & (uint8_t)(128u >> (i & 7u))) != 0; };
 	const uint64_t global = c->h[0]->size;
 	if (host_size == global) {
+		memset(nul_flag, 0, host_size / 8 + 1);
 		for (dbgk_handle *h : c->h) {
 			const uint64_t lo = h->geom.slot_lo, len = h->tslots;
 			std::vector<uint8_t> fl(len / 8 + 1);
