@@ -34,13 +34,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG = 33.25          # algorithmic bytes per k-mer, k=31 L=150: 1.25 B bases + 16 B node read + 16 B node write
+B_ALG = 33.25          # algorithmic bytes per k-mer, k=31 L=150: 1.25 B bases + 16 B node read + 16 B node write;
+                       # cfg5 (k=63, 32-byte nodes): 150/88 + 64 = 65.70 B, set in main()
 H2D_STEPS = 3          # extra steps timed from the first host-to-device copy (SURVEY 8(d) timed region), after the main loop
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 CONFIGS = {"cfg2": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, table_slots=600_000_000, synth_cfg=2,
                         workload="cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31"),
+           "cfg5": dict(reads_per_gpu=75_000_000, genome_per_gpu=375_000_000, table_slots=1_600_000_000, synth_cfg=5, kmer=63, sub_rate=0.001,
+                        workload="cfg5 share of one GPU: synthetic 75 M x 150 bp reads (30x of 375 Mb; the stated job is 600 M reads of a 3 Gb "
+                                 "genome on 8 GPUs), 0.1% subst, 0.01% N, k=63, 128-bit keys, 32-byte nodes (WIDE engine, PARITY UNPINNED: the "
+                                 "reference stops at k=31)"),
            "cfg3": dict(reads_per_gpu=25_000_000, genome_per_gpu=125_000_000, table_slots=1_075_000_000, synth_cfg=3,
                         workload="cfg3: synthetic 200 M x 150 bp reads of a 1 Gb genome at N=8 (25 M reads, 125 Mb, 1.075 G slots per GPU; "
                                  "fewer GPUs run that share of it), 0.5% subst, 0.01% N, k=31, ONE table over all GPUs")}
@@ -51,14 +56,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
                     help="cfg2 (default, the weak-scaling line): BASELINE configs[1] PER GPU -- 10 M x 150 bp reads, 50 Mb of genome "
                          "and 600 M table slots per GPU; cfg3: BASELINE configs[2] split over the GPUs that are there -- 25 M reads, "
                          "125 Mb of genome and 1.075 G slots per GPU, i.e. at N = 8 the stated job: 200 M reads of a 1 Gb genome "
-                         "into ONE table of 8.6 G slots (~5.6 G nodes)")
+                         "into ONE table of 8.6 G slots (~5.6 G nodes); cfg5: one GPU's share of BASELINE configs[4] (k = 63, WIDE engine, "
+                         "single GPU only)")
     ap.add_argument("--reads-per-gpu", type=int, default=None)
     ap.add_argument("--genome-per-gpu", type=int, default=None)
-    ap.add_argument("--kmer", type=int, default=31)
+    ap.add_argument("--kmer", type=int, default=None)
     ap.add_argument("--table-slots", type=int, default=None, help="per GPU; rounded up by find_next_prime")
     ap.add_argument("--engine", type=int, default=2, help="1 = DIRECT (global atomics), 2 = PARTITION (default)")
     ap.add_argument("--exchange", choices=["records", "nodes"], default="records",
@@ -80,6 +86,10 @@ def parse_args():
     for key in ("reads_per_gpu", "genome_per_gpu", "table_slots"):
         if getattr(args, key) is None:
             setattr(args, key, CONFIGS[args.config][key])
+    if args.kmer is None:
+        args.kmer = CONFIGS[args.config].get("kmer", 31)
+    if args.config == "cfg5":
+        args.engine = 5   # capi.ENGINE_WIDE
     return args
 
 
@@ -201,7 +211,9 @@ def main():
     n_reads = args.reads_per_gpu
     genome_len = args.genome_per_gpu * world
     kpr = 150 - args.kmer + 1
-    P = capi.synth_params(genome_len, 150, cfg=CONFIGS[args.config]["synth_cfg"])
+    P = capi.synth_params(genome_len, 150, sub_rate=CONFIGS[args.config].get("sub_rate", 0.005), cfg=CONFIGS[args.config]["synth_cfg"])
+    if args.config == "cfg5" and multi:
+        sys.exit("bench.py --config cfg5: the WIDE engine is single-GPU (sharding of 128-bit keys is not built yet)")
     # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
     # (PARTITION engine, slot-range ownership; up to 2^34 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
@@ -281,7 +293,7 @@ def main():
                      "(count/kmers/digest %r, expected %r)" % (got[:3], want[:3]))
         verified = "count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (CPU oracle, full size)"
     value_incl_h2d = None
-    if world == 1 and not multi and not args.no_h2d and not (debug_mode or debug_l2):
+    if world == 1 and not multi and not args.no_h2d and args.config != "cfg5" and not (debug_mode or debug_l2):
         import numpy as np
         h_bases = d_bases.to_host(np.uint8, nb)
         h_off = d_off.to_host(np.uint64)
@@ -304,7 +316,7 @@ def main():
         # Per-kernel figures (HIP events on the library's own streams), each kernel with ITS OWN bytes:
         # level 1 reads the bases and writes one 8-byte record per k-mer, level 2 reads and writes every
         # record, the region build reads every record and writes every 16-byte table slot once.
-        l1_name = "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else \
+        l1_name = "k_wide_extract_insert" if args.engine == capi.ENGINE_WIDE else "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else \
                   ("k_extract_scatter_uniform" if tm.uniform_launches else "k_extract_scatter")  # equal-length reads take the former
         l1_ms = tm.insert_ms / args.steps
         l2_ms, build_ms, wall_ms = tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
@@ -314,7 +326,7 @@ def main():
                          "k_build_regions": kmers_step * 8.0 + slots_local * 16.0}
             kernel_ms = {l1_name: l1_ms, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
         else:
-            own_bytes = {l1_name: kmers_step * B_ALG}
+            own_bytes = {l1_name: kmers_step * (B_ALG if args.kmer <= 32 else 150.0 / kpr + 64.0)}
             kernel_ms = {l1_name: l1_ms}
         kernels = {}
         for kname, ms in kernel_ms.items():
@@ -327,7 +339,8 @@ def main():
         pipeline_ms = l1_ms + (wall_ms if wall_ms > 0 else l2_ms + build_ms)   # kernels only: the concurrent pair at its wall time
         # THE roofline figure of this path: algorithmic bytes of one step (33.25 B per k-mer) over
         # the WHOLE step time (ms_per_step: reset, mark, all kernels, finalize), against the 8 TB/s spec peak
-        achieved = kmers_step * B_ALG / (ms_per_step * 1e-3) / 1e9   # per GPU (every rank processes kmers_step per step)
+        b_alg = B_ALG if args.kmer <= 32 else 150.0 / kpr + 64.0   # 32-byte nodes: one read + one write = 64 B (65.70 B at k=63)
+        achieved = kmers_step * b_alg / (ms_per_step * 1e-3) / 1e9   # per GPU (every rank processes kmers_step per step)
         copy_bw = None
         if world == 1:
             try:
@@ -335,13 +348,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
         out = {
-            "metric": "M k-mers/s hashed (k=31, 150 bp)", "value": value, "unit": "M k-mers/s",
+            "metric": "M k-mers/s hashed (k=%d, 150 bp)" % args.kmer, "value": value, "unit": "M k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.kmer <= 32 else "u128",
             "data": "synthetic",
             "config": {"workload": CONFIGS[args.config]["workload"],
                        "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
-                       "nodes": res["count"], "engine": "partition" if args.engine == capi.ENGINE_PARTITION else "direct",
+                       "nodes": res["count"], "engine": {capi.ENGINE_PARTITION: "partition", capi.ENGINE_WIDE: "wide"}.get(args.engine, "direct"),
                        "parallelism": ("reads sharded by record x%d, k-mers owned by slot range of one global table "
                                        "(all-to-all of level-1 record buckets)" % world) if sharded else
                                       ("reads sharded by record x%d, keys owned by hash (aggregated nodes exchanged)" % world
@@ -349,9 +362,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "whole step: " + " -> ".join(kernel_ms), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
-                         "bytes_per_kmer": B_ALG, "kmers_per_step": kmers_step, "step_ms": ms_per_step,
+                         "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, None),
-                         "kernels_only_ms": pipeline_ms, "kernels_only_frac": kmers_step * B_ALG / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernels_only_ms": pipeline_ms, "kernels_only_frac": kmers_step * b_alg / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "l2_build_wall_ms": wall_ms, "l2_build_chunks": chunks, "kernels": kernels},
             "phases_ms_per_step": {"mark": tm.mark_ms / args.steps, "insert": tm.insert_ms / args.steps,
                                    "partition": tm.partition_ms / args.steps, "build": tm.build_ms / args.steps,
@@ -361,7 +374,7 @@ def main():
         }
         if world == 1:
             out["copy_bandwidth_GBs"] = copy_bw
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and args.kmer <= 32:   # (the reference has no k > 31 path to time)
                 out["cpu_baseline"], out["cpu_baseline_variants"] = cpu_baseline(args, genome_len)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
