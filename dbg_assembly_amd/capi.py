@@ -96,6 +96,8 @@ SYMBOLS = [
     ("dbgk_link_stats_device", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_wide_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_wide_partition_export", _i, [_vp, C.c_uint32, _vp, _u64, _vp]),
+    ("dbgk_wide_merge_nodes", _i, [_vp, _vp, _u64]),
     ("dbgk_seed_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_seed_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -339,6 +341,14 @@ class Graph:
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_wide_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_wide_export_host_table")
         return array, flags
+
+    def wide_partition_export(self, n_parts, d_nodes=None, capacity=0):
+        counts = np.zeros(n_parts, np.uint64)
+        _chk(lib().dbgk_wide_partition_export(self._h, n_parts, d_nodes, capacity, counts.ctypes.data), "dbgk_wide_partition_export")
+        return counts
+
+    def wide_merge_nodes(self, d_nodes, n):
+        _chk(lib().dbgk_wide_merge_nodes(self._h, d_nodes, n), "dbgk_wide_merge_nodes")
 
     # ---- SEEDIDX engine
     SEED_DTYPE = np.dtype([("kmer", "<u8"), ("payload", "<u8")])  # payload = {id:32, pos:30, freq:1, direct:1}

@@ -1772,6 +1772,71 @@ extern "C" int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, d
 	return DBGK_OK;
 }
 
+// several GPUs with 128-bit keys: nodes grouped by owner, merged by the owner (dbgk_partition_* / dbgk_merge_nodes for
+// 32-byte nodes).  counts[p] includes, for p == 0, this handle's key-0 node, which is written first.
+extern "C" int dbgk_wide_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node32 *d_nodes, uint64_t capacity, uint64_t *counts)
+{
+	if (!h || !counts || n_parts < 1 || n_parts > (uint32_t)kMaxParts) return DBGK_ERR_ARG;
+	if (!h->wide || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	unsigned long long *d_counts = nullptr;
+	if (hipMalloc(&d_counts, n_parts * 8) != hipSuccess) return DBGK_ERR_NOMEM;
+	std::vector<unsigned long long> hc(n_parts, 0);
+	hipError_t e = hipMemsetAsync(d_counts, 0, n_parts * 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, n_parts, d_counts,
+		                   (unsigned long long *)nullptr, (dbgk_node32 *)nullptr, (uint64_t)0);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_counts, n_parts * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) {
+		(void)hipFree(d_counts);
+		return hip_fail(e, "wide_partition_export/count", __LINE__);
+	}
+	hc[0] += 1; // the key-0 node travels with part 0
+	uint64_t total = 0;
+	std::vector<unsigned long long> cursors(n_parts);
+	for (uint32_t p = 0; p < n_parts; p++) {
+		counts[p] = hc[p];
+		cursors[p] = total + (p == 0 ? 1 : 0);
+		total += hc[p];
+	}
+	if (!d_nodes) { // counts only
+		(void)hipFree(d_counts);
+		return DBGK_OK;
+	}
+	if (total > capacity) {
+		(void)hipFree(d_counts);
+		return DBGK_ERR_CAPACITY;
+	}
+	const dbgk_node32 zero = {0, 0, (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu), (uint32_t)(h->h_ctr->polyA_links >> 32), 0};
+	e = hipMemcpyAsync(d_counts, cursors.data(), n_parts * 8, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, n_parts,
+		                   (unsigned long long *)nullptr, d_counts, d_nodes, capacity);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_counts);
+	if (e != hipSuccess) return hip_fail(e, "wide_partition_export", __LINE__);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_wide_merge_nodes(dbgk_handle *h, const dbgk_node32 *d_nodes, uint64_t n)
+{
+	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
+	if (!h->wide) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n == 0) return DBGK_OK;
+	hipLaunchKernelGGL(k_wide_merge_nodes, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, d_nodes, n, h->wref(), h->d_ctr);
+	HIPCHK(hipGetLastError());
+	return DBGK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // KFREQ exports
 // ---------------------------------------------------------------------------------------------

@@ -302,4 +302,85 @@ __global__ __launch_bounds__(kBlock) void k_wide_link_stats(const WNode *__restr
 	}
 }
 
+// ---- several GPUs: nodes grouped by owner = (hash128(key) >> 32) % n_parts, merged by the owner ----------------
+// (the flow of dbgk_partition_export / dbgk_merge_nodes for 32-byte nodes: every GPU builds the graph of its share
+// of the reads, ships each node to its owner, the owner adds the counters up -- exact for any split of the input
+// because min(255, min(255,a) + min(255,b)) == min(255, a+b))
+__device__ __forceinline__ uint32_t wide_owner_of(Key128 key, uint32_t n_parts)
+{
+	return (uint32_t)((dbgk_wide::hash128(key) >> 32) % n_parts);
+}
+
+// counts != null: count pass (counts[p] += nodes owned by p); else scatter pass: cursors[p] starts at the part's base
+// offset, every block reserves one range per part per sweep
+__global__ __launch_bounds__(kBlock) void k_wide_partition(const WNode *__restrict__ nodes, uint64_t size, const WNode *__restrict__ side,
+                                                           uint32_t n_parts, unsigned long long *__restrict__ counts,
+                                                           unsigned long long *__restrict__ cursors, dbgk_node32 *__restrict__ out, uint64_t capacity)
+{
+	__shared__ unsigned int local[kMaxParts];
+	__shared__ unsigned long long base[kMaxParts];
+	const uint64_t total = size + kWideSideSlots;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	const uint64_t n_iter = (total + stride - 1) / stride;
+	for (uint64_t it = 0; it < n_iter; it++) {
+		if (threadIdx.x < kMaxParts) local[threadIdx.x] = 0;
+		__syncthreads();
+		const uint64_t i = it * stride + (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+		WNode nd = {0, 0, 0, 0};
+		if (i < total) nd = i < size ? nodes[i] : side[i - size];
+		const bool occ = i < total && (i < size ? nd.lo != 0ull : nd.hi1 != 0ull);
+		uint32_t part = 0, rank = 0;
+		if (occ) {
+			part = wide_owner_of(Key128{nd.hi1 - 1ull, nd.lo}, n_parts);
+			rank = atomicAdd(&local[part], 1u);
+		}
+		__syncthreads();
+		if (threadIdx.x < n_parts && local[threadIdx.x]) {
+			if (counts) atomicAdd(&counts[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+			else base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+		}
+		__syncthreads();
+		if (occ && !counts) {
+			const uint64_t dst = base[part] + rank;
+			if (dst < capacity) out[dst] = dbgk_node32{nd.hi1 - 1ull, nd.lo, (uint32_t)nd.links, (uint32_t)(nd.links >> 32), 0};
+		}
+		__syncthreads();
+	}
+}
+
+// insert-if-absent + per-byte saturating add of aggregated nodes; a key-0 node is folded into the side node
+__global__ __launch_bounds__(kBlock) void k_wide_merge_nodes(const dbgk_node32 *__restrict__ in, uint64_t n, WTable T, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+		const dbgk_node32 nd = in[i];
+		const Key128 key{nd.kmer_hi, nd.kmer_lo};
+		const uint64_t add = (uint64_t)nd.l_link | ((uint64_t)nd.r_link << 32);
+		if (dbgk_wide::is_zero(key)) { // another GPU's key-0 node (an all-zero record adds nothing)
+			links_cas_merge(&ctr->polyA_links, 0ull, add);
+			continue;
+		}
+		uint64_t guess;
+		if (key.lo == 0ull) {
+			const uint64_t s = wide_side_find_or_claim(T, key, guess, n_new);
+			if (s == ~0ull) { full = true; continue; }
+			links_cas_merge(&T.side[s].links, guess, add);
+			continue;
+		}
+		const uint64_t s = wide_find_or_claim(T, key, guess, n_new, n_conf);
+		if (s == ~0ull) { full = true; continue; }
+		links_cas_merge(&T.nodes[s].links, guess, add);
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+	if (full) atomicOr(&ctr->error, 1u);
+}
+
 } // namespace dbgk

@@ -223,6 +223,15 @@ int dbgk_wide_export_sorted(dbgk_handle *h, dbgk_node32 *out, uint64_t capacity,
  * reachable by linear probing from hash128(key) % host_size without crossing a clear flag, unused slots all-zero,
  * the key-0 node on key 0's chain -- the invariants of SURVEY 8(b) with the 128-bit hash                      */
 int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node32 *array, uint8_t *nul_flag);
+/* several GPUs: every GPU builds the graph of its share of the reads (reads shard by record), then ships each node to
+ * its owner, (hash128(key) >> 32) % n_parts -- the device analogue of the reference's `kmer % threadNum` ownership
+ * (DBGgraph.cpp:148) -- which adds the counters up (per-byte saturating, exact for any split of the input).
+ * dbgk_wide_partition_export: counts[p] = nodes owned by part p (this handle's key-0 node counts for part 0); with
+ * d_nodes != NULL the nodes are written grouped by owner into that DEVICE buffer (part p at sum(counts[0..p))).
+ * dbgk_wide_merge_nodes: insert-if-absent / saturating add of n nodes held in device memory of the handle's GPU;
+ * allowed before and after dbgk_finalize (dbgk_refresh_stats recounts).                                        */
+int dbgk_wide_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node32 *d_nodes, uint64_t capacity, uint64_t *counts);
+int dbgk_wide_merge_nodes(dbgk_handle *h, const dbgk_node32 *d_nodes, uint64_t n);
 
 /* ---- KFREQ engine: the k-mer frequency table of the correct_error module --------
  * The reference only CONSUMES this table (its producer, `kmerfreq`, is not part of the repository):

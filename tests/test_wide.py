@@ -171,3 +171,49 @@ def test_wide_engine_cfg5_shaped_sample_PARITY_UNPINNED(capi, oracle):
         assert np.array_equal(g.wide_export_sorted(), want)
         d_bases.free()
         d_off.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_parts", [(63, 3), (47, 2), (31, 4)])
+def test_wide_nodes_shipped_to_their_owners_PARITY_UNPINNED_above_k32(capi, oracle, k, n_parts):
+    """several GPUs with 128-bit keys (here: handles on the one GPU of the box): reads shard by record, every handle
+    builds the graph of its share, ships each node to its owner (hash128 >> 32) % n and the owners add the counters up
+    (dbgk_wide_partition_export / dbgk_wide_merge_nodes); the union of the owners' tables == the graph of all reads"""
+    rng = random.Random(k * 10 + n_parts)
+    reads = _reads(rng, 2500)
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    want, total = oracle.wide_build(bases, offsets, k, 250)
+    size = capi.find_next_prime_ref(3 * len(want))
+    mk = lambda: capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE)
+    sources, owners = [mk() for _ in range(n_parts)], [mk() for _ in range(n_parts)]
+    try:
+        for i, g in enumerate(sources):
+            g.push_reads(*oracle.pack_reads(reads[i::n_parts]))
+            g.finalize()
+        for g in sources:
+            counts = g.wide_partition_export(n_parts)
+            assert int(counts.sum()) == g.stats.count
+            buf = g.malloc(int(counts.sum()) * 32)
+            assert np.array_equal(g.wide_partition_export(n_parts, buf.ptr, int(counts.sum())), counts)
+            first = 0
+            for p in range(n_parts):
+                owners[p].wide_merge_nodes(buf.ptr + first * 32, int(counts[p]))
+                first += int(counts[p])
+            for o in owners:
+                o.sync()
+            buf.free()
+        got, key0_seen = [], 0
+        for p, o in enumerate(owners):
+            st = o.finalize()
+            nodes = o.wide_export_sorted()
+            if p:   # every handle reports a key-0 node; the real one was merged onto owner 0
+                assert nodes[0]["kmer_hi"] == 0 and nodes[0]["kmer_lo"] == 0 and nodes[0]["l_link"] == 0 and nodes[0]["r_link"] == 0
+                nodes = nodes[1:]
+            got.append(nodes)
+        got = np.sort(np.concatenate(got), order=["kmer_hi", "kmer_lo"])
+        assert np.array_equal(got, want)
+        assert sum(o.digest() for o in owners[:1]) % (1 << 64) != 0
+    finally:
+        for g in sources + owners:
+            g.close()
