@@ -329,7 +329,8 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 			}
 		}
 	}
-	lds_barrier(); // stage / hist are reused by the next tile; the global stores keep draining
+	// (level 1: no barrier here -- the next tile zeroes the histogram and packs its bytes, neither of which the
+	// copy-out reads, and then meets its first barrier before any record is parked in the stage buffer again)
 }
 
 // whole scatter for records held in registers (level 2)
@@ -578,13 +579,15 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
                                                 const uint32_t (&bkt)[16])
 {
 	lds_barrier(); // hist complete
-	uint32_t my_gbase[ScatterLds::kBpt];
-	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
-	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
+	// the parked records come back into registers BEFORE the reservation and the scan: the barriers inside the scan then
+	// also say that every thread has its records, and the stage buffer may be overwritten in sorted order right after
+	// (one barrier less per tile; with the one dropped after the copy-out: 5.53 -> 5.47 ms)
 	uint64_t rec[16];
 #pragma unroll
 	for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
-	lds_barrier(); // every parked record is in registers: the stage buffer may be overwritten in sorted order
+	uint32_t my_gbase[ScatterLds::kBpt];
+	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
+	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 	scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 }
 
