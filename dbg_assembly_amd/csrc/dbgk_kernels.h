@@ -146,16 +146,31 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 		if (b) atomicAdd(&ctr->stored_kmers, b);
 	}
 	if (dead_seen) atomicOr(&ctr->any_dead, 1u);
-	// shortest / longest read of the batch: equal => the partition engine's equal-length level-1 kernel applies
+	// shortest / longest read of the batch: equal => the partition engine's equal-length level-1 kernel applies.
+	// Reduced per BLOCK before the two atomics: thousands of same-address atomicMax (one pair per wave) serialise
+	// at the memory side and were most of this kernel's time.
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) {
 		const unsigned long long a2 = __shfl_down(len_lo, off, 64), b2 = __shfl_down(len_hi, off, 64);
 		len_lo = a2 < len_lo ? a2 : len_lo;
 		len_hi = b2 > len_hi ? b2 : len_hi;
 	}
-	if ((threadIdx.x & 63) == 0 && len_hi >= len_lo) {
-		atomicMax(&ctr->len_min_inv, ~len_lo);
-		atomicMax(&ctr->len_max, len_hi);
+	__shared__ unsigned long long lo_w[kBlock / 64], hi_w[kBlock / 64];
+	if ((threadIdx.x & 63) == 0) {
+		lo_w[threadIdx.x >> 6] = len_lo;
+		hi_w[threadIdx.x >> 6] = len_hi;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int w = 1; w < kBlock / 64; w++) {
+			len_lo = lo_w[w] < len_lo ? lo_w[w] : len_lo;
+			len_hi = hi_w[w] > len_hi ? hi_w[w] : len_hi;
+		}
+		if (len_hi >= len_lo) {
+			atomicMax(&ctr->len_min_inv, ~len_lo);
+			atomicMax(&ctr->len_max, len_hi);
+		}
 	}
 }
 
