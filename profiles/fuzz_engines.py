@@ -134,6 +134,11 @@ def build_sharded(reads, k, size, n_shards, rng, max_read_len, actual):
             for g in graphs:
                 if n:
                     g.shard_merge(p, n, is_triple=True)
+        for src in graphs:   # side tables of aggregated surplus (only where an overflow list ran full)
+            p, n = src.shard_heavy()
+            for g in graphs:
+                if n:
+                    g.shard_merge(p, n)
         for s, (p, n) in enumerate(out):
             if n:
                 graphs[(s + 1) % n_shards].shard_merge(p, n, from_previous_shard=True)

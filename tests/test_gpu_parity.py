@@ -510,6 +510,11 @@ def _sharded_build(capi, oracle, reads, n_shards, expected_per_shard, k=31, slot
             for g in graphs:
                 if n:
                     g.shard_merge(p, n, is_triple=True)
+        for src in graphs:              # ... and, where a rank's overflow list ran full, its side table of aggregated surplus
+            p, n = src.shard_heavy()
+            for g in graphs:
+                if n:
+                    g.shard_merge(p, n)
         for s, (p, n) in enumerate(out):  # nodes that ran off the end of shard s continue in shard s+1
             if n:
                 graphs[(s + 1) % n_shards].shard_merge(p, n, from_previous_shard=True)
@@ -627,6 +632,29 @@ def test_sharded_table_with_overflow_and_heavy_repeats(capi, oracle):
     assert n_ovf > 0
     assert sum(int(s.count) for s in final) == ref.count
     assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
+
+
+def test_sharded_heavy_hitters_beyond_the_overflow_list(capi, oracle):
+    """the heavy-hitter side table on SHARDED handles (round 1: none, such input ended in DBGK_ERR_CAPACITY): a tandem
+    repeat overflows its final buckets, the overflow lists fill up (1 M + 1/16 of the input), the surplus is aggregated
+    in every rank's side table, which is offered to all ranks after the build -- through the hand-written protocol of
+    _sharded_build and through the C++ communicator"""
+    rng = random.Random(98)
+    unit = "ACGGTCA"
+    reads = [(unit * 30)[rng.randint(0, 6):][:150].encode() for _ in range(40000)] + rand_reads(rng, 2000, G=20000)
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.002)
+    final, stats, nodes, infos, _, (n_ovf, n_out), size = _sharded_build(capi, oracle, reads, 2, ref.total_kmers // 2, want_tables=False)
+    assert n_ovf >= 2 * (1 << 20)   # both overflow lists ran full
+    assert sum(int(s.count) for s in final) == ref.count
+    assert np.array_equal(np.sort(nodes, order="kmer"), ref.nodes)
+    with capi.Comm(k=31, table_slots=capi.find_next_prime_ref(PART_SLOTS), devices=[0, 0, 0], expected_kmers=ref.total_kmers // 3) as c:
+        n = len(reads)
+        for a, b in zip(range(0, n, n // 6 + 1), list(range(n // 6 + 1, n, n // 6 + 1)) + [n]):
+            c.push_reads(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a])
+        st = c.finalize()
+        assert st.count == ref.count and c.digest() == oracle.nodes_digest(ref.nodes)
 
 
 # ------------------------------------------------------------------------------------------------
