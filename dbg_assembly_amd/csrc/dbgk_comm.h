@@ -429,14 +429,15 @@ extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbg
 	} else {
 		memset(array, 0, host_size * sizeof(dbgk_node));
 		memset(nul_flag, 0, host_size / 8 + 1);
-		for (dbgk_handle *h : c->h) {
-			const uint64_t len = h->tslots;
-			std::vector<dbgk_node> part(len);
-			std::vector<uint8_t> fl(len / 8 + 1);
-			int rc = dbgk_export_host_table(h, len, part.data(), fl.data());
+		for (dbgk_handle *h : c->h) { // only the occupied nodes of a shard travel (compacted on the device), not its whole slot range
+			dbgk_stats st;
+			fill_stats(h, &st);
+			std::vector<dbgk_node> part(st.count ? st.count : 1);
+			uint64_t n = 0;
+			int rc = dbgk_export_sorted(h, part.data(), part.size(), &n);
 			if (rc) return rc;
-			for (uint64_t i = 0; i < len; i++) {
-				if (part[i].kmer == 0) continue;
+			for (uint64_t i = 0; i < n; i++) {
+				if (part[i].kmer == 0) continue; // shard 0 lists the key-0 node: placed last, below
 				uint64_t hc = hash_code(part[i].kmer) % host_size;
 				while (flag_set(hc)) hc = (hc + 1 == host_size) ? 0 : hc + 1;
 				array[hc] = part[i];
