@@ -1133,7 +1133,8 @@ static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 template <int DBG>
 static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions, unsigned int *cursor)
 {
-	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 2u); // persistent: two 66-KiB workgroups fit a CU
+	static const int per_cu = getenv("DBGK_BUILD_PER_CU") ? std::max(1, atoi(getenv("DBGK_BUILD_PER_CU"))) : 2; // tuning knob
+	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * (uint32_t)per_cu); // persistent: two 66-KiB workgroups fit a CU
 	if (h->kfreq && h->incr)
 		hipLaunchKernelGGL((k_build_regions<0, true, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
 		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
