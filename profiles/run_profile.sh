@@ -31,14 +31,14 @@ PY
 } > $OUT/pmc_summary.csv
 fi
 cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
-# timeline of the LAST step of the trace: every dispatch with its start relative to the step's first kernel
+# timeline of the LAST timed step of the trace: every dispatch with its start relative to the step's first memset
 python3 - $OUT/kt/*/*kernel_trace.csv > $OUT/last_step_timeline.csv <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "k_mark" in r["Kernel_Name"] or "k_stats" in r["Kernel_Name"]]
-if marks:
-    rows = rows[marks[-1]:]
+marks = [i for i, r in enumerate(rows) if "k_mark" in r["Kernel_Name"]]
+if marks:   # from the memsets in front of the last step's k_mark to the end of the trace
+    rows = rows[max(marks[-1] - 6, 0):]
 t0 = int(rows[0]["Start_Timestamp"])
 print("kernel,start_us,end_us,dur_us,vgpr,lds")
 for r in rows:
