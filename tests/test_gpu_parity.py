@@ -365,6 +365,33 @@ def test_partition_engine_streaming_device_pushes_equal_one_shot(capi):
     assert res[0] == res[1]
 
 
+@pytest.mark.parametrize("n_reads", [1_600_000, 2_000_000])
+def test_streamed_build_at_high_load_equals_direct_engine(capi, n_reads):
+    """the incremental region build where it is stressed: the SMALLEST table the engine takes (2^26 slots) filled to
+    ~0.7 / ~0.85 by cfg2-shaped reads in four to five flush rounds -- regions near full, nodes spilling past their
+    region's end (merged through the global path, then FOREIGN blockers in the next region's image on every later
+    round), long probe chains.  Count, totals, digest and DepthStat must equal the DIRECT engine's (oracle-pinned)."""
+    G = 10_000_000
+    P = capi.synth_params(G, 150, cfg=2)
+    size = capi.find_next_prime_ref(1 << 26)
+    res = []
+    for engine, store in ((capi.ENGINE_DIRECT, 0), (capi.ENGINE_PARTITION, 60_000_000)):
+        with capi.Graph(k=31, table_slots=size, engine=engine, expected_kmers=store) as g:
+            pieces, per = 10, n_reads // 10
+            bufs = []
+            for i in range(pieces):
+                d_bases, d_off, nb = g.synth_reads_device(P, i * per, per)
+                g.push_reads_device(d_bases.ptr, d_off.ptr, per, nb)
+                bufs += [d_bases, d_off]
+            st = g.finalize()
+            res.append((int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest(), list(g.link_stats(2).depth_stat)))
+            load = st.count / size
+            for b in bufs:
+                b.free()
+    assert res[0] == res[1]
+    assert load > (0.65 if n_reads < 2_000_000 else 0.8)
+
+
 def test_partition_engine_bucket_overflow_goes_through_direct_path(capi, oracle):
     """expected_kmers far too small + one heavily repeated read: bucket capacities overflow and
     the excess records take the global-atomic path; the result must not change"""
