@@ -365,10 +365,10 @@ def test_partition_engine_streaming_device_pushes_equal_one_shot(capi):
     assert res[0] == res[1]
 
 
-@pytest.mark.parametrize("n_reads", [1_600_000, 2_000_000])
+@pytest.mark.parametrize("n_reads", [2_000_000, 2_800_000])
 def test_streamed_build_at_high_load_equals_direct_engine(capi, n_reads):
     """the incremental region build where it is stressed: the SMALLEST table the engine takes (2^26 slots) filled to
-    ~0.7 / ~0.85 by cfg2-shaped reads in four to five flush rounds -- regions near full, nodes spilling past their
+    ~0.67 / ~0.87 by cfg2-shaped reads in four to six flush rounds -- regions near full, nodes spilling past their
     region's end (merged through the global path, then FOREIGN blockers in the next region's image on every later
     round), long probe chains.  Count, totals, digest and DepthStat must equal the DIRECT engine's (oracle-pinned)."""
     G = 10_000_000
@@ -389,7 +389,7 @@ def test_streamed_build_at_high_load_equals_direct_engine(capi, n_reads):
             for b in bufs:
                 b.free()
     assert res[0] == res[1]
-    assert load > (0.65 if n_reads < 2_000_000 else 0.8)
+    assert load > (0.6 if n_reads < 2_500_000 else 0.8)
 
 
 def test_partition_engine_bucket_overflow_goes_through_direct_path(capi, oracle):
