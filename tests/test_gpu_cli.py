@@ -124,3 +124,34 @@ def test_cli_multi_gpu_path(tmp_path, case, gpus, store):
     ref = case["ref"]
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert re.search(r"^array_size:\t%d$" % ref["size"], r.stderr, re.M)
+
+
+@pytest.mark.parametrize("store", [None, "300000000"], ids=["one_build", "four_flush_rounds"])
+def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, oracle, store):
+    """The FULL BASELINE cfg2 workload (10 M x 150 bp reads as a 1.6 GB one-line FASTA file) through the command line:
+    node count, totals and `<prefix>.contig.kmer.freq` (DepthStat rows 1..255) == tests/golden/cfg2_full.json, which the
+    CPU oracle computed at full size.  Second run: a record store of 300 M occurrences, i.e. the input streams through
+    four flush rounds of the PARTITION engine (incremental region builds over the whole 9.6 GB table)."""
+    import ctypes as C
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg2_full.json")))
+    fa = str(tmp_path / "reads.fa")
+    PO = oracle.synth_params(gold["genome_len"], 150, cfg=2)
+    oracle.lib().orc_synth_write_file(C.byref(PO), 0, gold["n_reads"], os.fsencode(fa), 2, 0)
+    lib = tmp_path / "reads.lib"
+    lib.write_text(fa + "\n")
+    prefix = tmp_path / "out"
+    env = dict(os.environ, DBGK_TIMINGS="1")
+    if store:
+        env["DBGK_STORE_KMERS"] = store
+    r = subprocess.run([CLI, "-k", "31", "-f", "2", "-i", "0.6", "-t", "16", "-o", str(prefix), str(lib)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stderr
+    assert re.search(r"^count:\t%d$" % gold["count"], log, re.M)
+    assert "Total number of reads loaded into memory: %d" % gold["total_reads"] in log
+    assert "Total number of kmers loaded into memory: %d" % gold["total_kmers"] in log
+    assert "engine partition" in log
+    rows = open(str(prefix) + ".contig.kmer.freq").read().splitlines()
+    assert rows[0] == KMER_FREQ_HEADER and [int(x.split("\t")[1]) for x in rows[1:]] == gold["depth_stat"][1:]
+    os.remove(fa)
