@@ -361,11 +361,11 @@ static int plan_partition(dbgk_handle *h)
 	}
 	uint32_t r = 22; // measured on cfg2 (round 2, profiles/r02_r_sweep.txt): r = 20 / 21 / 22 -> 17.3 / 16.5 / 16.3 ms per step
 	if (const char *e = getenv("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(24, atoi(e))); // tuning knob: level-1 bucket = slot >> r
-	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kMaxBuckets) r++;
+	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kL1MaxB) r++;
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
-	while (r > 20 && qbits + (int)r + 6 > 64 && ((h->size + (1ull << (r - 1)) - 1) >> (r - 1)) <= (uint64_t)kMaxBuckets) r--; // small tables: q needs the bits
+	while (r > 20 && qbits + (int)r + 6 > 64 && ((h->size + (1ull << (r - 1)) - 1) >> (r - 1)) <= (uint64_t)kL1MaxB) r--; // small tables: q needs the bits
 	// level 1 fans out to <= 1024 buckets, level 2 to 2^(r-12) <= 4096 final buckets per level-1 bucket: 2^34 slots
 	const bool feasible = (1u << (r - kRegionBits)) <= (uint32_t)kMaxBucketsL2 && (qbits + (int)r + 6) <= 64 && h->size >= (1ull << 26) &&
 	                      h->size < (1ull << 34);
@@ -791,7 +791,7 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	c15 = q15 * 15u - W < q16 * 16u - W;
 	const uint64_t Q = c15 ? q15 : q16, C = c15 ? 15 : 16;
 	if (Q >= 2048 || n_reads * Q >= (1ull << 32)) return 0;
-	if ((1024 / Q + 2) * L + 96 > (uint64_t)kPkWords * 16) return 0; // bytes a tile of 1024 lanes can touch
+	if (((uint64_t)kL1Threads / Q + 2) * L + 96 > (uint64_t)kPkWords * 16) return 0; // bytes a tile of kL1Threads lanes can touch
 	U.L = (uint32_t)L;
 	U.W = W;
 	U.Q = (uint32_t)Q;
@@ -881,7 +881,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
-		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu);
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (1024 / kL1Threads));
 		const int wide = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
 		const bool ragged = umode == 2;
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
@@ -901,7 +901,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 #undef DBGK_LAUNCH_UNIFORM
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
-		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu); // 140 KiB of LDS: one workgroup per CU
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (1024 / kL1Threads)); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
 		const int wide_d = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
 		if (wide_d == 2 && has_long)

@@ -29,7 +29,14 @@ namespace dbgk {
 constexpr int kRegionBits = 12;                 // 4096 slots = 64 KiB of nodes per region
 constexpr int kRegionSlots = 1 << kRegionBits;
 constexpr int kSpillSlots = 128;                // LDS slots past the region end: probe overflow
-constexpr int kTileThreads = 1024;              // level 1: 16 waves, 16384-record tiles (level 2: kL2Threads below)
+#ifndef DBGK_L1_THREADS
+#define DBGK_L1_THREADS 1024
+#endif
+#ifndef DBGK_L1_MAXB
+#define DBGK_L1_MAXB 1024
+#endif
+constexpr int kTileThreads = DBGK_L1_THREADS;   // level 1: 16 waves, 16384-record tiles (level 2: kL2Threads below)
+constexpr int kL1MaxB = DBGK_L1_MAXB;           // level-1 fan-out limit (histogram size of the level-1 kernels)
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
 constexpr int kSubStores = 1;                   // level-1 sub-stores per bucket (8 = one per XCD was measured: 7.04 ms against 7.07, so off)
 constexpr int kL1Threads = kTileThreads;
@@ -177,7 +184,7 @@ struct ScatterLdsT {
 	Desc desc[MAXB];                 // copy-out descriptor per bucket (scatter_stage_copy)
 	uint32_t wave_tot[THREADS / 64];
 };
-using ScatterLds = ScatterLdsT<kTileThreads>;   // level 1: 16384-record tiles, one workgroup per CU
+using ScatterLds = ScatterLdsT<kTileThreads, kL1MaxB>;   // level 1: 16384-record tiles, one workgroup per CU
 #ifndef DBGK_L2_THREADS
 #define DBGK_L2_THREADS 512
 #endif
@@ -520,7 +527,7 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 	const uint32_t lwc = ~c.lw, nbc = ~c.nb;
 	uint32_t rev_mask = 0, key_min = ~0u;
 #pragma unroll
-	for (uint32_t i = NPOS; i < 16; i++) bkt[i] = (uint32_t)kMaxBuckets << 16; // lanes own NPOS positions: the rest never holds a record
+	for (uint32_t i = NPOS; i < 16; i++) bkt[i] = (uint32_t)kL1MaxB << 16; // lanes own NPOS positions: the rest never holds a record
 #pragma unroll
 	for (uint32_t i = 0; i < (uint32_t)NPOS; i++) {
 		const uint32_t sh = 30u - 2u * i;
@@ -553,7 +560,7 @@ __device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, C
 		const bool valid = (c.valid >> i) & 1u;
 		const bool zero = key == 0ull;
 		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
-		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kMaxBuckets + (tid & 63u);
+		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kL1MaxB + (tid & 63u);
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 		// roll to the next position (DBGgraph.cpp:71-73)
 		c.kbit = ((c.kbit << 2) | right) & head_mask;
@@ -619,7 +626,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 		const uint32_t tid = fresh_tid();
 		const uint64_t chunk = tile * kL1Threads + tid;
 		uint32_t bkt[16]; // (bucket << 16) | rank once the position has been processed
-		L.hist[tid] = 0;
+#pragma unroll
+		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[ScatterLds::kBpt * tid + j] = 0;
 		lds_barrier();
 		Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
 		if (chunk >= n_chunks) c.valid = 0u;
@@ -667,7 +675,7 @@ struct UniformGeom {
 	uint64_t n_lanes;    // n_reads * Q
 };
 
-constexpr int kPkWords = 1792; // packed words of one tile's byte range: <= 1024 lanes * 16 (1 + (k - 1) / W) bases + slack
+constexpr int kPkWords = 1792 * kTileThreads / 1024; // packed words of one tile's byte range: <= 1024 lanes * 16 (1 + (k - 1) / W) bases + slack
 struct UniformLds {
 	ScatterLds s;
 	uint32_t pk[kPkWords];
@@ -773,7 +781,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		if (tid < raw.n_blocks) UL.pk[tid] = pack16_ascii(raw.a);
 		if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
 		uint32_t bkt[16];
-		L.hist[tid] = 0;
+#pragma unroll
+		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[ScatterLds::kBpt * tid + j] = 0;
 		lds_barrier();
 		const uint64_t p = raw.p;                        // flat position of the lane's first window
 		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
