@@ -102,6 +102,8 @@ SYMBOLS = [
     ("dbgk_seed_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
     ("dbgk_kfreq_export_bits", _i, [_vp, C.c_uint32, _u64, _u64, _vp]),
+    ("dbgk_kfreq_merge_counts", _i, [_vp, _vp, _u64, _u64]),
+    ("dbgk_kfreq_device_counts", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("dbgk_extract_kmers", _i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("dbgk_partition_counts", _i, [_vp, C.c_uint32, _vp]),
     ("dbgk_partition_export", _i, [_vp, C.c_uint32, _vp, _u64]),
@@ -128,6 +130,8 @@ SYMBOLS = [
     ("dbgk_comm_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_comm_link_stats", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_comm_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_comm_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
+    ("dbgk_comm_kfreq_export_bits", _i, [_vp, C.c_uint32, _u64, _u64, _vp]),
     ("dbgk_synth_reads_device", _i, [_vp, C.POINTER(SynthParams), _u64, _u64, _vp, _vp]),
     ("dbgk_device_malloc", _i, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("dbgk_device_free", _i, [_vp, _vp]),
@@ -379,6 +383,16 @@ class Graph:
         _chk(lib().dbgk_kfreq_export_bits(self._h, cutoff, first_byte, n_bytes, out.ctypes.data), "dbgk_kfreq_export_bits")
         return out
 
+    def kfreq_device_counts(self):
+        """(device address, number of counters) of a finalized KFREQ handle"""
+        ptr, n = C.c_void_p(), _u64()
+        _chk(lib().dbgk_kfreq_device_counts(self._h, C.byref(ptr), C.byref(n)), "dbgk_kfreq_device_counts")
+        return int(ptr.value), int(n.value)
+
+    def kfreq_merge_counts(self, d_counts, first, n):
+        """counts[first, first + n) += n counters in device memory of this GPU (saturating)"""
+        _chk(lib().dbgk_kfreq_merge_counts(self._h, C.c_void_p(int(d_counts)), first, n), "dbgk_kfreq_merge_counts")
+
     # ---- sharded table (slot-range ownership)
     def shard_info(self):
         info = ShardInfo()
@@ -448,9 +462,9 @@ class Graph:
 class Comm:
     """N sharded handles of one table inside this process (dbgk_comm_*): the C++ host layer's multi-GPU path."""
 
-    def __init__(self, k, table_slots, devices, max_read_len=250, expected_kmers=0, max_batch_bases=0):
+    def __init__(self, k, table_slots, devices, max_read_len=250, expected_kmers=0, max_batch_bases=0, engine=ENGINE_PARTITION):
         self._c = None
-        cfg = Config(k, max_read_len, table_slots, 0, ENGINE_PARTITION, max_batch_bases, expected_kmers, 0, 0, 0)
+        cfg = Config(k, max_read_len, table_slots, 0, engine, max_batch_bases, expected_kmers, 0, 0, 0)
         dev = (C.c_int32 * len(devices))(*devices)
         c = C.c_void_p()
         _chk(lib().dbgk_comm_create(C.byref(cfg), dev, len(devices), C.byref(c)), "dbgk_comm_create")
@@ -505,6 +519,19 @@ class Comm:
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_comm_export_host_table(self._c, size, array.ctypes.data, flags.ctypes.data), "dbgk_comm_export_host_table")
         return array, flags
+
+    # ---- a communicator of frequency tables (engine=ENGINE_KFREQ)
+    def kfreq_counts(self, first=0, n=None):
+        n = 4 ** self.k - first if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        _chk(lib().dbgk_comm_kfreq_export_counts(self._c, first, n, out.ctypes.data), "dbgk_comm_kfreq_export_counts")
+        return out
+
+    def kfreq_bits(self, cutoff, first_byte=0, n_bytes=None):
+        n_bytes = 4 ** self.k // 8 - first_byte if n_bytes is None else n_bytes
+        out = np.empty(n_bytes, dtype=np.uint8)
+        _chk(lib().dbgk_comm_kfreq_export_bits(self._c, cutoff, first_byte, n_bytes, out.ctypes.data), "dbgk_comm_kfreq_export_bits")
+        return out
 
 
 # ---- host helpers mirrored from the reference (kmerSet.cpp:72-95), needed to size tables ---------

@@ -1294,6 +1294,8 @@ static int build_from_records(dbgk_handle *h)
 	return rc;
 }
 
+static int kfreq_summary(dbgk_handle *h, uint64_t first, uint64_t n, unsigned long long res[2]);
+
 extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 {
 	if (!h) return DBGK_ERR_ARG;
@@ -1311,17 +1313,9 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 		}
 	}
 	if (h->kfreq) {
-		unsigned long long *d_sum = nullptr, res[2] = {0, 0};
-		if (hipMalloc(&d_sum, 16) != hipSuccess) return DBGK_ERR_NOMEM;
-		hipError_t e = hipMemsetAsync(d_sum, 0, 16, h->stream);
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(k_counts_summary, dim3(grid_for(h, h->n_counts >> 3)), dim3(kBlock), 0, h->stream, h->counts, h->n_counts, d_sum);
-			e = hipGetLastError();
-		}
-		if (e == hipSuccess) e = hipMemcpyAsync(res, d_sum, 16, hipMemcpyDeviceToHost, h->stream);
-		if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-		(void)hipFree(d_sum);
-		if (e != hipSuccess) return hip_fail(e, "kfreq summary", __LINE__);
+		unsigned long long res[2];
+		rc = kfreq_summary(h, 0, h->n_counts, res);
+		if (rc) return rc;
 		h->kf_distinct = res[0];
 		h->kf_sum = res[1];
 	}
@@ -1352,6 +1346,11 @@ extern "C" int dbgk_refresh_stats(dbgk_handle *h, dbgk_stats *out)
 	rc = read_counters(h);
 	if (rc) return rc;
 	fill_stats(h, out);
+	if (h->kfreq && h->finalized) { // distinct canonical k-mers, as dbgk_finalize reports them
+		out->count = h->kf_distinct;
+		out->count_conflict = 0;
+		out->table_slots = h->n_counts;
+	}
 	return (h->h_ctr->error & 1u) ? DBGK_ERR_TABLE_FULL : DBGK_OK;
 }
 
@@ -1872,6 +1871,57 @@ extern "C" int dbgk_kfreq_export_bits(dbgk_handle *h, uint32_t cutoff, uint64_t 
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	(void)hipFree(d_bits);
 	if (e != hipSuccess) return hip_fail(e, "kfreq_export_bits", __LINE__);
+	return DBGK_OK;
+}
+
+// counts[first_kmer, first_kmer + n) += another partial table's slice held in device memory of this GPU
+// (saturating).  The distinct-k-mer count of the handle is recomputed.
+static int kfreq_summary(dbgk_handle *h, uint64_t first, uint64_t n, unsigned long long res[2])
+{
+	unsigned long long *d_sum = nullptr;
+	res[0] = res[1] = 0;
+	if (hipMalloc(&d_sum, 16) != hipSuccess) return DBGK_ERR_NOMEM;
+	hipError_t e = hipMemsetAsync(d_sum, 0, 16, h->stream);
+	if (e == hipSuccess && n) {
+		hipLaunchKernelGGL(k_counts_summary, dim3(grid_for(h, n >> 3)), dim3(kBlock), 0, h->stream, h->counts + first, n, d_sum);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(res, d_sum, 16, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	(void)hipFree(d_sum);
+	if (e != hipSuccess) return hip_fail(e, "kfreq summary", __LINE__);
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_kfreq_merge_counts(dbgk_handle *h, const uint8_t *d_counts, uint64_t first_kmer, uint64_t n)
+{
+	if (!h || !d_counts) return DBGK_ERR_ARG;
+	if (!h->kfreq || !h->finalized) return DBGK_ERR_STATE;
+	if (first_kmer > h->n_counts || n > h->n_counts - first_kmer) return DBGK_ERR_ARG;
+	if ((first_kmer & 15u) || (n & 15u) || ((uintptr_t)d_counts & 15u)) {
+		g_last_error = "dbgk_kfreq_merge_counts: first_kmer, n and the source address must be multiples of 16";
+		return DBGK_ERR_ARG;
+	}
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n) {
+		hipLaunchKernelGGL(k_counts_merge, dim3(grid_for(h, n >> 4)), dim3(kBlock), 0, h->stream, h->counts + first_kmer, d_counts, n);
+		HIPCHK(hipGetLastError());
+	}
+	unsigned long long res[2];
+	rc = kfreq_summary(h, 0, h->n_counts, res);
+	if (rc) return rc;
+	h->kf_distinct = res[0];
+	h->kf_sum = res[1];
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_kfreq_device_counts(dbgk_handle *h, uint8_t **d_counts, uint64_t *n)
+{
+	if (!h || !d_counts || !n) return DBGK_ERR_ARG;
+	if (!h->kfreq || !h->finalized) return DBGK_ERR_STATE;
+	*d_counts = h->counts;
+	*n = h->n_counts;
 	return DBGK_OK;
 }
 

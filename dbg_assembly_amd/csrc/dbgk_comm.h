@@ -26,6 +26,11 @@ struct dbgk_comm {
 	uint32_t next_push = 0;
 	uint32_t pieces = 8;
 	bool finalized = false;
+	// KFREQ communicators: every member counts its reads into a whole table of its own; at finalize member d
+	// becomes the owner of the k-mer values [kf_lo[d], kf_lo[d+1]) and adds the other members' slices to its own
+	bool kfreq = false;
+	std::vector<uint64_t> kf_lo;
+	uint64_t kf_distinct = 0;
 };
 
 static int comm_copy(dbgk_handle *dst, void *d_dst, dbgk_handle *src, const void *d_src, size_t bytes, hipStream_t stream)
@@ -70,9 +75,15 @@ extern "C" int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, 
 	for (uint32_t i = 0; i < n; i++) {
 		dbgk_config one = *cfg;
 		one.device_id = devices[i];
-		one.engine = DBGK_ENGINE_PARTITION;
-		one.shard_count = n;
-		one.shard_index = i;
+		if (cfg->engine == DBGK_ENGINE_KFREQ) {
+			c->kfreq = true;
+			one.shard_count = 0;
+			one.shard_index = 0;
+		} else {
+			one.engine = DBGK_ENGINE_PARTITION;
+			one.shard_count = n;
+			one.shard_index = i;
+		}
 		int rc = dbgk_create(&one, &c->h[i]);
 		if (rc == DBGK_OK && hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking) != hipSuccess) rc = DBGK_ERR_HIP;
 		if (rc == DBGK_OK && hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess) rc = DBGK_ERR_HIP;
@@ -267,6 +278,13 @@ static int comm_exchange_and_build(dbgk_comm *c)
 extern "C" int dbgk_comm_flush(dbgk_comm *c)
 {
 	if (!c || c->finalized) return DBGK_ERR_STATE;
+	if (c->kfreq) { // members are independent until finalize
+		for (dbgk_handle *h : c->h) {
+			const int rc = dbgk_flush(h);
+			if (rc) return rc;
+		}
+		return DBGK_OK;
+	}
 	bool pending = false;
 	for (dbgk_handle *h : c->h) pending = pending || h->pending_kmers > 0;
 	if (!pending) return DBGK_OK;
@@ -291,6 +309,10 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 	if (!c || !offsets) return DBGK_ERR_ARG;
 	if (c->finalized) return DBGK_ERR_STATE;
 	dbgk_handle *h = c->h[c->next_push];
+	if (c->kfreq) { // the member streams through its own record store
+		c->next_push = (c->next_push + 1) % (uint32_t)c->h.size();
+		return dbgk_push_reads(h, bases, offsets, n_reads);
+	}
 	uint64_t windows = 0;
 	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
 	for (uint64_t i = 0; i < n_reads; i++) {
@@ -303,6 +325,119 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 	}
 	c->next_push = (c->next_push + 1) % (uint32_t)c->h.size();
 	return dbgk_push_reads(h, bases, offsets, n_reads);
+}
+
+// KFREQ: the reduce-scatter of SURVEY 8(e)-4 with the exact combination rule (saturating byte add) instead of a
+// wrapping sum.  Owner d pulls the slice of every other member through two staging buffers of kStage bytes on its
+// own GPU: the peer copy of chunk j+1 (copy stream) runs while chunk j is added (the handle's stream).
+static int comm_kfreq_finalize(dbgk_comm *c)
+{
+	const uint32_t n = (uint32_t)c->h.size();
+	for (dbgk_handle *h : c->h) {
+		const int rc = dbgk_finalize(h, nullptr);
+		if (rc) return rc;
+	}
+	const uint64_t total = c->h[0]->n_counts;
+	c->kf_lo.assign(n + 1, 0);
+	for (uint32_t d = 0; d <= n; d++) c->kf_lo[d] = d == n ? total : (uint64_t)((unsigned __int128)total * d / n) & ~(uint64_t)1023; // 4^k >= 1024 for k >= 5
+	c->kf_distinct = 0;
+	if (n == 1) {
+		c->kf_distinct = c->h[0]->kf_distinct;
+		return DBGK_OK;
+	}
+	const uint64_t kStage = getenv("DBGK_COMM_KFREQ_STAGE_MB") ? (uint64_t)std::max(1, atoi(getenv("DBGK_COMM_KFREQ_STAGE_MB"))) << 20 : 256ull << 20;
+	struct Owner {
+		uint8_t *stage[2] = {nullptr, nullptr};
+		hipEvent_t arrived[2] = {nullptr, nullptr}, merged[2] = {nullptr, nullptr};
+		uint64_t chunks = 0;
+	};
+	std::vector<Owner> own(n);
+	int rc = DBGK_OK;
+	auto fail = [&](hipError_t e, int line) { if (e != hipSuccess && rc == DBGK_OK) rc = hip_fail(e, "kfreq reduce", line); return e != hipSuccess; };
+	for (uint32_t d = 0; d < n && rc == DBGK_OK; d++) {
+		if (use_device(c->h[d])) { rc = DBGK_ERR_HIP; break; }
+		for (int b = 0; b < 2 && rc == DBGK_OK; b++) {
+			if (hipMalloc(&own[d].stage[b], kStage) != hipSuccess) { (void)hipGetLastError(); rc = DBGK_ERR_NOMEM; break; }
+			if (fail(hipEventCreateWithFlags(&own[d].arrived[b], hipEventDisableTiming), __LINE__)) break;
+			if (fail(hipEventCreateWithFlags(&own[d].merged[b], hipEventDisableTiming), __LINE__)) break;
+		}
+	}
+	// all owners advance together, one chunk of one source at a time, so that every link carries traffic
+	for (uint32_t step = 1; step < n && rc == DBGK_OK; step++)
+		for (uint64_t off = 0;; off += kStage) {
+			bool any = false;
+			for (uint32_t d = 0; d < n && rc == DBGK_OK; d++) {
+				const uint64_t lo = c->kf_lo[d] + off, hi = c->kf_lo[d + 1];
+				if (lo >= hi) continue;
+				any = true;
+				dbgk_handle *hd = c->h[d], *hs = c->h[(d + step) % n];
+				Owner &o = own[d];
+				const uint64_t bytes = std::min(kStage, hi - lo);
+				const int b = (int)(o.chunks & 1);
+				if (use_device(hd)) { rc = DBGK_ERR_HIP; break; }
+				if (o.chunks >= 2 && fail(hipStreamWaitEvent(c->copy_stream[d], o.merged[b], 0), __LINE__)) break;
+				rc = comm_copy(hd, o.stage[b], hs, hs->counts + lo, bytes, c->copy_stream[d]);
+				if (rc) break;
+				if (fail(hipEventRecord(o.arrived[b], c->copy_stream[d]), __LINE__)) break;
+				if (fail(hipStreamWaitEvent(hd->stream, o.arrived[b], 0), __LINE__)) break;
+				hipLaunchKernelGGL(k_counts_merge, dim3(grid_for(hd, bytes >> 4)), dim3(kBlock), 0, hd->stream, hd->counts + lo, o.stage[b], bytes);
+				if (fail(hipGetLastError(), __LINE__)) break;
+				if (fail(hipEventRecord(o.merged[b], hd->stream), __LINE__)) break;
+				o.chunks++;
+			}
+			if (!any || rc) break;
+		}
+	for (uint32_t d = 0; d < n; d++) {
+		if (use_device(c->h[d])) continue;
+		(void)hipStreamSynchronize(c->copy_stream[d]);
+		(void)hipStreamSynchronize(c->h[d]->stream);
+		for (int b = 0; b < 2; b++) {
+			if (own[d].stage[b]) (void)hipFree(own[d].stage[b]);
+			if (own[d].arrived[b]) (void)hipEventDestroy(own[d].arrived[b]);
+			if (own[d].merged[b]) (void)hipEventDestroy(own[d].merged[b]);
+		}
+	}
+	if (rc) return rc;
+	for (uint32_t d = 0; d < n; d++) {
+		rc = use_device(c->h[d]);
+		if (rc) return rc;
+		unsigned long long res[2];
+		rc = kfreq_summary(c->h[d], c->kf_lo[d], c->kf_lo[d + 1] - c->kf_lo[d], res);
+		if (rc) return rc;
+		c->kf_distinct += res[0];
+	}
+	return DBGK_OK;
+}
+
+// the table of the whole job: every range is read from the member that owns it
+extern "C" int dbgk_comm_kfreq_export_counts(dbgk_comm *c, uint64_t first_kmer, uint64_t n, uint8_t *host_out)
+{
+	if (!c || !host_out) return DBGK_ERR_ARG;
+	if (!c->kfreq || !c->finalized) return DBGK_ERR_STATE;
+	const uint64_t total = c->h[0]->n_counts;
+	if (first_kmer > total || n > total - first_kmer) return DBGK_ERR_ARG;
+	for (size_t d = 0; d < c->h.size(); d++) {
+		const uint64_t lo = std::max(first_kmer, c->kf_lo[d]), hi = std::min(first_kmer + n, c->kf_lo[d + 1]);
+		if (lo >= hi) continue;
+		const int rc = dbgk_kfreq_export_counts(c->h[d], lo, hi - lo, host_out + (lo - first_kmer));
+		if (rc) return rc;
+	}
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_comm_kfreq_export_bits(dbgk_comm *c, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out)
+{
+	if (!c || !host_out) return DBGK_ERR_ARG;
+	if (!c->kfreq || !c->finalized) return DBGK_ERR_STATE;
+	const uint64_t total_bytes = c->h[0]->n_counts >> 3;
+	if (first_byte > total_bytes || n_bytes > total_bytes - first_byte) return DBGK_ERR_ARG;
+	for (size_t d = 0; d < c->h.size(); d++) { // slice bounds are multiples of 1024 k-mers = 128 bytes of the bit table
+		const uint64_t lo = std::max(first_byte, c->kf_lo[d] >> 3), hi = std::min(first_byte + n_bytes, c->kf_lo[d + 1] >> 3);
+		if (lo >= hi) continue;
+		const int rc = dbgk_kfreq_export_bits(c->h[d], cutoff, lo, hi - lo, host_out + (lo - first_byte));
+		if (rc) return rc;
+	}
+	return DBGK_OK;
 }
 
 static void comm_sum_stats(dbgk_comm *c, dbgk_stats *out)
@@ -318,6 +453,12 @@ static void comm_sum_stats(dbgk_comm *c, dbgk_stats *out)
 		out->count_conflict += st.count_conflict;
 	}
 	out->table_slots = c->h[0]->size;
+	if (c->kfreq) {
+		out->count = c->kf_distinct;
+		out->count_conflict = 0;
+		out->table_slots = c->h[0]->n_counts;
+		return;
+	}
 	const Counters &c0 = *c->h[0]->h_ctr;
 	out->polyA_l_link = (uint32_t)(c0.polyA_links & 0xFFFFFFFFu);
 	out->polyA_r_link = (uint32_t)(c0.polyA_links >> 32);
@@ -340,6 +481,13 @@ extern "C" int dbgk_comm_finalize(dbgk_comm *c, dbgk_stats *out)
 {
 	if (!c) return DBGK_ERR_ARG;
 	if (c->finalized) return DBGK_ERR_STATE;
+	if (c->kfreq) {
+		int rc = comm_kfreq_finalize(c);
+		if (rc) return rc;
+		c->finalized = true;
+		if (out) comm_sum_stats(c, out);
+		return DBGK_OK;
+	}
 	int rc = comm_exchange_and_build(c);
 	if (rc) return rc;
 	for (dbgk_handle *h : c->h) {

@@ -511,6 +511,35 @@ __global__ __launch_bounds__(kBlock) void k_counts_summary(const uint8_t *__rest
 	}
 }
 
+// counts[i] = min(255, counts[i] + other[i]) over n bytes (n a multiple of 16, both 16-byte aligned): the
+// combination rule of two partial frequency tables, exact because min(255, min(255,a) + min(255,b)) = min(255, a+b)
+// (SURVEY 8(e)).  Four counters per 32-bit word, byte-wise saturating add without unpacking.
+__device__ __forceinline__ uint32_t sat_add_u8x4(uint32_t a, uint32_t b)
+{
+	const uint32_t low = (a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu);         // 7-bit sums, carries stay inside their byte
+	const uint32_t carry = ((a & b) | ((a | b) & low)) & 0x80808080u;   // carry out of bit 7 of every byte
+	const uint32_t sum = low ^ ((a ^ b) & 0x80808080u);
+	return sum | ((carry >> 7) * 0xFFu);
+}
+
+__global__ __launch_bounds__(kBlock) void k_counts_merge(uint8_t *__restrict__ counts, const uint8_t *__restrict__ other, uint64_t n)
+{
+	const uint64_t n16 = n >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	uint4 *dst = reinterpret_cast<uint4 *>(counts);
+	const uint4 *src = reinterpret_cast<const uint4 *>(other);
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+		const uint4 b = src[i];
+		if ((b.x | b.y | b.z | b.w) == 0u) continue; // most of a sparse table
+		uint4 a = dst[i];
+		a.x = sat_add_u8x4(a.x, b.x);
+		a.y = sat_add_u8x4(a.y, b.y);
+		a.z = sat_add_u8x4(a.z, b.z);
+		a.w = sat_add_u8x4(a.w, b.w);
+		dst[i] = a;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // SEEDIDX engine: the seed index of the link_scaffold module,
 // chop_contig_to_kmerset (link_scaffold/map_func.cpp:119-173) over add_kmerset

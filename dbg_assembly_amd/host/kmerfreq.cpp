@@ -85,7 +85,8 @@ int main(int argc, char **argv)
 	cfg.max_read_len = max_read_len < k ? k : max_read_len;
 	cfg.engine = DBGK_ENGINE_KFREQ;
 	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
-	cfg.max_batch_bases = (128ull << 20) + 65536;
+	const uint64_t batch_bytes = getenv("DBGK_BATCH_BYTES") ? max<uint64_t>(1, strtoull(getenv("DBGK_BATCH_BYTES"), NULL, 10)) : (128ull << 20);
+	cfg.max_batch_bases = batch_bytes + 65536;
 	// partitioned counting (occurrences radix-partitioned by hash, aggregated per key in LDS; input of any size
 	// streams through the record store in rounds) unless -a asks for atomics on the byte table
 	if (!atomics && expected == 0) {
@@ -107,15 +108,37 @@ int main(int argc, char **argv)
 		if (expected < 1024) expected = 1024;
 	}
 	cfg.expected_kmers = atomics ? 0 : expected;
+	// several GPUs (DBGK_GPUS=N: devices 0..N-1, or DBGK_GPU_LIST=a,b,c): every GPU counts the batches dealt to it
+	// into a table of its own, the tables are combined by range at the end (dbgk_comm_* in include/dbgk.h)
+	vector<int32_t> devices;
+	if (const char *lst = getenv("DBGK_GPU_LIST")) {
+		for (const char *p = lst; *p;) {
+			devices.push_back((int32_t)strtol(p, const_cast<char **>(&p), 10));
+			while (*p == ',' || *p == ' ') p++;
+		}
+	} else if (const char *ng = getenv("DBGK_GPUS")) {
+		for (int i = 0; i < atoi(ng); i++) devices.push_back(i);
+	}
 	dbgk_handle *h = nullptr;
-	int rc = dbgk_create(&cfg, &h);
-	if (rc) die("dbgk_create", rc);
+	dbgk_comm *comm = nullptr;
+	int rc;
+	if (devices.size() > 1) {
+		if (cfg.expected_kmers) cfg.expected_kmers = max<uint64_t>(cfg.expected_kmers / devices.size(), 1024);
+		rc = dbgk_comm_create(&cfg, devices.data(), (uint32_t)devices.size(), &comm);
+		if (rc) die("dbgk_comm_create", rc);
+		cerr << "counting on " << devices.size() << " GPUs" << endl;
+	} else {
+		if (devices.size() == 1) cfg.device_id = devices[0];
+		rc = dbgk_create(&cfg, &h);
+		if (rc) die("dbgk_create", rc);
+	}
 
 	vector<char> bases;
 	vector<uint64_t> offsets(1, 0);
 	auto flush = [&]() {
 		if (offsets.size() > 1) {
-			rc = dbgk_push_reads(h, bases.data(), offsets.data(), offsets.size() - 1);
+			rc = comm ? dbgk_comm_push_reads(comm, bases.data(), offsets.data(), offsets.size() - 1)
+			          : dbgk_push_reads(h, bases.data(), offsets.data(), offsets.size() - 1);
 			if (rc) die("dbgk_push_reads", rc);
 		}
 		bases.clear();
@@ -129,13 +152,13 @@ int main(int argc, char **argv)
 		const bool ok = for_each_read_in_file(path, fmt, [&](const char *seq, size_t len) {
 			bases.insert(bases.end(), seq, seq + len);
 			offsets.push_back(bases.size());
-			if (bases.size() >= (128ull << 20)) flush();
+			if (bases.size() >= batch_bytes) flush();
 		});
 		if (!ok) cerr << "fail to open reads file " << path << endl;
 	}
 	flush();
 	dbgk_stats st;
-	rc = dbgk_finalize(h, &st);
+	rc = comm ? dbgk_comm_finalize(comm, &st) : dbgk_finalize(h, &st);
 	if (rc) die("dbgk_finalize", rc);
 	cerr << "reads " << st.total_reads << "  k-mers " << st.stored_kmers << "  distinct canonical k-mers " << st.count << endl;
 
@@ -158,8 +181,12 @@ int main(int argc, char **argv)
 				int erc;
 				{
 					lock_guard<mutex> g(*export_lock);
-					erc = bits == 1 ? dbgk_kfreq_export_bits(h, (uint32_t)cutoff, first / 8, nbytes, raw.data())
-					                : dbgk_kfreq_export_counts(h, first, n, raw.data());
+					if (comm)
+						erc = bits == 1 ? dbgk_comm_kfreq_export_bits(comm, (uint32_t)cutoff, first / 8, nbytes, raw.data())
+						                : dbgk_comm_kfreq_export_counts(comm, first, n, raw.data());
+					else
+						erc = bits == 1 ? dbgk_kfreq_export_bits(h, (uint32_t)cutoff, first / 8, nbytes, raw.data())
+						                : dbgk_kfreq_export_counts(h, first, n, raw.data());
 				}
 				if (erc) { failed = erc; return; }
 				uLongf clen = compressBound(nbytes);
@@ -181,6 +208,7 @@ int main(int argc, char **argv)
 	}
 	fclose(fz);
 	cerr << "wrote " << cz << " (" << n_blocks << " blocks, " << bits << "-bit format)" << endl;
-	dbgk_destroy(h);
+	if (comm) dbgk_comm_destroy(comm);
+	else dbgk_destroy(h);
 	return 0;
 }

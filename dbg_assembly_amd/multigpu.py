@@ -331,3 +331,47 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global,
             "handed_over_nodes": int(out_sizes.sum()), "overflow_observations": int(ovf_sizes.sum())}
+
+
+# ---- the k-mer frequency table on several GPUs -----------------------------------------------
+# Every rank counts its share of the reads into a whole 4^k-counter table (ENGINE_KFREQ, finalized).  The
+# combination is a reduce-scatter whose operator is the per-byte saturating add -- RCCL's sum would wrap -- so it
+# is written as chunked all-to-alls plus the library's merge kernel: rank d ends up owning the counters of the
+# k-mer values [bounds[d], bounds[d+1]).
+
+def kfreq_slice_bounds(n_counts, world):
+    return [n_counts if d == world else (n_counts * d // world) & ~1023 for d in range(world + 1)]
+
+
+def kfreq_reduce(g, device, group=None, wrap=None, chunk_bytes=256 << 20):
+    """g: this rank's finalized KFREQ capi.Graph.  Returns (lo, hi): the range of k-mer values whose counters in
+    g's table are now those of the whole job."""
+    wrap_device_memory = wrap or globals()["wrap_device_memory"]
+    on_gpu = torch.device(device).type == "cuda"
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ptr, n_counts = g.kfreq_device_counts()
+    table = wrap_device_memory(ptr, n_counts, device)
+    bounds = kfreq_slice_bounds(n_counts, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    if world == 1:
+        return lo, hi
+    longest = max(bounds[d + 1] - bounds[d] for d in range(world))
+    chunk = min(int(chunk_bytes), longest) & ~1023 or 1024
+    stage = torch.empty(world * chunk, dtype=torch.uint8, device=device)
+    for off in range(0, longest, chunk):
+        send, recv = [], []
+        for d in range(world):  # piece [off, off + chunk) of every owner's range
+            a, b = min(bounds[d] + off, bounds[d + 1]), min(bounds[d] + off + chunk, bounds[d + 1])
+            send.append(table[a:b])
+        mine = max(0, min(lo + off + chunk, hi) - min(lo + off, hi))
+        for s in range(world):
+            recv.append(stage[s * chunk: s * chunk + mine])
+        _exchange_uneven([(send[p], recv[p], p) for p in range(world) if p != rank], rank, group)  # ranges differ in length
+        if on_gpu:
+            torch.cuda.synchronize()
+        for s in range(world):
+            if s != rank and mine:
+                g.kfreq_merge_counts(recv[s].data_ptr(), lo + off, mine)
+        g.sync()
+    return lo, hi

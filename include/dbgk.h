@@ -243,6 +243,12 @@ int dbgk_wide_merge_nodes(dbgk_handle *h, const dbgk_node32 *d_nodes, uint64_t n
 int dbgk_kfreq_export_counts(dbgk_handle *h, uint64_t first_kmer, uint64_t n, uint8_t *host_out);
 /* n_bytes bytes of the bit table starting at byte first_byte: bit set when count > cutoff          */
 int dbgk_kfreq_export_bits(dbgk_handle *h, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out);
+/* Partial tables of several GPUs: counts[first_kmer, first_kmer + n) of a finalized handle
+ * += n counters held in device memory of the handle's GPU, per-byte saturating -- exact, because
+ * min(255, min(255,a) + min(255,b)) = min(255, a+b).  first_kmer, n and the address: multiples of 16.
+ * dbgk_kfreq_device_counts: the handle's 4^k counters in device memory (what a peer sends).          */
+int dbgk_kfreq_merge_counts(dbgk_handle *h, const uint8_t *d_counts, uint64_t first_kmer, uint64_t n);
+int dbgk_kfreq_device_counts(dbgk_handle *h, uint8_t **d_counts, uint64_t *n);
 
 /* ---- SEEDIDX engine: the contig k-mer index of the link_scaffold module ----------
  * chop_contig_to_kmerset (link_scaffold/map_func.cpp:119-173): push the contig sequences with
@@ -369,6 +375,12 @@ int dbgk_comm_link_stats(dbgk_comm *c, int32_t kmer_freq_cutoff, dbgk_link_stats
 /* the host KmerSet of the whole job (same contract as dbgk_export_host_table): the shards side by side when
  * host_size is the global table size, otherwise every node re-seated on the host                          */
 int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
+/* cfg->engine == DBGK_ENGINE_KFREQ: a communicator of n whole frequency tables.  Every member counts the reads
+ * dealt to it; dbgk_comm_finalize makes member d the owner of an n-th of the k-mer values and adds the other
+ * members' slices of that range to its own (peer copies in chunks, overlapped with the saturating add).  The
+ * two exports read every range from its owner; stats.count = distinct canonical k-mers of the whole job.     */
+int dbgk_comm_kfreq_export_counts(dbgk_comm *c, uint64_t first_kmer, uint64_t n, uint8_t *host_out);
+int dbgk_comm_kfreq_export_bits(dbgk_comm *c, uint32_t cutoff, uint64_t first_byte, uint64_t n_bytes, uint8_t *host_out);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
 

@@ -130,6 +130,85 @@ def test_kmerfreq_tool_files_load_like_the_reference(oracle, tmp_path, k, fmt):
             assert np.array_equal(got_ref, got)
 
 
+# ---- several GPUs: partial tables combined by the per-byte saturating add --------------------
+
+@pytest.mark.gpu
+def test_kfreq_merge_counts_of_two_partial_tables(oracle):
+    """dbgk_kfreq_merge_counts: min(255, a + b) per counter, the rule kfreq_reduce (multigpu.py) and dbgk_comm_* use"""
+    from dbg_assembly_amd import capi
+    k = 11
+    reads = _reads(random.Random(77), 3000)
+    want = oracle.kfreq_expected_counts([oracle.pack_reads(reads)], k)
+    halves = [oracle.pack_reads(reads[0::2]), oracle.pack_reads(reads[1::2])]
+    parts = [oracle.kfreq_expected_counts([h], k) for h in halves]
+    assert ((parts[0].astype(np.int32) + parts[1]) > 255).any() and parts[0].max() == 255  # saturation in the sum AND in one part
+    with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000) as a, \
+            capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=200000) as b:
+        for g, (bases, offsets) in zip((a, b), halves):
+            g.push_reads(bases, offsets)
+            g.finalize()
+        ptr, n = b.kfreq_device_counts()
+        assert n == 4 ** k
+        lo = 4 ** k // 3 & ~15
+        a.kfreq_merge_counts(ptr + lo, lo, n - lo)  # in two pieces: [lo, n) then [0, lo)
+        a.kfreq_merge_counts(ptr, 0, lo)
+        assert np.array_equal(a.kfreq_counts(), want)
+        assert a.refresh_stats().count == int((want > 0).sum())
+        with pytest.raises(capi.DbgkError):
+            a.kfreq_merge_counts(ptr + 8, 8, 16)  # alignment is part of the contract
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_shards,expected,stage_mb", [(9, 2, 0, 0), (12, 3, 150000, 1), (13, 4, 20000, 1)])
+def test_kfreq_communicator_equals_oracle(oracle, k, n_shards, expected, stage_mb, monkeypatch):
+    """dbgk_comm_* with DBGK_ENGINE_KFREQ: n whole tables on (here) one GPU, reduced by range at finalize; staging
+    buffers of 1 MiB make the copy / add pipeline go through many chunks (4^13 = 64 MiB of counters)"""
+    from dbg_assembly_amd import capi
+    if stage_mb:
+        monkeypatch.setenv("DBGK_COMM_KFREQ_STAGE_MB", str(stage_mb))
+    reads = _reads(random.Random(k * 31 + n_shards), 4000)
+    want = oracle.kfreq_expected_counts([oracle.pack_reads(reads)], k)
+    with capi.Comm(k, 0, [0] * n_shards, max_read_len=1000000, expected_kmers=expected, engine=capi.ENGINE_KFREQ) as c:
+        step = 450
+        for i in range(0, len(reads), step):
+            c.push_reads(*oracle.pack_reads(reads[i:i + step]))
+        st = c.finalize()
+        assert st.count == int((want > 0).sum())
+        assert st.total_reads == len(reads) and st.stored_kmers == sum(max(0, len(r) - k + 1) for r in reads)
+        assert np.array_equal(c.kfreq_counts(), want)
+        first, n = 4 ** k // 5 + 3, 4 ** k // 2 + 11   # a range across owners, unaligned
+        assert np.array_equal(c.kfreq_counts(first, n), want[first:first + n])
+        for cutoff in (0, 1, 254):
+            assert np.array_equal(np.unpackbits(c.kfreq_bits(cutoff)), (want > cutoff).astype(np.uint8))
+        fb, nb = 4 ** k // 8 // 3 + 1, 4 ** k // 8 // 2
+        assert np.array_equal(c.kfreq_bits(1, fb, nb), np.packbits(want > 1)[fb:fb + nb])
+        with pytest.raises(capi.DbgkError):
+            c.digest()  # graph-only entry points are refused
+
+
+@pytest.mark.gpu
+def test_kmerfreq_tool_on_several_gpu_shards(oracle, tmp_path):
+    """`DBGK_GPU_LIST=0,0,0 kmerfreq`: the same files as one GPU writes"""
+    k = 12
+    reads = _reads(random.Random(5), 2500)
+    f1 = str(tmp_path / "a.fa")
+    oracle.write_reads_file(f1, reads, fmt=2)
+    lib = str(tmp_path / "reads.lib")
+    open(lib, "w").write(f1 + "\n")
+    outs = {}
+    for name, env in (("one", {}), ("three", {"DBGK_GPU_LIST": "0,0,0", "DBGK_BATCH_BYTES": "30000"})):
+        prefix = str(tmp_path / name)
+        r = subprocess.run([TOOL, "-k", str(k), "-f", "2", "-b", "8", "-t", "4", "-o", prefix, lib], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert ("counting on 3 GPUs" in r.stderr) == (name == "three")
+        outs[name] = (open(prefix + ".kmer.freq.cz", "rb").read(), open(prefix + ".kmer.freq.cz.len").read(), r.stderr.strip().splitlines()[-2])
+    assert outs["one"] == outs["three"]
+    want = oracle.kfreq_expected_counts([oracle.pack_reads(reads)], k)
+    got, n_total, n_effect = oracle.kfreq_load_8bit(str(tmp_path / "three.kmer.freq.cz"), k, 0)
+    assert n_effect == int((want > 0).sum()) and n_total == int(want.astype(np.int64).sum())
+
+
 # ---- BASELINE cfg4 at its stated size: k = 17, 4^17 = 17 179 869 184 counters (16 GiB) --------------------
 # Counting semantics are THIS BUILD'S (the reference's producer, `kmerfreq`, is not in its repository:
 # "counting parity unpinned", SURVEY section 8(c)): every window of every read, N as A, canonical = min(forward,

@@ -327,3 +327,71 @@ def test_sharded_finalize_gloo(oracle, world, chunks):
     for rank, out, _ in results:
         assert (out["count"], out["total_reads"], out["total_kmers"]) == (whole.count, whole.total_reads, whole.total_kmers)
         assert (out["ranged_calls"] > 1) == (chunks > 1)  # the pieces were built as they arrived
+
+
+# ---- kfreq_reduce: partial k-mer frequency tables -> one table, ranges owned by rank ----------
+
+class FakeKfreqGraph:
+    """a finalized KFREQ handle on the host: the oracle's counts of this rank's reads"""
+
+    def __init__(self, O, reads, k):
+        self.table = np.ascontiguousarray(O.kfreq_expected_counts([O.pack_reads(reads)], k))
+        self.merges = 0
+
+    def kfreq_device_counts(self):
+        return self.table.ctypes.data, self.table.size
+
+    def kfreq_merge_counts(self, ptr, first, n):
+        other = np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=np.uint8)
+        self.table[first:first + n] = np.minimum(self.table[first:first + n].astype(np.int32) + other, 255)
+        self.merges += 1
+
+    def sync(self):
+        pass
+
+
+def _kfreq_worker(rank, world, port, reads, k, chunk, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as O
+    from dbg_assembly_amd.multigpu import kfreq_reduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FakeKfreqGraph(O, reads[rank::world], k)
+    lo, hi = kfreq_reduce(g, "cpu", wrap=_wrap_host, chunk_bytes=chunk)
+    q.put((rank, lo, hi, g.table[lo:hi].tobytes(), g.merges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunk", [(2, 256 << 20), (3, 4096), (2, 1024)])
+def test_kfreq_reduce_gloo(oracle, world, chunk):
+    rng = random.Random(world * 7 + chunk)
+    g = "".join(rng.choice("ACGT") for _ in range(3000))
+    reads = []
+    for _ in range(900):
+        s = rng.randint(0, 3000 - 80)
+        reads.append(g[s:s + 80].encode())
+    reads += [b"A" * 80] * 70 + [b"ACGTTGCA" * 10] * 40 + [b"AC"]  # counters that saturate only in the sum
+    rng.shuffle(reads)
+    k = 8
+    want = oracle.kfreq_expected_counts([oracle.pack_reads(reads)], k)
+    assert want.max() == 255
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kfreq_worker, args=(r, world, port, reads, k, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == 0 and results[-1][2] == 4 ** k
+    for a, b in zip(results, results[1:]):
+        assert a[2] == b[1]  # the ranges tile the table
+    got = np.concatenate([np.frombuffer(r[3], dtype=np.uint8) for r in results])
+    assert np.array_equal(got, want)
+    if chunk < 4 ** k // world:
+        assert all(r[4] > world - 1 for r in results)  # several rounds of chunks
