@@ -15,6 +15,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 
 #include "dbgk.h"
@@ -70,6 +71,8 @@ struct Session {
 	uint64_t bound_since = 0;              // k-mer windows handed over (pushed or pending here) since then: new keys <= this
 	uint64_t reads_in_block = 0;           // reads since the last full block of the current file
 	bool stop_file = false;                // the reference would have left this file's block loop (-e cap)
+	// host wall clock per phase (DBGK_TIMINGS): device calls made while parsing are timed on their own
+	double t_create = 0, t_parse = 0, t_push = 0, t_count = 0, t_finalize = 0, t_export = 0;
 	// DBGK_LAYOUT=ref: reproduce the reference's -t 1 slot layout (first-seen order replay)
 	bool ref_layout = false;
 	uint64_t pos = 0;                      // bases handed to the device so far (+ pending batch)
@@ -77,6 +80,13 @@ struct Session {
 };
 
 Session *g_session = nullptr;
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Stopwatch { // adds its lifetime to a counter
+	double &acc, t0;
+	explicit Stopwatch(double &a) : acc(a), t0(now_s()) {}
+	~Stopwatch() { acc += now_s() - t0; }
+};
 
 void fail(Session &S, int rc, const char *what)
 {
@@ -104,6 +114,7 @@ inline float clamped_load_factor()
 void exact_count(Session &S)
 {
 	if (S.status != DBGK_OK) return;
+	Stopwatch sw(S.t_count);
 	int rc = S.comm ? dbgk_comm_flush(S.comm) : (S.partition ? dbgk_flush(S.h) : DBGK_OK);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_flush");
 	dbgk_stats st;
@@ -145,6 +156,7 @@ void flush_batch(Session &S)
 	}
 	reserve_device_slots(S);
 	if (S.status == DBGK_OK) {
+		Stopwatch sw(S.t_push);
 		int rc = S.comm ? dbgk_comm_push_reads(S.comm, S.bases.data(), S.offsets.data(), n_reads)
 		                : dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
 		if (rc != DBGK_OK) fail(S, rc, "dbgk_push_reads");
@@ -374,6 +386,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
 	}
 
+	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
 	cerr << "The initialization memory used:  " << initHashSize * 16 << " G" << endl;
 	time_end = clock();
@@ -382,7 +395,11 @@ void build_debruijn_graph(vector<string> &reads_files)
 	cerr << "\nparse input reads files: " << endl;
 	for (size_t i = 0; i < reads_files.size(); i++) {
 		cerr << "\nStart to parse reads file: " << reads_files[i] << endl;
-		if (S->status == DBGK_OK) parse_one_reads_file(reads_files[i]);
+		if (S->status == DBGK_OK) {
+			const double t0 = now_s(), dev0 = S->t_push + S->t_count;
+			parse_one_reads_file(reads_files[i]);
+			S->t_parse += (now_s() - t0) - (S->t_push + S->t_count - dev0);
+		}
 		dbgk_stats st;
 		if (S->status == DBGK_OK && (S->comm ? dbgk_comm_refresh_stats(S->comm, &st) : dbgk_refresh_stats(S->h, &st)) == DBGK_OK)
 			Kmer_total_num = st.total_kmers;
@@ -396,9 +413,11 @@ void build_debruijn_graph(vector<string> &reads_files)
 	dbgk_stats st;
 	memset(&st, 0, sizeof st);
 	if (S->status == DBGK_OK) {
+		Stopwatch sw(S->t_finalize);
 		rc = S->comm ? dbgk_comm_finalize(S->comm, &st) : dbgk_finalize(S->h, &st);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
 	}
+	const double t_export0 = now_s();
 	KmerSet *result = NULL;
 	if (S->status == DBGK_OK && S->ref_layout) {
 		Kmer_total_num = st.total_kmers;
@@ -452,6 +471,10 @@ void build_debruijn_graph(vector<string> &reads_files)
 	if (kset) free_hash(kset);
 	kset = result;
 	DbgkLastStatus = S->status;
+	S->t_export = now_s() - t_export0;
+	if (getenv("DBGK_TIMINGS"))
+		cerr << "Host phases (s): create " << S->t_create << " read+parse " << S->t_parse << " push " << S->t_push << " count/flush " << S->t_count
+		     << " finalize " << S->t_finalize << " host table " << S->t_export << endl;
 	if (getenv("DBGK_TIMINGS") && S->h) { // device time per phase, summed over the run (HIP events on the library's streams)
 		dbgk_timings tm;
 		if (dbgk_get_timings(S->h, &tm) == DBGK_OK)

@@ -56,6 +56,7 @@ with tempfile.TemporaryDirectory() as tmp:
         dt = time.perf_counter() - t0
         line = [l for l in r.stderr.splitlines() if l.startswith("GPU phases")]
         count = [l for l in r.stderr.splitlines() if l.startswith("count:")]
-        out[name] = {"rc": r.returncode, "wall_seconds": dt, "M_kmers_per_s_wall": n_reads * 120 / dt / 1e6, "gpu_phases": line[-1] if line else None,
+        host = [l for l in r.stderr.splitlines() if l.startswith("Host phases")]
+        out[name] = {"rc": r.returncode, "wall_seconds": dt, "M_kmers_per_s_wall": n_reads * 120 / dt / 1e6, "gpu_phases": line[-1] if line else None, "host_phases": host[-1] if host else None,
                      "count_line": count[-1] if count else None}
 print(json.dumps(out))
