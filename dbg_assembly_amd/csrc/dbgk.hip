@@ -195,6 +195,14 @@ static int collect_spans(dbgk_handle *h)
 
 static inline uint64_t bitmap_words(uint64_t n_bases) { return (n_bases >> 5) + 4; }
 
+// level-1 workgroups per CU: as many as fill the CU's wave slots, unless DBGK_L1_PER_CU says otherwise (experiments with
+// 512-thread builds that leave LDS for a workgroup of another kernel)
+static int l1_wgs_per_cu()
+{
+	static const int v = getenv("DBGK_L1_PER_CU") ? std::max(1, atoi(getenv("DBGK_L1_PER_CU"))) : 1024 / kL1Threads;
+	return v;
+}
+
 static int grid_for(const dbgk_handle *h, uint64_t items)
 {
 	uint64_t blocks = (items + kBlock - 1) / kBlock;
@@ -881,7 +889,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
 		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
-		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (1024 / kL1Threads));
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu());
 		const int wide = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
 		const bool ragged = umode == 2;
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
@@ -901,7 +909,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 #undef DBGK_LAUNCH_UNIFORM
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
-		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (1024 / kL1Threads)); // 140 KiB of LDS: one workgroup per CU
+		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu()); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
 		const int wide_d = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
 		if (wide_d == 2 && has_long)
