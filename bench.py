@@ -226,7 +226,8 @@ def main():
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
-                   expected_kmers=n_reads * kpr if args.engine == capi.ENGINE_PARTITION else 0,  # exact for fixed-length reads
+                   expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not os.environ.get("DBGK_WIDE_DIRECT")
+                   else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     engine = HipEngine(g, device)
@@ -321,10 +322,16 @@ def main():
         l1_ms = tm.insert_ms / args.steps
         l2_ms, build_ms, wall_ms = tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
         slots_local = size // world if sharded else size
+        wide_records = args.engine == capi.ENGINE_WIDE and l2_ms > 0   # the WIDE handle went through 16-byte records
         if args.engine == capi.ENGINE_PARTITION:
             own_bytes = {l1_name: kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * 16.0,
                          "k_build_regions": kmers_step * 8.0 + slots_local * 16.0}
             kernel_ms = {l1_name: l1_ms, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
+        elif wide_records:
+            l1_name = "k_wide_scatter_l1"
+            own_bytes = {l1_name: kmers_step * (150.0 / kpr + 16.0), "k_wide_scatter_l2": kmers_step * 32.0,
+                         "k_wide_build_regions": kmers_step * 16.0 + slots_local * 32.0}
+            kernel_ms = {l1_name: l1_ms, "k_wide_scatter_l2": l2_ms, "k_wide_build_regions": build_ms}
         else:
             own_bytes = {l1_name: kmers_step * (B_ALG if args.kmer <= 32 else 150.0 / kpr + 64.0)}
             kernel_ms = {l1_name: l1_ms}

@@ -17,6 +17,7 @@
 #include "dbgk_kernels.h"
 #include "dbgk_partition.h"
 #include "dbgk_wide_kernels.h"
+#include "dbgk_wide_partition.h"
 
 // dbgk_sort.hip
 extern "C" int dbgk_internal_sort_pairs(uint64_t *d_keys, uint64_t *d_vals, uint64_t n, hipStream_t stream);
@@ -107,6 +108,14 @@ struct dbgk_handle {
 	bool wide = false;            // WIDE engine: 128-bit keys, 32-byte nodes (dbgk_wide_kernels.h)
 	WNode *wnodes = nullptr;      // [size]
 	WNode *wside = nullptr;       // [kWideSideSlots]
+	// WIDE through radix-partitioned records (dbgk_wide_partition.h): expected_kmers > 0 and a feasible geometry
+	bool wpart = false;
+	bool wbuilt = false;          // the records have been turned into the table: later batches use the atomic kernels
+	bool wzero_pending = false;   // the main table is stale (reset without memset): the build overwrites every slot
+	WPartGeom wgeom;
+	WPartStore wstore;
+	uint32_t *w_tile_prefix = nullptr;
+	unsigned int *w_cursor = nullptr;
 	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
@@ -252,6 +261,17 @@ static void free_partition_stores(dbgk_handle *h)
 	h->inbox_cnt = nullptr;
 }
 
+static void free_wide_partition(dbgk_handle *h)
+{
+	WPartStore &P = h->wstore;
+	for (void *p : {(void *)P.l1, (void *)P.cnt1, (void *)P.l2, (void *)P.cnt2, (void *)P.ovf, (void *)P.spill, (void *)P.ovf_n, (void *)h->w_tile_prefix,
+	                (void *)h->w_cursor})
+		if (p) (void)hipFree(p);
+	memset(&P, 0, sizeof P);
+	h->w_tile_prefix = nullptr;
+	h->w_cursor = nullptr;
+}
+
 static void free_handle(dbgk_handle *h)
 {
 	if (!h) return;
@@ -280,6 +300,7 @@ static void free_handle(dbgk_handle *h)
 		if (h->join_ev) (void)hipEventDestroy(h->join_ev);
 		if (h->stream2) (void)hipStreamDestroy(h->stream2);
 	}
+	if (h->wpart) free_wide_partition(h);
 	if (h->wnodes) (void)hipFree(h->wnodes);
 	if (h->wside) (void)hipFree(h->wside);
 	if (h->table) (void)hipFree(h->table);
@@ -319,11 +340,140 @@ static int clear_record_store(dbgk_handle *h)
 	return DBGK_OK;
 }
 
+// kernels with more than 64 KiB of dynamic LDS have to say so
+#define DBGK_LDS_ATTR(KERNEL, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+
+// ---- WIDE through radix-partitioned records (dbgk_wide_partition.h) ---------------------------------
+// geometry: level-1 bucket = slot >> r with n1 = ceil(size / 2^r) <= 1024, final bucket = slot >> 11 (one 2048-slot
+// region), n2 = 2^(r - 11) <= 2048; the second half of a record holds q = hash / size, r slot bits, 6 neighbour bits
+static bool plan_wide_partition(dbgk_handle *h)
+{
+	static const bool off = getenv("DBGK_WIDE_DIRECT") != nullptr; // always the atomic kernels
+	if (off || h->cfg.expected_kmers == 0 || h->size < (1ull << 26) || h->size > (1ull << 32)) return false;
+	const uint64_t qmax = ~0ull / h->size;
+	int qbits = 0;
+	while (qbits < 64 && (qmax >> qbits)) qbits++;
+	uint32_t r = 21;
+	if (const char *e = getenv("DBGK_WIDE_R")) r = (uint32_t)std::max(kWRegionBits + 1, std::min(22, atoi(e)));
+	while (((h->size + (1ull << r) - 1) >> r) > 1024ull) r++;
+	while (r > (uint32_t)kWRegionBits + 1u && qbits + (int)r + 6 > 64) r--;
+	const uint64_t n1 = (h->size + (1ull << r) - 1) >> r;
+	if (n1 > 1024ull || (1u << (r - kWRegionBits)) > 2048u || qbits + (int)r + 6 > 64) return false;
+	WPartGeom &G = h->wgeom;
+	memset(&G, 0, sizeof G);
+	G.size = h->size;
+	G.magic = h->magic;
+	G.r = r;
+	G.n1 = (uint32_t)n1;
+	G.n2 = 1u << (r - kWRegionBits);
+	G.n_regions = (uint32_t)((h->size + kWRegionSlots - 1) >> kWRegionBits);
+	const double per_slot = (double)h->cfg.expected_kmers / (double)h->size;
+	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05) + 65536;
+	G.cap2 = (uint64_t)(per_slot * (double)kWRegionSlots * 1.25) + 512;
+	G.chunk_buckets = (G.n1 + 7u) / 8u;
+	return true;
+}
+
+static int setup_wide_partition(dbgk_handle *h)
+{
+	const WPartGeom &G = h->wgeom;
+	WPartStore &P = h->wstore;
+	memset(&P, 0, sizeof P);
+	P.ovf_cap = h->cfg.expected_kmers / 16 + (1ull << 20);
+	P.spill_cap = (uint64_t)G.n_regions * 8 + (1ull << 16);
+	const size_t l1_bytes = (size_t)G.n1 * G.cap1 * 16, l2_bytes = (size_t)G.chunk_buckets * G.n2 * G.cap2 * 16;
+	const bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
+	                hipMalloc(&P.cnt1, (size_t)G.n1 * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.chunk_buckets * G.n2 * 4) == hipSuccess &&
+	                hipMalloc(&P.ovf, P.ovf_cap * sizeof(dbgk_node32)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(dbgk_node32)) == hipSuccess &&
+	                hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->w_tile_prefix, ((size_t)G.n1 + 1) * 4) == hipSuccess &&
+	                hipMalloc(&h->w_cursor, 4) == hipSuccess;
+	if (!ok) {
+		(void)hipGetLastError();
+		g_last_error = "hipMalloc of the wide record stores failed";
+		return DBGK_ERR_NOMEM;
+	}
+	HIPCHK(hipMemsetAsync(P.cnt1, 0, (size_t)G.n1 * 4, h->stream));
+	HIPCHK(hipMemsetAsync(P.ovf_n, 0, 16, h->stream));
+	DBGK_LDS_ATTR(k_wide_scatter_l1<false>, sizeof(WL1Lds));
+	DBGK_LDS_ATTR(k_wide_scatter_l1<true>, sizeof(WL1Lds));
+	DBGK_LDS_ATTR(k_wide_scatter_l2<1024>, sizeof(WL2Lds<1024>));
+	DBGK_LDS_ATTR(k_wide_scatter_l2<2048>, sizeof(WL2Lds<2048>));
+	DBGK_LDS_ATTR(k_wide_build_regions, sizeof(WBuildLds));
+	h->store_capacity = h->cfg.expected_kmers;
+	h->pending_kmers = 0;
+	return DBGK_OK;
+}
+
+// the main table of a WIDE handle that was reset without a memset (the region build rewrites every slot)
+static int wide_ensure_zero(dbgk_handle *h)
+{
+	if (!h->wzero_pending) return DBGK_OK;
+	HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+	h->wzero_pending = false;
+	return DBGK_OK;
+}
+
+// records -> table.  Afterwards the handle is an ordinary WIDE handle: whatever is pushed later goes through the
+// atomic kernels onto the table built here.
+static int wide_build_from_records(dbgk_handle *h)
+{
+	if (!h->wpart || h->wbuilt) return DBGK_OK;
+	const WPartGeom &G = h->wgeom;
+	const WPartStore &P = h->wstore;
+	TimedSpan sp;
+	int rc = DBGK_OK;
+	hipLaunchKernelGGL(k_wide_l2_plan, dim3(1), dim3(1024), 0, h->stream, G, P.cnt1, h->w_tile_prefix);
+	HIPCHK(hipGetLastError());
+	// chunk by chunk of level-1 buckets: level 2 into the (small) level-2 store, then the regions of those buckets
+	for (uint32_t j0 = 0; j0 < G.n1; j0 += G.chunk_buckets) {
+		const uint32_t j1 = std::min(j0 + G.chunk_buckets, G.n1);
+		rc = span_begin(h, PH_PARTITION, sp);
+		if (rc) return rc;
+		HIPCHK(hipMemsetAsync(P.cnt2, 0, (size_t)G.chunk_buckets * G.n2 * 4, h->stream));
+		if (G.n2 > 1024u)
+			hipLaunchKernelGGL(k_wide_scatter_l2<2048>, dim3(h->n_cu & ~7), dim3(kWL2Threads), sizeof(WL2Lds<2048>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, j0, j1);
+		else
+			hipLaunchKernelGGL(k_wide_scatter_l2<1024>, dim3((h->n_cu * 2) & ~7), dim3(kWL2Threads), sizeof(WL2Lds<1024>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, j0, j1);
+		HIPCHK(hipGetLastError());
+		rc = span_end(h, sp);
+		if (rc) return rc;
+		const uint32_t r0 = j0 * G.n2, r1 = std::min(j1 * G.n2, G.n_regions);
+		if (r1 <= r0) continue;
+		rc = span_begin(h, PH_BUILD, sp);
+		if (rc) return rc;
+		HIPCHK(hipMemsetAsync(h->w_cursor, 0, 4, h->stream));
+		hipLaunchKernelGGL(k_wide_build_regions, dim3(std::min<uint32_t>(r1 - r0, (uint32_t)h->n_cu * 3u)), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P,
+		                   h->wnodes, h->d_ctr, h->w_cursor, r0, r1 - r0);
+		HIPCHK(hipGetLastError());
+		rc = span_end(h, sp);
+		if (rc) return rc;
+	}
+	h->wzero_pending = false; // every slot has just been written
+	rc = span_begin(h, PH_FIXUP, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_wide_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.spill, &P.ovf_n[1], P.spill_cap, h->wref(), h->d_ctr);
+	hipLaunchKernelGGL(k_wide_insert_obs, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.ovf, &P.ovf_n[0], P.ovf_cap, h->wref(), h->d_ctr);
+	HIPCHK(hipGetLastError());
+	rc = span_end(h, sp);
+	if (rc) return rc;
+	h->wbuilt = true;
+	h->pending_kmers = 0;
+	return DBGK_OK;
+}
+
 static int reset_state(dbgk_handle *h)
 {
 	if (h->kfreq) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
 	if (h->wide) {
-		HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+		if (h->wpart) { // the region build overwrites every slot of the main table: zero it only if something writes it before
+			h->wzero_pending = true;
+			h->wbuilt = false;
+			h->pending_kmers = 0;
+			HIPCHK(hipMemsetAsync(h->wstore.cnt1, 0, (size_t)h->wgeom.n1 * 4, h->stream));
+			HIPCHK(hipMemsetAsync(h->wstore.ovf_n, 0, 16, h->stream));
+		} else {
+			HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+		}
 		HIPCHK(hipMemsetAsync(h->wside, 0, kWideSideSlots * sizeof(WNode), h->stream));
 	} else if (h->kfreq && !h->part) {
 	} else if (h->part) {
@@ -458,7 +608,6 @@ static int setup_partition(dbgk_handle *h)
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	h->store_capacity = expected;
-#define DBGK_LDS_ATTR(KERNEL, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
 #define DBGK_UNIFORM_ATTRS(W)                                                  \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true>), sizeof(UniformLds));  \
@@ -479,7 +628,6 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 2048>), sizeof(ScatterLdsL2T<2048>));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 4096>), sizeof(ScatterLdsL2T<4096>));
-#undef DBGK_LDS_ATTR
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
 	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
@@ -578,6 +726,11 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 			g_last_error = "hipMalloc of the wide k-mer table failed";
 			return fail(DBGK_ERR_NOMEM);
 		}
+		if (plan_wide_partition(h)) { // input size known: records first, the table in one pass at the end
+			h->wpart = true;
+			const int wrc = setup_wide_partition(h);
+			if (wrc != DBGK_OK) return fail(wrc);
+		}
 	} else if (hipMalloc(&h->table, h->tslots * sizeof(Node)) != hipSuccess) {
 		g_last_error = "hipMalloc of the k-mer table failed";
 		return fail(DBGK_ERR_NOMEM);
@@ -643,6 +796,7 @@ static int setup_partition(dbgk_handle *h);
 // into LDS first), record store emptied.
 static int flush_records(dbgk_handle *h)
 {
+	if (h->wpart && !h->finalized) return h->pending_kmers ? wide_build_from_records(h) : DBGK_OK;
 	if (!h->part || h->finalized) return DBGK_OK;
 	if (h->sharded) {
 		g_last_error = "dbgk_flush: a sharded handle is flushed by its communicator (dbgk_comm_flush)";
@@ -876,7 +1030,15 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (rc) return rc;
 	if (h->seed) {
 		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
+	} else if (h->wide && h->wpart && !h->wbuilt) {
+		const int grid = (int)std::min<uint64_t>((n_chunks + kWL1Threads - 1) / kWL1Threads, (uint64_t)h->n_cu);
+		if (has_long)
+			hipLaunchKernelGGL(k_wide_scatter_l1<true>, dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, h->wgeom, h->wstore, h->wref(), h->d_ctr);
+		else
+			hipLaunchKernelGGL(k_wide_scatter_l1<false>, dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, h->wgeom, h->wstore, h->wref(), h->d_ctr);
 	} else if (h->wide) {
+		rc = wide_ensure_zero(h);
+		if (rc) return rc;
 		if (has_long)
 			hipLaunchKernelGGL(k_wide_extract_insert<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->wref(), h->d_ctr);
 		else
@@ -996,8 +1158,8 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 	// preceded by a flush (records -> table, dbgk_flush).  Batches are cut to the room that is left only when
 	// the store is at least one staging batch large; a smaller store (expected_kmers a gross under-estimate)
 	// takes whole batches and sends the excess through its overflow lists as before.
-	const bool streaming = h->part && !h->sharded;
-	const bool cut_to_room = streaming && h->store_capacity >= h->cap_bases;
+	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
+	const bool cut_to_room = streaming && h->store_capacity >= h->cap_bases && !h->wpart; // (a wide store is built once: no point in filling it to the brim)
 	uint64_t r0 = 0;
 	while (r0 < n_reads) {
 		// largest [r0, r1) that fits the staging buffers (and the record store)
@@ -1011,7 +1173,8 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			batch_windows += w;
 			r1++;
 		}
-		if (streaming && h->pending_kmers > 0 && (r1 == r0 || (!cut_to_room && h->pending_kmers + batch_windows > h->store_capacity))) {
+		if (streaming && !(h->wpart && h->wbuilt) && h->pending_kmers > 0 &&
+		    (r1 == r0 || (!cut_to_room && h->pending_kmers + batch_windows > h->store_capacity))) {
 			rc = flush_records(h);
 			if (rc) return rc;
 			if (r1 == r0) continue; // cut again with the whole store free
@@ -1077,7 +1240,7 @@ extern "C" int dbgk_push_reads_device(dbgk_handle *h, const char *d_bases, const
 	}
 	// the record store takes what it was sized for; the number of windows of a device batch is only known as
 	// an upper bound here (one per base)
-	if (h->part && !h->sharded && h->pending_kmers > 0 && h->pending_kmers + n_bases > h->store_capacity) {
+	if (((h->part && !h->sharded) || (h->wpart && !h->wbuilt)) && h->pending_kmers > 0 && h->pending_kmers + n_bases > h->store_capacity) {
 		rc = flush_records(h);
 		if (rc) return rc;
 	}
@@ -1098,8 +1261,9 @@ extern "C" int dbgk_flush(dbgk_handle *h)
 extern "C" int dbgk_store_room(dbgk_handle *h, uint64_t *pending_kmers, uint64_t *capacity_kmers)
 {
 	if (!h) return DBGK_ERR_ARG;
-	if (pending_kmers) *pending_kmers = h->part ? h->pending_kmers : 0;
-	if (capacity_kmers) *capacity_kmers = h->part ? h->store_capacity : 0;
+	const bool records = h->part || (h->wpart && !h->wbuilt);
+	if (pending_kmers) *pending_kmers = records ? h->pending_kmers : 0;
+	if (capacity_kmers) *capacity_kmers = records ? h->store_capacity : 0;
 	return DBGK_OK;
 }
 
@@ -1309,6 +1473,14 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 	if (!h) return DBGK_ERR_ARG;
 	int rc = use_device(h);
 	if (rc) return rc;
+	if (h->wpart && !h->finalized) {
+		if (!h->wbuilt && h->pending_kmers > 0) {
+			rc = wide_build_from_records(h);
+			if (rc) return rc;
+		}
+		rc = wide_ensure_zero(h); // nothing was pushed at all
+		if (rc) return rc;
+	}
 	if (h->part && !h->part_built && !h->finalized) {
 		if (h->sharded && !h->exchanged) {
 			g_last_error = "sharded handle: exchange the level-1 buckets (dbgk_shard_buffers) and call dbgk_shard_mark_exchanged first";
@@ -1837,6 +2009,15 @@ extern "C" int dbgk_wide_merge_nodes(dbgk_handle *h, const dbgk_node32 *d_nodes,
 {
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
 	if (!h->wide) return DBGK_ERR_STATE;
+	if (h->wpart && !h->finalized) { // pending records become the table first: the region build rewrites every slot
+		int frc = use_device(h);
+		if (frc) return frc;
+		frc = h->pending_kmers && !h->wbuilt ? wide_build_from_records(h) : DBGK_OK;
+		if (frc) return frc;
+		frc = wide_ensure_zero(h);
+		if (frc) return frc;
+		h->wbuilt = true; // whatever comes later joins the table through the atomic kernels
+	}
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (n == 0) return DBGK_OK;

@@ -217,3 +217,150 @@ def test_wide_nodes_shipped_to_their_owners_PARITY_UNPINNED_above_k32(capi, orac
     finally:
         for g in sources + owners:
             g.close()
+
+
+# ---- WIDE through radix-partitioned records (dbgk_wide_partition.h): expected_kmers > 0, table of >= 2^26 slots --------
+
+M64 = (1 << 64) - 1
+
+
+def _hash_code(k):
+    """kmerSet.h:105-116 on Python integers"""
+    k = (k + (~(k << 32) & M64)) & M64
+    k ^= k >> 22
+    k = (k + (~(k << 13) & M64)) & M64
+    k ^= k >> 8
+    k = (k + (k << 3)) & M64
+    k ^= k >> 15
+    k = (k + (~(k << 27) & M64)) & M64
+    k ^= k >> 31
+    return k
+
+
+def _hash_code_inverse(h):
+    inv = lambda a: pow(a & M64, -1, 1 << 64)
+    h ^= h >> 31; h ^= h >> 62
+    h = ((h + 1) * inv(1 - (1 << 27))) & M64
+    h ^= h >> 15; h ^= h >> 30; h ^= h >> 60
+    h = (h * inv(9)) & M64
+    h ^= h >> 8; h ^= h >> 16; h ^= h >> 32
+    h = ((h + 1) * inv(1 - (1 << 13))) & M64
+    h ^= h >> 22; h ^= h >> 44
+    h = ((h + 1) * inv(1 - (1 << 32))) & M64
+    return h
+
+
+def _kmer_string(value, k):
+    return "".join("ACGT"[(value >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def _is_canonical(s):
+    return s <= "".join(COMP[c] for c in reversed(s))
+
+
+def test_python_hash_code_inverse():
+    for x in (0, 1, 0x0123456789ABCDEF, M64, 488296166657017542):
+        assert _hash_code_inverse(_hash_code(x)) == x
+
+
+def _crafted_reads(size, rng):
+    """reads of exactly k bases (one window each, no neighbours) whose keys stress the region build:
+    k = 63: pairs of DIFFERENT keys with the SAME hash128 -- (hi1, lo1) and (hi2, lo1 ^ hash_code(hi1) ^ hash_code(hi2)) --
+            so that the second half of their records is identical and only the high word tells them apart;
+    k = 32: many keys whose home slots are the last two of one 2048-slot region (they probe past the region's end:
+            the spill list) and of the table's last, partial region (they wrap around to slot 0)"""
+    pairs = []
+    while len(pairs) < 40:
+        hi1, hi2, lo1 = rng.getrandbits(62) | 1, rng.getrandbits(62) | 1, rng.getrandbits(64) | 1
+        lo2 = lo1 ^ _hash_code(hi1) ^ _hash_code(hi2)
+        a, b = _kmer_string((hi1 << 64) | lo1, 63), _kmer_string((hi2 << 64) | lo2, 63)
+        if hi1 != hi2 and lo2 != 0 and _is_canonical(a) and _is_canonical(b):
+            pairs += [a, b]
+    tails = []
+    for home in [5 * 2048 + 2046, 5 * 2048 + 2047, size - 2, size - 1]:
+        found = 0
+        q = rng.getrandbits(20)
+        while found < 70:
+            q += 1
+            s = _kmer_string(_hash_code_inverse(q * size + home), 32)
+            if _is_canonical(s) and "A" * 16 != s[16:]:
+                tails.append(s)
+                found += 1
+    return [p.encode() for p in pairs], [t.encode() for t in tails]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,r,store", [(63, 250, "ample"), (33, 250, "ample"), (47, 100, "small"), (32, 250, "ample"), (17, 100, "heavy"), (63, 63, "heavy")])
+def test_wide_records_path_equals_cpu_restatement_PARITY_UNPINNED_above_k32(capi, oracle, k, r, store):
+    """WIDE handle with a known input size: 16-byte records, two scatter levels, 2048-slot regions built in LDS.
+    ample: everything becomes records; small: the store takes the first batches, the table is built when it is full and
+    the rest joins through the atomic kernels; heavy: 3000 copies of one read -- far more records than a final bucket
+    holds (its capacity follows the MEAN fill), so most of them overflow into the observation list"""
+    rng = random.Random(k * 77 + r)
+    reads = _reads(rng, 2500)
+    if store == "heavy":
+        reads += [b"GATTACAGATTACACCGGTTAACCGGTTTTGACGTCAGCATGCATGCATCGATCGATCGGCTAGCTAGGCT"] * 3000
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    want, total = oracle.wide_build(bases, offsets, k, r)
+    windows = sum(max(0, min(len(x), r) - k + 1) for x in reads)
+    size = capi.find_next_prime_ref((1 << 26) + 12345)
+    expected = {"ample": windows + 1000, "small": windows // 3, "heavy": windows + 1000}[store]
+    with capi.Graph(k=k, table_slots=size, max_read_len=r, engine=capi.ENGINE_WIDE, max_batch_bases=1 << 16, expected_kmers=expected) as g:
+        assert g.store_room() == (0, expected)   # the record path is in use
+        g.push_reads(bases, offsets)
+        pending, cap = g.store_room()
+        assert (cap == 0) == (store == "small")  # small: already built, the handle has gone over to the atomic kernels
+        st = g.finalize()
+        assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (len(reads), total, len(want))
+        assert np.array_equal(g.wide_export_sorted(), want)
+        assert g.digest() == oracle.wide_digest(want)
+        if k == 63 and store == "ample":
+            array, flags = g.wide_export_host_table()
+            assert oracle.wide_check_host_table(array, flags, size, st.count) == 0
+        g.reset()   # reusable: records again
+        assert g.store_room() == (0, expected)
+        half = len(reads) // 2
+        g.push_reads(bases[:int(offsets[half])], offsets[:half + 1])
+        g.push_reads(bases[int(offsets[half]):], offsets[half:] - offsets[half])
+        assert g.finalize().count == len(want)
+        assert g.digest() == oracle.wide_digest(want)
+
+
+@pytest.mark.gpu
+def test_wide_records_path_crafted_keys_PARITY_UNPINNED(capi, oracle):
+    size = capi.find_next_prime_ref((1 << 26) + 999)
+    rng = random.Random(4242)
+    pairs, tails = _crafted_reads(size, rng)
+    for k, reads in ((63, pairs * 3 + _reads(rng, 300)), (32, tails * 2 + _reads(rng, 300))):
+        bases, offsets = oracle.pack_reads(reads)
+        want, total = oracle.wide_build(bases, offsets, k, 250)
+        with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=200000) as g:
+            assert g.store_room()[1] == 200000
+            g.push_reads(bases, offsets)
+            st = g.finalize()
+            assert int(st.count) == len(want)
+            assert np.array_equal(g.wide_export_sorted(), want)
+            array, flags = g.wide_export_host_table()
+            assert oracle.wide_check_host_table(array, flags, size, st.count) == 0
+            if k == 32:   # the crafted keys really crowd the end of their regions: some sit outside them now
+                occ = np.unpackbits(flags)[:size].astype(bool)
+                assert occ[6 * 2048:6 * 2048 + 8].any() and occ[:8].any()
+
+
+@pytest.mark.gpu
+def test_wide_records_path_cfg5_shaped_sample_PARITY_UNPINNED(capi, oracle):
+    n_reads, G = 60000, 300000
+    P, PO = capi.synth_params(G, 150, sub_rate=0.001, cfg=5), oracle.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    bases, offsets = oracle.synth_reads(PO, 0, n_reads)
+    want, total = oracle.wide_build(bases, offsets, 63, 250)
+    size = capi.find_next_prime_ref(1 << 27)
+    with capi.Graph(k=63, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 150) as g:
+        d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+        g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        assert g.store_room()[0] > 0
+        st = g.finalize()
+        assert (int(st.total_kmers), int(st.stored_kmers), int(st.count)) == (total, 88 * n_reads, len(want))
+        assert np.array_equal(g.wide_export_sorted(), want)
+        d_bases.free()
+        d_off.free()
