@@ -363,6 +363,7 @@ static bool plan_wide_partition(dbgk_handle *h)
 	memset(&G, 0, sizeof G);
 	G.size = h->size;
 	G.magic = h->magic;
+	if (h->size < (1ull << 32)) G.div = make_div32_magic((uint32_t)h->size);
 	G.r = r;
 	G.n1 = (uint32_t)n1;
 	G.n2 = 1u << (r - kWRegionBits);
@@ -394,8 +395,12 @@ static int setup_wide_partition(dbgk_handle *h)
 	}
 	HIPCHK(hipMemsetAsync(P.cnt1, 0, (size_t)G.n1 * 4, h->stream));
 	HIPCHK(hipMemsetAsync(P.ovf_n, 0, 16, h->stream));
-	DBGK_LDS_ATTR(k_wide_scatter_l1<false>, sizeof(WL1Lds));
-	DBGK_LDS_ATTR(k_wide_scatter_l1<true>, sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 0>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 0>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 1>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 1>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 2>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 2>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<1024>, sizeof(WL2Lds<1024>));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<2048>, sizeof(WL2Lds<2048>));
 	DBGK_LDS_ATTR(k_wide_build_regions, sizeof(WBuildLds));
@@ -1032,10 +1037,16 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
 	} else if (h->wide && h->wpart && !h->wbuilt) {
 		const int grid = (int)std::min<uint64_t>((n_chunks + kWL1Threads - 1) / kWL1Threads, (uint64_t)h->n_cu);
-		if (has_long)
-			hipLaunchKernelGGL(k_wide_scatter_l1<true>, dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, h->wgeom, h->wstore, h->wref(), h->d_ctr);
-		else
-			hipLaunchKernelGGL(k_wide_scatter_l1<false>, dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, h->wgeom, h->wstore, h->wref(), h->d_ctr);
+		const int wd = h->size >= (1ull << 32) ? 2 : (h->size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
+#define DBGK_LAUNCH_WIDE_L1(DEAD, WD)                                                                                                          \
+	hipLaunchKernelGGL((k_wide_scatter_l1<DEAD, WD>), dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, h->wgeom, h->wstore, h->wref(), \
+	                   h->d_ctr)
+		if (has_long) {
+			if (wd == 2) DBGK_LAUNCH_WIDE_L1(true, 2); else if (wd == 1) DBGK_LAUNCH_WIDE_L1(true, 1); else DBGK_LAUNCH_WIDE_L1(true, 0);
+		} else {
+			if (wd == 2) DBGK_LAUNCH_WIDE_L1(false, 2); else if (wd == 1) DBGK_LAUNCH_WIDE_L1(false, 1); else DBGK_LAUNCH_WIDE_L1(false, 0);
+		}
+#undef DBGK_LAUNCH_WIDE_L1
 	} else if (h->wide) {
 		rc = wide_ensure_zero(h);
 		if (rc) return rc;

@@ -37,6 +37,7 @@ constexpr int kWBuildThreads = 512;              // three workgroups per CU (51 
 struct WPartGeom {
 	uint64_t size;
 	ModMagic magic;
+	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h)
 	uint32_t r;          // level-1 bucket = slot >> r
 	uint32_t n1;         // ceil(size / 2^r) <= 1024
 	uint32_t n2;         // 2^(r - 11)       <= 2048
@@ -96,14 +97,111 @@ struct WScatterLds {
 	Desc desc[MAXB];
 	uint32_t wave_tot[THREADS / 64];
 };
-using WL1Lds = WScatterLds<kWL1Threads, 8, 1024, false>;
+struct WL1Lds : WScatterLds<kWL1Threads, 8, 1024, true> {
+	uint16_t bucket_of[kWL1Threads * 8]; // level-1 bucket of every staged record: the copy-out walks the stage linearly
+};
 template <int MAXB> using WL2Lds = WScatterLds<kWL2Threads, 8, MAXB, true>;
 
 // ---- level 1 --------------------------------------------------------------------------------------
-// One lane owns 16 consecutive base positions (as in k_wide_extract_insert), handled as two tiles of 8: the
-// 160-bit window state stays in registers between them.  Per position nothing branches except the rare keys
-// with lo == 0; positions without a record rank themselves in a per-lane dummy bin.
+// One lane owns 16 consecutive base positions, handled as two tiles of 8.  As in the 64-bit engine's level 1
+// (dbgk_partition.h: decode_chunk16 / l1_positions) the forward and the reverse-complement k-mer ROLL by one base per
+// position (DBGgraph.cpp:71-73), the entering / left-neighbour bases of the 16 positions sit in two packed words, and
+// the three per-position predicates (window inside one read, has a left / right neighbour) are computed once per lane
+// as 16-bit masks with log-step sliding ORs over the 128-bit boundary bitmaps.  A lane loads only ITS 16 bases; the
+// four following packed words come from the next lanes by shuffle and from four halo chunks at the wave's end.
+typedef unsigned __int128 u128;
+
+// bit i of the result = OR of bits i .. i+w-1 of x (w wave-uniform, 0..63), for the low 16 result bits
+__device__ __forceinline__ uint32_t sliding_or128_lo16(u128 x, uint32_t w)
+{
+	u128 res = 0, cur = x;
+	uint32_t done = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < 6; j++) {
+		if (w & (1u << j)) {
+			res |= cur >> done;
+			done += 1u << j;
+		}
+		cur |= cur >> (1u << j);
+	}
+	return (uint32_t)res & 0xFFFFu;
+}
+
+struct WChunk16 {
+	Key128 fwd, rc;      // forward / reverse-complement k-mer of the window at position 0
+	uint32_t nb;         // bases k .. k+15: the base entering at position i+1 = right neighbour of position i
+	uint32_t lw;         // bases -1 .. 14: left neighbour of position i
+	uint32_t valid, has_l, has_r; // 16-bit masks, bit i <-> position p0 + i
+};
+
 template <bool HAS_DEAD>
+__device__ __forceinline__ WChunk16 wide_decode_chunk16(const ReadBatch &rb, uint64_t chunk, uint64_t n_chunks)
+{
+	WChunk16 c;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint32_t lane = fresh_tid() & 63u;
+	const bool live = chunk < n_chunks;
+	const uint64_t p0 = chunk * 16u;
+	const uint64_t wave_chunk0 = chunk - lane;
+	const uint32_t w0 = live ? load_packed_chunk(rb.bases, rb.n_bases, chunk) : 0u;
+	const uint32_t hw = (lane < 4u) ? load_packed_chunk(rb.bases, rb.n_bases, wave_chunk0 + 64u + lane) : 0u; // (0 beyond the end)
+	const uint32_t h0 = __builtin_amdgcn_readlane(hw, 0), h1 = __builtin_amdgcn_readlane(hw, 1), h2 = __builtin_amdgcn_readlane(hw, 2),
+	               h3 = __builtin_amdgcn_readlane(hw, 3);
+	uint32_t w1 = __shfl_down(w0, 1, 64), w2 = __shfl_down(w0, 2, 64), w3 = __shfl_down(w0, 3, 64), w4 = __shfl_down(w0, 4, 64);
+	if (lane == 63u) { w1 = h0; w2 = h1; w3 = h2; w4 = h3; }
+	if (lane == 62u) { w2 = h0; w3 = h1; w4 = h2; }
+	if (lane == 61u) { w3 = h0; w4 = h1; }
+	if (lane == 60u) w4 = h0;
+	uint32_t prev = __shfl_up(w0, 1, 64) & 3u; // last base of the previous lane's chunk
+	uint32_t pb = 0u;
+	if (lane == 0u && live && chunk > 0u) pb = pack4_ascii((uint32_t)(uint8_t)rb.bases[p0 - 1u]) >> 6;
+	pb = __builtin_amdgcn_readlane(pb, 0);
+	if (lane == 0u) prev = pb;
+	if (chunk == 0u) prev = 0u;
+	// 80 bases from p0, MSB first
+	const uint64_t A = ((uint64_t)w0 << 32) | w1, B = ((uint64_t)w2 << 32) | w3, C = (uint64_t)w4 << 32;
+	if (2u * k <= 64u) {
+		c.fwd.hi = 0ull;
+		c.fwd.lo = A >> (64u - 2u * k);
+	} else {
+		const uint32_t sh = 128u - 2u * k; // 2..62
+		c.fwd.hi = A >> sh;
+		c.fwd.lo = (B >> sh) | (A << (64u - sh));
+	}
+	c.rc = dbgk_wide::revcomp(c.fwd, (int)k);
+	// bases k .. k+15 of the 80: the 32 bits at bit offset 2k of the 160-bit string A:B:C
+	{
+		const uint32_t off = 2u * k; // 2..126
+		const uint64_t top = (uint64_t)(((((u128)A << 64) | B) << off) >> 64);   // bits off .. off+63 of A:B (zeros shifted in)
+		const uint64_t tail = off > 64u ? (C >> (128u - off)) : 0ull;           // ... continued by C where the 64 bits reach past B
+		c.nb = (uint32_t)((top | tail) >> 32);
+	}
+	c.lw = (prev << 30) | (w0 >> 2);
+	uint64_t S0 = 0, S1 = 0, D0 = 0, D1 = 0;
+	if (live) {
+		load_bits128(rb.start_bits, p0, rb.n_bases, S0, S1);
+		if (HAS_DEAD) load_bits128(rb.dead_bits, p0, rb.n_bases, D0, D1);
+	}
+	const u128 S = ((u128)S1 << 64) | S0;
+	// window i is inside one read iff no read starts at positions i+1 .. i+k-1 (and no dead position in i .. i+k-1)
+	uint32_t bad = sliding_or128_lo16(S >> 1, k - 1u);
+	uint32_t no_r = (uint32_t)(S >> k) & 0xFFFFu;
+	if (HAS_DEAD) {
+		const u128 D = ((u128)D1 << 64) | D0;
+		bad |= sliding_or128_lo16(D, k);
+		no_r |= (uint32_t)(D >> k) & 0xFFFFu;
+	}
+	const uint64_t room = (live && rb.n_bases > p0) ? rb.n_bases - p0 : 0ull;
+	const uint32_t nv = room >= k ? (uint32_t)(room - k + 1u < 16u ? room - k + 1u : 16u) : 0u;
+	const uint32_t nr = room > k ? (uint32_t)(room - k < 16u ? room - k : 16u) : 0u;
+	c.valid = ~bad & ((1u << nv) - 1u);
+	c.has_r = ~no_r & ((1u << nr) - 1u);
+	c.has_l = ~(uint32_t)S0 & 0xFFFFu & (p0 ? 0xFFFFu : 0xFFFEu);
+	return c;
+}
+
+// WIDE_D: how hash / size is computed -- 0: size < 2^31, 1: size < 2^32, 2: any size (see l1_positions)
+template <bool HAS_DEAD, int WIDE_D>
 __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, WPartGeom G, WPartStore P, WTable T, Counters *__restrict__ ctr)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -113,99 +211,76 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, W
 	const uint32_t k = (uint32_t)rb.k; // 1..63
 	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
 	const uint32_t rmask = (1u << G.r) - 1u;
-	const uint64_t inner_mask = (k > 1u) ? ((1ull << (k - 1u)) - 1ull) : 0ull; // k - 1 <= 62 bits
-	const uint64_t km = (1ull << k) - 1ull;                                      // k <= 63
-	const uint32_t top = 2u * k - 2u;                                            // bit position of a window's first base
+	const uint32_t top = 2u * k - 2u;  // bit position of a window's first base
+	const uint64_t mask_hi = k > 32u ? ((1ull << (2u * k - 64u)) - 1ull) : 0ull;
+	const uint64_t mask_lo = k >= 32u ? ~0ull : ((1ull << (2u * k)) - 1ull);
 	for (uint64_t c0 = (uint64_t)blockIdx.x * kWL1Threads; c0 < n_chunks; c0 += (uint64_t)gridDim.x * kWL1Threads) {
 		const uint32_t tid = fresh_tid();
-		const uint64_t chunk = c0 + tid;
-		const bool live = chunk < n_chunks;
-		const uint64_t p0 = chunk * 16u;
-		// 80 bases from p0 (window of the last position + its right neighbour: 15 + 63 + 1), MSB first
-		uint64_t A = 0, B = 0, C = 0, S0 = 0, S1 = 0, D0 = 0, D1 = 0;
-		uint32_t prev = 0;
-		if (live) {
-			A = ((uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk) << 32) | load_packed_chunk(rb.bases, rb.n_bases, chunk + 1);
-			B = ((uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk + 2) << 32) | load_packed_chunk(rb.bases, rb.n_bases, chunk + 3);
-			C = (uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk + 4) << 32;
-			prev = chunk ? pack4_ascii((uint32_t)(uint8_t)rb.bases[p0 - 1]) >> 6 : 0u;
-			load_bits128(rb.start_bits, p0, rb.n_bases, S0, S1);
-			if (HAS_DEAD) load_bits128(rb.dead_bits, p0, rb.n_bases, D0, D1);
-		}
-		// reverse complement of the first window; it then ROLLS by one base per position like the forward k-mer
-		Key128 rc;
-		{
-			Key128 f0;
-			if (2u * k <= 64u) {
-				f0.hi = 0ull;
-				f0.lo = A >> (64u - 2u * k);
-			} else {
-				const uint32_t sh = 128u - 2u * k;
-				f0.hi = A >> sh;
-				f0.lo = (B >> sh) | (A << (64u - sh));
-			}
-			rc = dbgk_wide::revcomp(f0, (int)k);
-		}
+		WChunk16 c = wide_decode_chunk16<HAS_DEAD>(rb, c0 + tid, n_chunks);
 #pragma unroll 1
 		for (uint32_t half = 0; half < 2u; half++) {
 			L.hist[tid] = 0u; // kBpt == 1
 			if (tid < 64u) L.hist[1024u + tid] = 0u;
 			lds_barrier();
 			uint32_t bkt[8];
+			uint32_t rev_mask = 0, zero_lo = 0;
 #pragma unroll
 			for (uint32_t i = 0; i < 8u; i++) {
-				const uint64_t p = p0 + half * 8u + i;
-				Key128 fwd;
-				uint32_t right;
-				if (2u * k <= 64u) {
-					fwd.hi = 0ull;
-					fwd.lo = A >> (64u - 2u * k);
-					right = (2u * k < 64u) ? (uint32_t)(A >> (62u - 2u * k)) & 3u : (uint32_t)(B >> 62);
-				} else {
-					const uint32_t sh = 128u - 2u * k; // 2..62
-					fwd.hi = A >> sh;
-					fwd.lo = (B >> sh) | (A << (64u - sh));
-					right = (uint32_t)(B >> (sh - 2u)) & 3u;
-				}
-				// the window [p, p + k) lies inside one read (no read starts at p+1 .. p+k-1) and inside the trimmed part
-				bool valid = live && (p + k <= rb.n_bases) && (((S0 >> 1) | (S1 << 63)) & inner_mask) == 0ull;
-				const bool has_left = p > 0 && !(S0 & 1ull);
-				bool has_right = (p + k < rb.n_bases) && !((S0 >> k) & 1ull); // k <= 63
-				if (HAS_DEAD) {
-					valid = valid && (D0 & km) == 0ull;
-					has_right = has_right && !((D0 >> k) & 1ull);
-				}
-				// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97)
-				const bool rev = rc.hi < fwd.hi || (rc.hi == fwd.hi && rc.lo < fwd.lo);
-				const Key128 key{rev ? rc.hi : fwd.hi, rev ? rc.lo : fwd.lo};
-				const uint32_t cl = has_left ? prev : 4u, cr = has_right ? right : 4u;
-				const uint32_t lb = rev ? (cr == 4u ? 4u : 3u - cr) : cl, rbb = rev ? (cl == 4u ? 4u : 3u - cl) : cr;
-				if (valid && key.lo == 0ull) wide_insert(T, key, lb, rbb, ctr, n_new, n_conf, full); // rare: k-mer ends in 32 A's
-				const bool has_rec = valid && key.lo != 0ull;
+				const uint32_t sh = 30u - 2u * i;
+				const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+				// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97).  The loop
+				// assumes both neighbours exist; windows at a read's first / last position are patched afterwards.
+				const bool rev = c.rc.hi < c.fwd.hi || (c.rc.hi == c.fwd.hi && c.rc.lo < c.fwd.lo);
+				const Key128 key{rev ? c.rc.hi : c.fwd.hi, rev ? c.rc.lo : c.fwd.lo};
+				const uint32_t links = rev ? (((3u - right) << 3) | (3u - left)) : ((left << 3) | right);
+				rev_mask |= (rev ? 1u : 0u) << i;
+				const bool valid = (c.valid >> i) & 1u;
+				zero_lo |= (valid && key.lo == 0ull ? 1u : 0u) << i; // rare: handled after the loop through the atomic path
 				uint64_t q;
-				const uint64_t slot = fast_divmod(hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo), G.magic, q);
-				const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)((uint32_t)slot & rmask) << 6) | (lb << 3) | rbb;
-				const uint32_t b = has_rec ? (uint32_t)(slot >> G.r) : 1024u + (tid & 63u);
+				const uint64_t hv = hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo);
+				uint32_t slot_lo, bucket;
+				if (WIDE_D == 2) {
+					const uint64_t s64 = fast_divmod(hv, G.magic, q);
+					slot_lo = (uint32_t)s64;
+					bucket = (uint32_t)(s64 >> G.r);
+				} else {
+					slot_lo = WIDE_D ? divmod_u64_u32(hv, G.div, q) : divmod_magic_small(hv, G.magic.m, (uint32_t)G.magic.d, q);
+					bucket = slot_lo >> G.r;
+				}
+				const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & rmask) << 6) | links;
+				const uint32_t b = (valid && key.lo != 0ull) ? bucket : 1024u + (tid & 63u);
 				L.stage[i * kWL1Threads + tid] = ull2{key.hi, w};
 				bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-				// slide by one base
-				prev = (uint32_t)(A >> 62);
-				A = (A << 2) | (B >> 62);
-				B = (B << 2) | (C >> 62);
-				C <<= 2;
-				S0 = (S0 >> 1) | (S1 << 63);
-				S1 >>= 1;
-				if (HAS_DEAD) {
-					D0 = (D0 >> 1) | (D1 << 63);
-					D1 >>= 1;
-				}
-				// reverse complement of the next window: drop the complement of the base that left, the complement of
-				// the entering base (`right`) arrives at the top
-				rc.lo = (rc.lo >> 2) | (rc.hi << 62);
-				rc.hi >>= 2;
+				// roll to the next position
+				c.fwd.hi = ((c.fwd.hi << 2) | (c.fwd.lo >> 62)) & mask_hi;
+				c.fwd.lo = ((c.fwd.lo << 2) | right) & mask_lo;
+				c.rc.lo = (c.rc.lo >> 2) | (c.rc.hi << 62);
+				c.rc.hi >>= 2;
 				const uint64_t comp = (uint64_t)(3u - right);
-				if (top >= 64u) rc.hi |= comp << (top - 64u); else rc.lo |= comp << top;
+				if (top >= 64u) c.rc.hi |= comp << (top - 64u); else c.rc.lo |= comp << top;
 			}
+			// windows without a left / right neighbour: that side's code becomes 4 = none; keys with lo == 0 go through the
+			// atomic path with their final codes (their parked record sits in a dummy bin and is never copied out)
+			const uint32_t no_l = ~c.has_l & 0xFFu, no_r = ~c.has_r & 0xFFu, v8 = c.valid & 0xFFu;
+			for (uint32_t fix = ((no_l | no_r) & v8) | zero_lo; fix; fix &= fix - 1u) {
+				const uint32_t i = (uint32_t)__builtin_ctz(fix);
+				const bool fwd_strand = !((rev_mask >> i) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+				ull2 rec = L.stage[i * kWL1Threads + tid];
+				uint32_t lb = ((uint32_t)rec.y >> 3) & 7u, rbb = (uint32_t)rec.y & 7u;
+				if (fwd_strand ? nl : nr) lb = 4u;
+				if (fwd_strand ? nr : nl) rbb = 4u;
+				rec.y = (rec.y & ~63ull) | (lb << 3) | rbb;
+				if ((zero_lo >> i) & 1u) {
+					wide_insert(T, Key128{rec.x, 0ull}, lb, rbb, ctr, n_new, n_conf, full);
+				} else {
+					L.stage[i * kWL1Threads + tid] = rec;
+				}
+			}
+			c.lw <<= 16;
+			c.nb <<= 16;
+			c.valid >>= 8;
+			c.has_l >>= 8;
+			c.has_r >>= 8;
 			lds_barrier(); // histogram complete, parked records visible
 			ull2 rec[8];
 #pragma unroll
@@ -214,33 +289,30 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, W
 			scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
 #pragma unroll
 			for (uint32_t i = 0; i < 8u; i++)
-				if ((bkt[i] >> 16) < 1024u) L.stage[L.lbase[bkt[i] >> 16] + (bkt[i] & 0xFFFFu)] = rec[i];
+				if ((bkt[i] >> 16) < 1024u) {
+					const uint32_t at = L.lbase[bkt[i] >> 16] + (bkt[i] & 0xFFFFu);
+					L.stage[at] = rec[i];
+					L.bucket_of[at] = (uint16_t)(bkt[i] >> 16);
+				}
+			L.desc[fresh_tid()] = my_gbase[0];
+			lds_barrier();
+			// copy-out: the sorted stage is walked linearly, one 16-byte record per lane and every lane busy -- with several
+			// hundred level-1 buckets a tile holds only a handful of records per bucket, and the memory pipe charges a store
+			// instruction the same whatever its lane count (dbgk_partition.h)
 			{
 				const uint32_t t = fresh_tid();
-				L.desc[t] = ((uint64_t)my_gbase[0] << 32) | (L.hist[t] << 16) | L.lbase[t]; // <= 8192 records per tile: 16 bits each
-			}
-			lds_barrier();
-			// copy-out: wave w takes buckets w, w + 16, ...; one 16-byte record per lane and store
-			{
-				const uint32_t t = fresh_tid(), lane = t & 63u, wave = t >> 6;
-				constexpr uint32_t kWaves = kWL1Threads / 64;
-				const uint32_t per_wave = (G.n1 + kWaves - 1u - wave) / kWaves; // <= 64
-				const uint64_t d = (lane < per_wave) ? L.desc[wave + kWaves * lane] : 0ull;
-				const uint32_t d_lo = (uint32_t)d, d_hi = (uint32_t)(d >> 32);
-				for (uint32_t kk = 0; kk < per_wave; kk++) {
-					const uint32_t kq = __builtin_amdgcn_readfirstlane(kk);
-					const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kq), dst = __builtin_amdgcn_readlane(d_hi, kq);
-					const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
-					if (n == 0) continue;
-					const uint32_t b = wave + kWaves * kq;
-					ull2 *o = P.l1 + (uint64_t)b * G.cap1 + dst;
-					for (uint32_t j = lane; j < n; j += 64u) {
-						const ull2 rcd = L.stage[src + j];
-						if ((uint64_t)dst + j < G.cap1) {
-							o[j] = rcd;
-						} else { // the bucket is full
-							wide_push_overflow(P, wide_record_key(rcd, b, G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
-						}
+				const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u];
+#pragma unroll
+				for (uint32_t u = 0; u < 8u; u++) {
+					const uint32_t p = u * kWL1Threads + t;
+					if (p >= total) continue;
+					const ull2 rcd = L.stage[p];
+					const uint32_t b = L.bucket_of[p];
+					const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
+					if (off < G.cap1) {
+						P.l1[(uint64_t)b * G.cap1 + off] = rcd;
+					} else { // the bucket is full
+						wide_push_overflow(P, wide_record_key(rcd, b, G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
 					}
 				}
 			}
