@@ -56,8 +56,12 @@ typedef struct dbgk_handle dbgk_handle;
                                      index, position, strand) of its first occurrence + uniqueness flag   */
 #define DBGK_ENGINE_WIDE       5  /* k-mers of up to 63 bases: 128-bit keys, 32-byte nodes (include/dbgk_wide.h; the reference
                                      stops at k = 31, so this path is this build's own definition: parity unpinned for
-                                     k > 32, identical to the reference's rules for k <= 32).  Fused extract + atomic insert;
-                                     results through dbgk_wide_export_*, dbgk_digest, dbgk_link_stats_device            */
+                                     k > 32, identical to the reference's rules for k <= 32).  expected_kmers > 0 and
+                                     2^26 <= table_slots <= 2^32: 16-byte records are radix-partitioned and the table is built
+                                     region by region in LDS (2.7x faster; 16 bytes per occurrence + an eighth again must fit
+                                     the device; what does not fit the record store joins through the atomic kernels after
+                                     the build); otherwise fused extract + atomic insert.  Results through
+                                     dbgk_wide_export_*, dbgk_digest, dbgk_link_stats_device                            */
 #define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
                                      canonical k-mers (the correct_error module's frequency table);
                                      table_slots is ignored, k <= 18.  expected_kmers > 0: the occurrences
