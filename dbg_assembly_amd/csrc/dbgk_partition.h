@@ -26,7 +26,13 @@
 
 namespace dbgk {
 
-constexpr int kRegionBits = 12;                 // 4096 slots = 64 KiB of nodes per region
+#ifndef DBGK_REGION_BITS
+#define DBGK_REGION_BITS 12
+#endif
+#ifndef DBGK_BUILD_THREADS
+#define DBGK_BUILD_THREADS 1024
+#endif
+constexpr int kRegionBits = DBGK_REGION_BITS;   // 4096 slots = 64 KiB of nodes per region (experiments: 11)
 constexpr int kRegionSlots = 1 << kRegionBits;
 constexpr int kSpillSlots = 128;                // LDS slots past the region end: probe overflow
 #ifndef DBGK_L1_THREADS
@@ -40,7 +46,7 @@ constexpr int kL1MaxB = DBGK_L1_MAXB;           // level-1 fan-out limit (histog
 constexpr int kMaxBuckets = 1024;               // per-level fan-out limit (LDS histogram size)
 constexpr int kSubStores = 1;                   // level-1 sub-stores per bucket (8 = one per XCD was measured: 7.04 ms against 7.07, so off)
 constexpr int kL1Threads = kTileThreads;
-constexpr int kBuildThreads = 1024;            // 2 workgroups per CU (66 KiB LDS each) = 32 waves per CU, needs <= 64 VGPRs
+constexpr int kBuildThreads = DBGK_BUILD_THREADS; // 2 workgroups per CU (66 KiB LDS each) = 32 waves per CU, needs <= 64 VGPRs
 
 // ---- inverse of hash_code ------------------------------------------------------------------
 constexpr uint64_t mod_inverse_u64(uint64_t a) // a odd; Newton iteration doubles the correct bits
