@@ -186,7 +186,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
-    from dbg_assembly_amd.multigpu import HipEngine, exchange_and_merge, sharded_finalize
+    from dbg_assembly_amd.multigpu import HipEngine, WideHipEngine, exchange_and_merge, sharded_finalize
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,8 +212,6 @@ def main():
     genome_len = args.genome_per_gpu * world
     kpr = 150 - args.kmer + 1
     P = capi.synth_params(genome_len, 150, sub_rate=CONFIGS[args.config].get("sub_rate", 0.005), cfg=CONFIGS[args.config]["synth_cfg"])
-    if args.config == "cfg5" and multi:
-        sys.exit("bench.py --config cfg5: the WIDE engine is single-GPU (sharding of 128-bit keys is not built yet)")
     # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
     # (PARTITION engine, slot-range ownership; up to 2^34 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
@@ -230,7 +228,8 @@ def main():
                    else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
-    engine = HipEngine(g, device)
+    # WIDE (cfg5) on several GPUs: every rank builds the graph of its reads, the aggregated 32-byte nodes go to their owners
+    engine = WideHipEngine(g, device) if args.engine == capi.ENGINE_WIDE else HipEngine(g, device)
 
     debug_mode = int(os.environ.get("DBGK_DEBUG_MODE", "0"))  # kernel timing experiments: results are wrong
     debug_l2 = int(os.environ.get("DBGK_DEBUG_L2", "0")) or int(os.environ.get("DBGK_DEBUG_BUILD", "0"))

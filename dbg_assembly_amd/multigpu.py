@@ -58,6 +58,26 @@ class HipEngine:
         self.g.sync()
 
 
+class WideHipEngine(HipEngine):
+    """the same flow for a WIDE handle (k <= 63): 32-byte nodes {kmer_hi, kmer_lo, l_link, r_link, reserved},
+    owner of a node = (hash128 >> 32) % n (dbgk_wide_partition_export / dbgk_wide_merge_nodes)"""
+    node_bytes = 32
+
+    def partition_counts(self, n_parts):
+        return self.g.wide_partition_export(n_parts).astype(np.int64)
+
+    def partition_export(self, n_parts, total_nodes):
+        buf = torch.empty(max(int(total_nodes), 1) * self.node_bytes, dtype=torch.uint8, device=self.device)
+        self.g.wide_partition_export(n_parts, buf.data_ptr(), int(total_nodes))
+        return buf
+
+    def new_buffer(self, n_nodes):
+        return torch.empty(max(int(n_nodes), 1) * self.node_bytes, dtype=torch.uint8, device=self.device)
+
+    def merge(self, buf, n_nodes):
+        self.g.wide_merge_nodes(buf.data_ptr(), int(n_nodes))
+
+
 # One message per peer and transfer is bounded: a single 3.5 GB all_to_all_single (the node buffers of a
 # bench-size table) was observed to move only its first 1.78 GB on this RCCL build and report success
 # (profiles/ history, round 1).  Every bulk transfer below goes through point-to-point sends/receives of
@@ -113,6 +133,7 @@ def exchange_and_merge(engine, group=None):
     exactly the keys this rank owns, fully merged."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    NODE_BYTES = getattr(engine, "node_bytes", 16)
     st = engine.local_stats()
     local_reads, local_kmers, local_stored = int(st.total_reads), int(st.total_kmers), int(st.stored_kmers)
 

@@ -54,6 +54,40 @@ def test_exchange_and_merge_single_rank_nccl(engine):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("expected", [0, 200000 * 150])
+def test_exchange_and_merge_wide_single_rank_nccl(expected):
+    """`bench.py --config cfg5` on several GPUs: the same flow with 32-byte nodes (WideHipEngine), the local graph built
+    by the fused-atomic kernels (expected = 0) or through records"""
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import WideHipEngine, exchange_and_merge
+
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_reads, G = 200000, 1500000
+        P = capi.synth_params(G, 150, sub_rate=0.001, cfg=5)
+        size = capi.find_next_prime_ref(1 << 26)
+        with capi.Graph(k=63, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=expected) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            for _ in range(2):   # two steps: the handle must be reusable (bench loop)
+                g.reset()
+                g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+                st = g.finalize()
+                want = (st.count, st.total_kmers, st.total_reads, g.digest())
+                out = exchange_and_merge(WideHipEngine(g, torch.device("cuda", 0)))
+                assert (out["count"], out["total_kmers"], out["total_reads"]) == want[:3]
+                assert out["sent_nodes"] == out["recv_nodes"] == st.count
+                assert g.digest() == want[3]
+            d_bases.free()
+            d_off.free()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("chunks", [8, 1])
 def test_sharded_finalize_single_rank_nccl(oracle, chunks):
     """slot-range ownership flow of bench.py (N > 1) with a one-rank shard: the all-to-all runs on
