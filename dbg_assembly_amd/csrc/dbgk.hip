@@ -401,6 +401,9 @@ static int setup_wide_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 1>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 2>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 2>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<0>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<1>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<2>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<1024>, sizeof(WL2Lds<1024>));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<2048>, sizeof(WL2Lds<2048>));
 	DBGK_LDS_ATTR(k_wide_build_regions, sizeof(WBuildLds));
@@ -968,6 +971,26 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	return (double)(n_reads * Q * C) <= 0.93 * (double)n_bases ? 2 : 0;
 }
 
+// WIDE record path: can this batch take the equal-length level-1 kernel (k_wide_scatter_l1_uniform)?
+static int wide_uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t n_reads, uint64_t n_bases, int has_long, WUniformGeom &U)
+{
+	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
+	if (off || has_long || n_reads == 0 || uniform_len <= 0) return 0;
+	const uint64_t L = (uint64_t)uniform_len, k = (uint64_t)h->cfg.kmer_size;
+	if (L > (uint64_t)h->cfg.max_read_len || L < k || L >= (1ull << 24) || n_bases != n_reads * L) return 0;
+	const uint32_t W = (uint32_t)(L - k + 1);
+	const uint64_t Q = (W + 7u) / 8u;
+	if (Q >= 2048 || n_reads * Q >= (1ull << 40)) return 0;
+	if (((uint64_t)kWL1Threads / Q + 2) * L + 96 > (uint64_t)(kWPkWords - 8u) * 16) return 0; // bytes a tile of 1024 lanes can touch
+	if ((double)(n_reads * Q * 8) > 0.93 * (double)n_bases) return 0; // (k small against L: the flat kernel wastes little)
+	U.L = (uint32_t)L;
+	U.W = W;
+	U.Q = (uint32_t)Q;
+	U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
+	U.n_lanes = n_reads * Q;
+	return 1;
+}
+
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
                         int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */,
@@ -994,8 +1017,13 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		                   h->cfg.kmer_size, h->cfg.max_read_len, d_start, has_long != 0 ? d_dead : nullptr, h->d_ctr, with_stats);
 		return DBGK_OK;
 	};
-	const bool may_skip_bits = h->part && !h->seed;
-	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15);
+	const bool wrec = h->wide && h->wpart && !h->wbuilt; // WIDE handle that is still collecting records
+	WUniformGeom WU{};
+	auto decide_umode = [&]() {
+		return wrec ? wide_uniform_mode(h, uniform_len, n_reads, n_bases, has_long, WU) : uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15);
+	};
+	const bool may_skip_bits = (h->part && !h->seed) || wrec;
+	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) umode = decide_umode();
 	if (may_skip_bits && (umode > 0 || umode < 0)) {
 		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases, h->cfg.kmer_size,
 		                   h->cfg.max_read_len, (uint32_t *)nullptr, (uint32_t *)nullptr, h->d_ctr, 1); // statistics only
@@ -1006,7 +1034,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (h->seed && n_bases)
 		hipLaunchKernelGGL(k_mark_n, dim3(grid_for(h, (n_bases + 31) >> 5)), dim3(kBlock), 0, h->stream, d_bases, n_bases, d_dead);
 	HIPCHK(hipGetLastError());
-	if (has_long < 0 || (uniform_len < 0 && h->part)) {
+	if (has_long < 0 || (uniform_len < 0 && (h->part || wrec))) {
 		HIPCHK(hipMemcpyAsync(&h->h_ctr->any_dead, &h->d_ctr->any_dead, 20, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		if (has_long < 0) has_long = h->h_ctr->any_dead ? 1 : 0;
@@ -1016,7 +1044,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		}
 	}
 	if (may_skip_bits && umode < 0) {
-		umode = uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15);
+		umode = decide_umode();
 		if (umode == 0) { // the general kernel after all: it needs the bitmaps
 			rc = mark_bits(0);
 			if (rc) return rc;
@@ -1035,7 +1063,16 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (rc) return rc;
 	if (h->seed) {
 		hipLaunchKernelGGL(k_seed_insert, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, d_offsets, n_reads, id_base, h->tref(), h->d_ctr);
-	} else if (h->wide && h->wpart && !h->wbuilt) {
+	} else if (wrec && umode > 0) {
+		h->uniform_launches++;
+		const int grid = (int)std::min<uint64_t>((WU.n_lanes + kWL1Threads - 1) / kWL1Threads, (uint64_t)h->n_cu);
+		const int wd = h->size >= (1ull << 32) ? 2 : (h->size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
+#define DBGK_LAUNCH_WIDE_L1U(WD)                                                                                                                    \
+	hipLaunchKernelGGL((k_wide_scatter_l1_uniform<WD>), dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, WU, h->wgeom, h->wstore, h->wref(), \
+	                   h->d_ctr)
+		if (wd == 2) DBGK_LAUNCH_WIDE_L1U(2); else if (wd == 1) DBGK_LAUNCH_WIDE_L1U(1); else DBGK_LAUNCH_WIDE_L1U(0);
+#undef DBGK_LAUNCH_WIDE_L1U
+	} else if (wrec) {
 		const int grid = (int)std::min<uint64_t>((n_chunks + kWL1Threads - 1) / kWL1Threads, (uint64_t)h->n_cu);
 		const int wd = h->size >= (1ull << 32) ? 2 : (h->size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
 #define DBGK_LAUNCH_WIDE_L1(DEAD, WD)                                                                                                          \

@@ -200,125 +200,128 @@ __device__ __forceinline__ WChunk16 wide_decode_chunk16(const ReadBatch &rb, uin
 	return c;
 }
 
-// WIDE_D: how hash / size is computed -- 0: size < 2^31, 1: size < 2^32, 2: any size (see l1_positions)
-template <bool HAS_DEAD, int WIDE_D>
-__global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, WPartGeom G, WPartStore P, WTable T, Counters *__restrict__ ctr)
+// One tile of level 1: the first 8 positions of every lane's chunk state (bits 0..7 of its masks, the top halves of
+// nb / lw) -> records parked, ranked, sorted by bucket in LDS and copied out.  The chunk state is rolled forward by
+// 8 positions.  WIDE_D: how hash / size is computed -- 0: size < 2^31, 1: size < 2^32, 2: any size (see l1_positions)
+struct WideL1Consts {
+	uint32_t rmask, top;
+	uint64_t mask_hi, mask_lo;
+};
+
+template <int WIDE_D>
+__device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, const WPartStore &P, const WTable &T, Counters *ctr, WChunk16 &c,
+                                             const WideL1Consts &K, unsigned long long &n_new, unsigned long long &n_conf, bool &full)
 {
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	WL1Lds &L = *reinterpret_cast<WL1Lds *>(lds_raw);
-	unsigned long long n_new = 0, n_conf = 0;
-	bool full = false;
-	const uint32_t k = (uint32_t)rb.k; // 1..63
-	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
-	const uint32_t rmask = (1u << G.r) - 1u;
-	const uint32_t top = 2u * k - 2u;  // bit position of a window's first base
-	const uint64_t mask_hi = k > 32u ? ((1ull << (2u * k - 64u)) - 1ull) : 0ull;
-	const uint64_t mask_lo = k >= 32u ? ~0ull : ((1ull << (2u * k)) - 1ull);
-	for (uint64_t c0 = (uint64_t)blockIdx.x * kWL1Threads; c0 < n_chunks; c0 += (uint64_t)gridDim.x * kWL1Threads) {
-		const uint32_t tid = fresh_tid();
-		WChunk16 c = wide_decode_chunk16<HAS_DEAD>(rb, c0 + tid, n_chunks);
-#pragma unroll 1
-		for (uint32_t half = 0; half < 2u; half++) {
-			L.hist[tid] = 0u; // kBpt == 1
-			if (tid < 64u) L.hist[1024u + tid] = 0u;
-			lds_barrier();
-			uint32_t bkt[8];
-			uint32_t rev_mask = 0, zero_lo = 0;
+	const uint32_t tid = fresh_tid();
+	uint32_t bkt[8];
+	uint32_t rev_mask = 0, zero_lo = 0;
 #pragma unroll
-			for (uint32_t i = 0; i < 8u; i++) {
-				const uint32_t sh = 30u - 2u * i;
-				const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
-				// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97).  The loop
-				// assumes both neighbours exist; windows at a read's first / last position are patched afterwards.
-				const bool rev = c.rc.hi < c.fwd.hi || (c.rc.hi == c.fwd.hi && c.rc.lo < c.fwd.lo);
-				const Key128 key{rev ? c.rc.hi : c.fwd.hi, rev ? c.rc.lo : c.fwd.lo};
-				const uint32_t links = rev ? (((3u - right) << 3) | (3u - left)) : ((left << 3) | right);
-				rev_mask |= (rev ? 1u : 0u) << i;
-				const bool valid = (c.valid >> i) & 1u;
-				zero_lo |= (valid && key.lo == 0ull ? 1u : 0u) << i; // rare: handled after the loop through the atomic path
-				uint64_t q;
-				const uint64_t hv = hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo);
-				uint32_t slot_lo, bucket;
-				if (WIDE_D == 2) {
-					const uint64_t s64 = fast_divmod(hv, G.magic, q);
-					slot_lo = (uint32_t)s64;
-					bucket = (uint32_t)(s64 >> G.r);
-				} else {
-					slot_lo = WIDE_D ? divmod_u64_u32(hv, G.div, q) : divmod_magic_small(hv, G.magic.m, (uint32_t)G.magic.d, q);
-					bucket = slot_lo >> G.r;
-				}
-				const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & rmask) << 6) | links;
-				const uint32_t b = (valid && key.lo != 0ull) ? bucket : 1024u + (tid & 63u);
-				L.stage[i * kWL1Threads + tid] = ull2{key.hi, w};
-				bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-				// roll to the next position
-				c.fwd.hi = ((c.fwd.hi << 2) | (c.fwd.lo >> 62)) & mask_hi;
-				c.fwd.lo = ((c.fwd.lo << 2) | right) & mask_lo;
-				c.rc.lo = (c.rc.lo >> 2) | (c.rc.hi << 62);
-				c.rc.hi >>= 2;
-				const uint64_t comp = (uint64_t)(3u - right);
-				if (top >= 64u) c.rc.hi |= comp << (top - 64u); else c.rc.lo |= comp << top;
-			}
-			// windows without a left / right neighbour: that side's code becomes 4 = none; keys with lo == 0 go through the
-			// atomic path with their final codes (their parked record sits in a dummy bin and is never copied out)
-			const uint32_t no_l = ~c.has_l & 0xFFu, no_r = ~c.has_r & 0xFFu, v8 = c.valid & 0xFFu;
-			for (uint32_t fix = ((no_l | no_r) & v8) | zero_lo; fix; fix &= fix - 1u) {
-				const uint32_t i = (uint32_t)__builtin_ctz(fix);
-				const bool fwd_strand = !((rev_mask >> i) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
-				ull2 rec = L.stage[i * kWL1Threads + tid];
-				uint32_t lb = ((uint32_t)rec.y >> 3) & 7u, rbb = (uint32_t)rec.y & 7u;
-				if (fwd_strand ? nl : nr) lb = 4u;
-				if (fwd_strand ? nr : nl) rbb = 4u;
-				rec.y = (rec.y & ~63ull) | (lb << 3) | rbb;
-				if ((zero_lo >> i) & 1u) {
-					wide_insert(T, Key128{rec.x, 0ull}, lb, rbb, ctr, n_new, n_conf, full);
-				} else {
-					L.stage[i * kWL1Threads + tid] = rec;
-				}
-			}
-			c.lw <<= 16;
-			c.nb <<= 16;
-			c.valid >>= 8;
-			c.has_l >>= 8;
-			c.has_r >>= 8;
-			lds_barrier(); // histogram complete, parked records visible
-			ull2 rec[8];
-#pragma unroll
-			for (uint32_t i = 0; i < 8u; i++) rec[i] = L.stage[i * kWL1Threads + fresh_tid()];
-			uint32_t my_gbase[1];
-			scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
-#pragma unroll
-			for (uint32_t i = 0; i < 8u; i++)
-				if ((bkt[i] >> 16) < 1024u) {
-					const uint32_t at = L.lbase[bkt[i] >> 16] + (bkt[i] & 0xFFFFu);
-					L.stage[at] = rec[i];
-					L.bucket_of[at] = (uint16_t)(bkt[i] >> 16);
-				}
-			L.desc[fresh_tid()] = my_gbase[0];
-			lds_barrier();
-			// copy-out: the sorted stage is walked linearly, one 16-byte record per lane and every lane busy -- with several
-			// hundred level-1 buckets a tile holds only a handful of records per bucket, and the memory pipe charges a store
-			// instruction the same whatever its lane count (dbgk_partition.h)
-			{
-				const uint32_t t = fresh_tid();
-				const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u];
-#pragma unroll
-				for (uint32_t u = 0; u < 8u; u++) {
-					const uint32_t p = u * kWL1Threads + t;
-					if (p >= total) continue;
-					const ull2 rcd = L.stage[p];
-					const uint32_t b = L.bucket_of[p];
-					const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
-					if (off < G.cap1) {
-						P.l1[(uint64_t)b * G.cap1 + off] = rcd;
-					} else { // the bucket is full
-						wide_push_overflow(P, wide_record_key(rcd, b, G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
-					}
-				}
-			}
-			lds_barrier(); // the next tile parks its records in the stage buffer again
+	for (uint32_t i = 0; i < 8u; i++) {
+		const uint32_t sh = 30u - 2u * i;
+		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+		// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97).  The loop
+		// assumes both neighbours exist; windows at a read's first / last position are patched afterwards.
+		const bool rev = c.rc.hi < c.fwd.hi || (c.rc.hi == c.fwd.hi && c.rc.lo < c.fwd.lo);
+		const Key128 key{rev ? c.rc.hi : c.fwd.hi, rev ? c.rc.lo : c.fwd.lo};
+		const uint32_t links = rev ? (((3u - right) << 3) | (3u - left)) : ((left << 3) | right);
+		rev_mask |= (rev ? 1u : 0u) << i;
+		const bool valid = (c.valid >> i) & 1u;
+		zero_lo |= (valid && key.lo == 0ull ? 1u : 0u) << i; // rare: handled after the loop through the atomic path
+		uint64_t q;
+		const uint64_t hv = hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo);
+		uint32_t slot_lo, bucket;
+		if (WIDE_D == 2) {
+			const uint64_t s64 = fast_divmod(hv, G.magic, q);
+			slot_lo = (uint32_t)s64;
+			bucket = (uint32_t)(s64 >> G.r);
+		} else {
+			slot_lo = WIDE_D ? divmod_u64_u32(hv, G.div, q) : divmod_magic_small(hv, G.magic.m, (uint32_t)G.magic.d, q);
+			bucket = slot_lo >> G.r;
+		}
+		const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & K.rmask) << 6) | links;
+		const uint32_t b = (valid && key.lo != 0ull) ? bucket : 1024u + (tid & 63u);
+		L.stage[i * kWL1Threads + tid] = ull2{key.hi, w};
+		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+		// roll to the next position
+		c.fwd.hi = ((c.fwd.hi << 2) | (c.fwd.lo >> 62)) & K.mask_hi;
+		c.fwd.lo = ((c.fwd.lo << 2) | right) & K.mask_lo;
+		c.rc.lo = (c.rc.lo >> 2) | (c.rc.hi << 62);
+		c.rc.hi >>= 2;
+		const uint64_t comp = (uint64_t)(3u - right);
+		if (K.top >= 64u) c.rc.hi |= comp << (K.top - 64u); else c.rc.lo |= comp << K.top;
+	}
+	// windows without a left / right neighbour: that side's code becomes 4 = none; keys with lo == 0 go through the
+	// atomic path with their final codes (their parked record sits in a dummy bin and is never copied out)
+	const uint32_t no_l = ~c.has_l & 0xFFu, no_r = ~c.has_r & 0xFFu, v8 = c.valid & 0xFFu;
+	for (uint32_t fix = ((no_l | no_r) & v8) | zero_lo; fix; fix &= fix - 1u) {
+		const uint32_t i = (uint32_t)__builtin_ctz(fix);
+		const bool fwd_strand = !((rev_mask >> i) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+		ull2 rec = L.stage[i * kWL1Threads + tid];
+		uint32_t lb = ((uint32_t)rec.y >> 3) & 7u, rbb = (uint32_t)rec.y & 7u;
+		if (fwd_strand ? nl : nr) lb = 4u;
+		if (fwd_strand ? nr : nl) rbb = 4u;
+		rec.y = (rec.y & ~63ull) | (lb << 3) | rbb;
+		if ((zero_lo >> i) & 1u) {
+			wide_insert(T, Key128{rec.x, 0ull}, lb, rbb, ctr, n_new, n_conf, full);
+		} else {
+			L.stage[i * kWL1Threads + tid] = rec;
 		}
 	}
+	c.lw <<= 16;
+	c.nb <<= 16;
+	c.valid >>= 8;
+	c.has_l >>= 8;
+	c.has_r >>= 8;
+	lds_barrier(); // histogram complete, parked records visible
+	ull2 rec[8];
+#pragma unroll
+	for (uint32_t i = 0; i < 8u; i++) rec[i] = L.stage[i * kWL1Threads + fresh_tid()];
+	uint32_t my_gbase[1];
+	scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
+#pragma unroll
+	for (uint32_t i = 0; i < 8u; i++)
+		if ((bkt[i] >> 16) < 1024u) {
+			const uint32_t at = L.lbase[bkt[i] >> 16] + (bkt[i] & 0xFFFFu);
+			L.stage[at] = rec[i];
+			L.bucket_of[at] = (uint16_t)(bkt[i] >> 16);
+		}
+	L.desc[fresh_tid()] = my_gbase[0];
+	lds_barrier();
+	// copy-out: the sorted stage is walked linearly, one 16-byte record per lane and every lane busy -- with several
+	// hundred level-1 buckets a tile holds only a handful of records per bucket, and the memory pipe charges a store
+	// instruction the same whatever its lane count (dbgk_partition.h)
+	{
+		const uint32_t t = fresh_tid();
+		const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u];
+#pragma unroll
+		for (uint32_t u = 0; u < 8u; u++) {
+			const uint32_t p = u * kWL1Threads + t;
+			if (p >= total) continue;
+			const ull2 rcd = L.stage[p];
+			const uint32_t b = L.bucket_of[p];
+			const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
+			if (off < G.cap1) {
+				P.l1[(uint64_t)b * G.cap1 + off] = rcd;
+			} else { // the bucket is full
+				wide_push_overflow(P, wide_record_key(rcd, b, G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
+			}
+		}
+	}
+	lds_barrier(); // the next tile parks its records in the stage buffer again
+}
+
+__device__ __forceinline__ WideL1Consts wide_l1_consts(uint32_t k, const WPartGeom &G)
+{
+	WideL1Consts K;
+	K.rmask = (1u << G.r) - 1u;
+	K.top = 2u * k - 2u; // bit position of a window's first base
+	K.mask_hi = k > 32u ? ((1ull << (2u * k - 64u)) - 1ull) : 0ull;
+	K.mask_lo = k >= 32u ? ~0ull : ((1ull << (2u * k)) - 1ull);
+	return K;
+}
+
+__device__ __forceinline__ void wide_l1_finish(unsigned long long n_new, unsigned long long n_conf, bool full, Counters *ctr)
+{
 	__shared__ unsigned long long red[kWL1Threads / 64];
 	const unsigned long long a = block_sum_n<kWL1Threads>(n_new, red);
 	const unsigned long long b = block_sum_n<kWL1Threads>(n_conf, red);
@@ -327,6 +330,121 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, W
 		if (b) atomicAdd(&ctr->n_conflict, b);
 	}
 	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// the general form: lanes own flat base positions, 16 each, as two tiles
+template <bool HAS_DEAD, int WIDE_D>
+__global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1(ReadBatch rb, WPartGeom G, WPartStore P, WTable T, Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	WL1Lds &L = *reinterpret_cast<WL1Lds *>(lds_raw);
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const WideL1Consts K = wide_l1_consts((uint32_t)rb.k, G);
+	for (uint64_t c0 = (uint64_t)blockIdx.x * kWL1Threads; c0 < n_chunks; c0 += (uint64_t)gridDim.x * kWL1Threads) {
+		WChunk16 c = wide_decode_chunk16<HAS_DEAD>(rb, c0 + fresh_tid(), n_chunks);
+#pragma unroll 1
+		for (uint32_t half = 0; half < 2u; half++) {
+			const uint32_t tid = fresh_tid();
+			L.hist[tid] = 0u; // kBpt == 1
+			if (tid < 64u) L.hist[1024u + tid] = 0u;
+			lds_barrier();
+			wide_l1_tile<WIDE_D>(L, G, P, T, ctr, c, K, n_new, n_conf, full);
+		}
+	}
+	wide_l1_finish(n_new, n_conf, full, ctr);
+}
+
+// Batches of EQUAL-LENGTH reads (no read longer than maxReadLen): lanes are mapped to chunks of 8 VALID windows -- read
+// lane / Q, chunk lane % Q, Q = ceil(W / 8), W = L - k + 1 -- instead of flat base positions, so no position a lane
+// hashes straddles a read boundary (62 of 150 do at k = 63) and no boundary bitmap is needed.  As in
+// k_extract_scatter_uniform the tile's byte range is packed cooperatively into LDS (it borrows the bucket-tag array,
+// which is only used from the staging on) and every lane funnels its 80 bases out of seven packed words.
+struct WUniformGeom {
+	uint32_t L;          // length of every read of the batch, k <= L <= maxReadLen
+	uint32_t W;          // windows of a read = L - k + 1
+	uint32_t Q;          // lanes per read = ceil(W / 8)
+	uint32_t qmagic;     // ceil(2^22 / Q): (x * qmagic) >> 22 == x / Q for x < 2048 + Q
+	uint64_t n_lanes;    // n_reads * Q
+};
+constexpr uint32_t kWPkWords = kWL1Threads * 8 * 2 / 4; // the bucket-tag array seen as 32-bit words (4096)
+
+template <int WIDE_D>
+__global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBatch rb, WUniformGeom U, WPartGeom G, WPartStore P, WTable T,
+                                                                        Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	WL1Lds &L = *reinterpret_cast<WL1Lds *>(lds_raw);
+	uint32_t *pk = reinterpret_cast<uint32_t *>(L.bucket_of);
+	unsigned long long n_new = 0, n_conf = 0;
+	bool full = false;
+	const uint32_t k = (uint32_t)rb.k;
+	const WideL1Consts K = wide_l1_consts(k, G);
+	const uint64_t n_tiles = (U.n_lanes + kWL1Threads - 1) / kWL1Threads;
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		const uint64_t lane0 = tile * kWL1Threads;
+		const uint64_t r0 = lane0 / U.Q;
+		const uint32_t c0 = (uint32_t)(lane0 - r0 * U.Q);
+		// the tile's byte range: from one base before its first lane's first window to the end of its last lane's windows
+		const uint64_t p_first = r0 * U.L + 8u * c0;
+		const uint64_t B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
+		const uint64_t lane_last = min(lane0 + kWL1Threads, U.n_lanes) - 1u;
+		const uint32_t xl = c0 + (uint32_t)(lane_last - lane0);
+		const uint32_t drl = (xl * U.qmagic) >> 22;
+		uint64_t end = (r0 + drl) * U.L + 8u * (xl - drl * U.Q) + 8u + k + 2u;
+		end = min(end, (rb.n_bases + 15u) & ~15ull);
+		const uint32_t n_blocks = end > B0 ? min((uint32_t)((end - B0 + 15u) >> 4), kWPkWords - 8u) : 0u;
+		for (uint32_t b = tid; b < n_blocks + 8u; b += kWL1Threads) // (+ 8 words of 'A' padding: a lane reads seven words from its first)
+			pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + b)) : 0u;
+		L.hist[tid] = 0u;
+		if (tid < 64u) L.hist[1024u + tid] = 0u;
+		lds_barrier();
+		WChunk16 c;
+		{
+			const uint32_t x = c0 + tid;
+			const uint32_t dr = (x * U.qmagic) >> 22;
+			const uint32_t cc = x - dr * U.Q;
+			const uint32_t first_w = 8u * cc;   // index of the lane's first window inside its read
+			const bool live = lane0 + tid < U.n_lanes && first_w < U.W;
+			const uint64_t p = (r0 + dr) * U.L + first_w; // flat position of the lane's first window
+			const uint64_t s0 = p ? p - 1u : 0u;           // the packed stream starts one base earlier (left neighbour)
+			const uint32_t rel = live ? (uint32_t)(s0 - B0) : 0u;
+			const uint32_t d = rel >> 4, sh = 2u * (rel & 15u);
+			const uint32_t x0 = pk[d], x1 = pk[d + 1], x2 = pk[d + 2], x3 = pk[d + 3], x4 = pk[d + 4], x5 = pk[d + 5], x6 = pk[d + 6];
+			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh),
+			               X4 = funnel_left(x4, x5, sh), X5 = funnel_left(x5, x6, sh);
+			// stream Y starts at position p (X starts at p - 1 unless p == 0)
+			const uint32_t adv = p ? 2u : 0u;
+			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = funnel_left(X3, X4, adv),
+			               Y4 = funnel_left(X4, X5, adv);
+			c.lw = p ? X0 : (X0 >> 2); // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
+			const uint64_t A = ((uint64_t)Y0 << 32) | Y1, B = ((uint64_t)Y2 << 32) | Y3, C = (uint64_t)Y4 << 32;
+			if (2u * k <= 64u) {
+				c.fwd.hi = 0ull;
+				c.fwd.lo = A >> (64u - 2u * k);
+			} else {
+				const uint32_t s2 = 128u - 2u * k; // 2..62
+				c.fwd.hi = A >> s2;
+				c.fwd.lo = (B >> s2) | (A << (64u - s2));
+			}
+			c.rc = dbgk_wide::revcomp(c.fwd, (int)k);
+			{
+				const uint32_t off = 2u * k; // 2..126
+				const uint64_t top = (uint64_t)(((((u128)A << 64) | B) << off) >> 64);
+				const uint64_t tail = off > 64u ? (C >> (128u - off)) : 0ull;
+				c.nb = (uint32_t)((top | tail) >> 32);
+			}
+			const uint32_t nv = live ? min(8u, U.W - first_w) : 0u;
+			const uint32_t nr = (live && first_w + 1u < U.W) ? min(8u, U.W - 1u - first_w) : 0u;
+			c.valid = (1u << nv) - 1u;
+			c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
+			c.has_l = cc ? 0xFFu : 0xFEu;       // its first window no left one
+		}
+		wide_l1_tile<WIDE_D>(L, G, P, T, ctr, c, K, n_new, n_conf, full);
+	}
+	wide_l1_finish(n_new, n_conf, full, ctr);
 }
 
 // ---- level 2 --------------------------------------------------------------------------------------

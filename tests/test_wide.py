@@ -364,3 +364,39 @@ def test_wide_records_path_cfg5_shaped_sample_PARITY_UNPINNED(capi, oracle):
         assert np.array_equal(g.wide_export_sorted(), want)
         d_bases.free()
         d_off.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L", [(63, 150), (63, 64), (63, 63), (47, 100), (33, 250), (32, 150), (17, 150), (5, 36)])
+def test_wide_records_path_equal_length_reads_PARITY_UNPINNED_above_k32(capi, oracle, k, L):
+    """batches of equal-length reads take k_wide_scatter_l1_uniform (lanes mapped to chunks of 8 valid windows, bases
+    funnelled out of an LDS-packed byte range) unless k is so small against L that the flat kernel wastes nothing"""
+    rng = random.Random(k * 1000 + L)
+    G = 20000
+    g = "".join(rng.choice("ACGT") for _ in range(G))
+    reads = []
+    for _ in range(3000):
+        s = rng.randint(0, G - L)
+        r = list(g[s:s + L])
+        if rng.random() < 0.5:
+            r = [COMP[c] for c in reversed(r)]
+        for j in range(L):
+            x = rng.random()
+            if x < 0.01:
+                r[j] = rng.choice("ACGTNn")
+            elif x < 0.02:
+                r[j] = r[j].lower()
+        reads.append("".join(r).encode())
+    reads += [b"A" * L] * 50 + [b"T" * L] * 20 + [(b"C" + b"A" * 200)[:L]] * 7 + [(b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 8)[:L]] * 300
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    want, total = oracle.wide_build(bases, offsets, k, 250)
+    size = capi.find_next_prime_ref((1 << 26) + 777)
+    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=len(bases), max_batch_bases=200000) as g:
+        for a in range(0, len(reads), 1000):   # several batches, each of equal-length reads
+            b = min(a + 1000, len(reads))
+            g.push_reads(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a])
+        st = g.finalize()
+        assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (len(reads), total, len(want))
+        assert np.array_equal(g.wide_export_sorted(), want)
+        assert g.digest() == oracle.wide_digest(want)
