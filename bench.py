@@ -133,7 +133,7 @@ def cpu_baseline(args, genome_len):
     visible = len(os.sched_getaffinity(0))
     cores = min(visible, args.cpu_threads)
     n = args.cpu_sample_reads
-    P = O.synth_params(genome_len, 150, cfg=CONFIGS[args.config]["synth_cfg"])
+    P = O.synth_params(genome_len, 150, sub_rate=CONFIGS[args.config].get("sub_rate", 0.005), cfg=CONFIGS[args.config]["synth_cfg"])
     init = max(2.2 * n * (150 - args.kmer + 1) / 1e9 * 0.75, 0.001)  # distinct <= kmers; load <= ~0.6
     host = "%s, %d logical CPUs on the box, %d visible to this process" % (cpu_model(), os.cpu_count() or 0, visible)
     sample = "first %d reads of the N=1 workload (%d k-mers), -i %.3f -b 10000" % (n, n * (150 - args.kmer + 1), init)
@@ -146,6 +146,17 @@ def cpu_baseline(args, genome_len):
         return {"value": res.total_kmers / dt / 1e6, "unit": "M k-mers/s", "cores": threads, "kind": "port", "host": host,
                 "sample": sample + ", -t %d, reads pre-loaded in memory (no file parsing), wall %.2f s" % (threads, dt)}
 
+    if args.kmer > 32:
+        # the reference stops at k = 31: the CPU figure next to the WIDE engine is this build's own single-threaded
+        # restatement of the 128-bit rules (oracle/wide_oracle.cpp; PARITY UNPINNED), reads pre-loaded in memory
+        n_w = min(n, 200000)
+        bases, offsets = O.synth_reads(P, 0, n_w)
+        t0 = time.perf_counter()
+        nodes, total = O.wide_build(bases, offsets, args.kmer, 250)
+        dt = time.perf_counter() - t0
+        return {"value": n_w * (150 - args.kmer + 1) / dt / 1e6, "unit": "M k-mers/s", "cores": 1, "kind": "port", "host": host,
+                "sample": "first %d reads of the N=1 workload (%d k-mers), 128-bit restatement, one thread, reads pre-loaded in memory, wall %.2f s"
+                          % (n_w, n_w * (150 - args.kmer + 1), dt)}, []
     if not O.have_ref():
         return port(cores), []
     out = []
