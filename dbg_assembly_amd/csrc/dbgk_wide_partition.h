@@ -382,22 +382,48 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 	const uint32_t k = (uint32_t)rb.k;
 	const WideL1Consts K = wide_l1_consts(k, G);
 	const uint64_t n_tiles = (U.n_lanes + kWL1Threads - 1) / kWL1Threads;
+	// a tile's byte range: from one base before its first lane's first window to the end of its last lane's windows
+	struct Range {
+		uint64_t r0, B0;
+		uint32_t c0, n_blocks;
+	};
+	auto range_of = [&](uint64_t tile) {
+		Range R{0, 0, 0, 0};
+		if (tile >= n_tiles) return R;
+		const uint64_t lane0 = tile * kWL1Threads;
+		R.r0 = lane0 / U.Q;
+		R.c0 = (uint32_t)(lane0 - R.r0 * U.Q);
+		const uint64_t p_first = R.r0 * U.L + 8u * R.c0;
+		R.B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
+		const uint64_t lane_last = min(lane0 + kWL1Threads, U.n_lanes) - 1u;
+		const uint32_t xl = R.c0 + (uint32_t)(lane_last - lane0);
+		const uint32_t drl = (xl * U.qmagic) >> 22;
+		uint64_t end = (R.r0 + drl) * U.L + 8u * (xl - drl * U.Q) + 8u + k + 2u;
+		end = min(end, (rb.n_bases + 15u) & ~15ull);
+		R.n_blocks = end > R.B0 ? min((uint32_t)((end - R.B0 + 15u) >> 4), kWPkWords - 8u) : 0u;
+		return R;
+	};
+	// the first two 16-byte blocks of a lane (block tid, block tid + 1024) are requested one tile ahead
+	auto fetch = [&](const Range &R, uint4 &a, uint4 &b) {
+		const uint32_t t = fresh_tid();
+		a = b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+		if (t < R.n_blocks) a = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t);
+		if (t + kWL1Threads < R.n_blocks) b = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t + kWL1Threads);
+	};
+	Range R = range_of(blockIdx.x);
+	uint4 ra, rb2;
+	fetch(R, ra, rb2);
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t tid = fresh_tid();
 		const uint64_t lane0 = tile * kWL1Threads;
-		const uint64_t r0 = lane0 / U.Q;
-		const uint32_t c0 = (uint32_t)(lane0 - r0 * U.Q);
-		// the tile's byte range: from one base before its first lane's first window to the end of its last lane's windows
-		const uint64_t p_first = r0 * U.L + 8u * c0;
-		const uint64_t B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
-		const uint64_t lane_last = min(lane0 + kWL1Threads, U.n_lanes) - 1u;
-		const uint32_t xl = c0 + (uint32_t)(lane_last - lane0);
-		const uint32_t drl = (xl * U.qmagic) >> 22;
-		uint64_t end = (r0 + drl) * U.L + 8u * (xl - drl * U.Q) + 8u + k + 2u;
-		end = min(end, (rb.n_bases + 15u) & ~15ull);
-		const uint32_t n_blocks = end > B0 ? min((uint32_t)((end - B0 + 15u) >> 4), kWPkWords - 8u) : 0u;
-		for (uint32_t b = tid; b < n_blocks + 8u; b += kWL1Threads) // (+ 8 words of 'A' padding: a lane reads seven words from its first)
+		const uint64_t r0 = R.r0, B0 = R.B0;
+		const uint32_t c0 = R.c0, n_blocks = R.n_blocks;
+		if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? pack16_ascii(ra) : 0u; // (+ 8 words of 'A' padding: a lane reads seven words from its first)
+		if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? pack16_ascii(rb2) : 0u;
+		for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
 			pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + b)) : 0u;
+		R = range_of(tile + gridDim.x);
+		fetch(R, ra, rb2); // in flight during this tile
 		L.hist[tid] = 0u;
 		if (tid < 64u) L.hist[1024u + tid] = 0u;
 		lds_barrier();
