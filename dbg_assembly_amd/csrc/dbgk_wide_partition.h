@@ -10,11 +10,12 @@
 //   Keys whose low word is 0 never become records: the device table marks an empty slot with lo == 0
 //   (dbgk_wide_kernels.h), so they go to the side table / the key-0 side node through the atomic path right away.
 //
-//   k_wide_scatter_l1     reads -> records, scattered into n1 <= 1024 level-1 buckets (slot >> r); 8192-record tiles
+//   k_wide_scatter_l1[_uniform]  reads -> records, scattered into n1 <= 1024 level-1 buckets (slot >> r); 8192-record
+//                         tiles; the _uniform form for batches of equal-length reads (no position straddles a read)
 //   k_wide_l2_plan        tiles per level-1 bucket
-//   k_wide_scatter_l2     every level-1 bucket -> n2 = 2^(r-11) final buckets (slot >> 11); XCD-aware tile order
-//   k_wide_build_regions  one 2048-slot region at a time in LDS, emitted as 64 KiB of device nodes
-//   afterwards            region spill-over nodes through k_wide_merge_nodes, bucket-overflow observations through
+//   k_wide_scatter_l2     a chunk of level-1 buckets -> n2 = 2^(r-11) final buckets each (slot >> 11); XCD-aware tile order
+//   k_wide_build_regions  the regions of that chunk, one 2048-slot region at a time in LDS, emitted as 64 KiB of device nodes
+//   afterwards            region spill-over nodes through k_wide_merge_spill, bucket-overflow observations through
 //                         k_wide_insert_obs (both global atomics, normally a handful)
 // Once the table has been built the handle continues with the atomic kernels (k_wide_extract_insert) for anything
 // pushed later: the built table IS a valid table of that engine.
@@ -29,7 +30,6 @@ constexpr int kWRegionBits = 11;                 // 2048 slots = 64 KiB of 32-by
 constexpr int kWRegionSlots = 1 << kWRegionBits;
 constexpr int kWSpillSlots = 128;
 constexpr int kWL1Threads = 1024;                // level 1: 8 positions per lane and tile, 8192 records of 16 bytes
-constexpr int kWL1Records = kWL1Threads * 8;
 constexpr int kWL2Threads = 512;                 // level 2: 4096-record tiles
 constexpr int kWL2Records = kWL2Threads * 8;
 constexpr int kWBuildThreads = 512;              // three workgroups per CU (51 KiB of LDS each)
