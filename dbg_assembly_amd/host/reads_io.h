@@ -36,7 +36,7 @@ bool for_each_read_in_file(const std::string &path, int format, Callback cb, con
 		size_t pos = 0;
 		while (pos < end && !(stop && *stop)) {
 			const size_t span = end - pos;
-			if (span > buf.size()) break; // (never: pos < end <= buf.size(); tells the optimiser the bound of the scan)
+			if (span > ((size_t)1 << 40)) break; // (never: pos < end <= buf.size(); tells the optimiser the bound of the scan)
 			const char *nl = static_cast<const char *>(memchr(buf.data() + pos, '\n', span));
 			size_t line_end;
 			if (nl) line_end = (size_t)(nl - buf.data());
