@@ -391,6 +391,12 @@ def main():
         }
         if world == 1:
             out["copy_bandwidth_GBs"] = copy_bw
+            try:   # the practical random-access ceiling, next to the streaming one
+                gb, ga = g.gather_bandwidth(16 << 30, 1 << 29)
+                out["random_gather_64B"] = {"GBs": gb, "G_sectors_per_s": ga, "buffer_bytes": 16 << 30,
+                                            "note": "random 64-byte sectors of a 16 GiB buffer, four lanes per sector"}
+            except Exception as e:  # noqa: BLE001
+                print("random gather probe failed: %s" % e, file=sys.stderr)
             if not args.no_cpu_baseline:   # (k > 32: the 128-bit restatement, the reference has no such path)
                 out["cpu_baseline"], out["cpu_baseline_variants"] = cpu_baseline(args, genome_len)
         result_out.write(json.dumps(out) + "\n")

@@ -141,6 +141,7 @@ SYMBOLS = [
     ("dbgk_reset_timings", _i, [_vp]),
     ("dbgk_stream", _vp, [_vp]),
     ("dbgk_measure_copy_bandwidth", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    ("dbgk_measure_gather_bandwidth", _i, [_vp, C.c_size_t, _u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dbgk_device_count", _i, []),
     ("dbgk_abi_version", _i, []),
     ("dbgk_strerror", C.c_char_p, [_i]),
@@ -457,6 +458,12 @@ class Graph:
         g = C.c_double()
         _chk(lib().dbgk_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "dbgk_measure_copy_bandwidth")
         return g.value
+
+    def gather_bandwidth(self, nbytes=16 << 30, n_accesses=1 << 30):
+        """random 64-byte sectors of an nbytes buffer: (GB/s, G sectors/s)"""
+        g, a = C.c_double(), C.c_double()
+        _chk(lib().dbgk_measure_gather_bandwidth(self._h, nbytes, n_accesses, C.byref(g), C.byref(a)), "dbgk_measure_gather_bandwidth")
+        return g.value, a.value
 
 
 class Comm:

@@ -2593,6 +2593,74 @@ extern "C" int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int ite
 	return DBGK_OK;
 }
 
+// Random 64-byte gather (the practical ceiling of the engines that touch one random node per k-mer
+// occurrence, DIRECT / WIDE-atomic / SEEDIDX).  Four lanes fetch one 64-byte sector each (16 bytes per lane) at a
+// pseudo-random sector of a buffer far larger than the caches; every lane group runs its own xorshift stream.
+__global__ __launch_bounds__(kBlock) void k_random_gather64(const uint4 *__restrict__ buf, uint64_t n_sectors, uint32_t per_group,
+                                                            unsigned long long *__restrict__ sink)
+{
+	const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	const uint64_t group = tid >> 2;
+	const uint32_t part = (uint32_t)tid & 3u;
+	uint64_t x = (group + 1u) * 0x9E3779B97F4A7C15ull;
+	uint32_t acc = 0;
+	for (uint32_t i = 0; i < per_group; i++) {
+		x ^= x << 13;
+		x ^= x >> 7;
+		x ^= x << 17;
+		const uint64_t sector = (uint64_t)(((unsigned __int128)x * n_sectors) >> 64);
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(buf) + sector * 4u + part);
+		acc ^= v.x ^ v.y ^ v.z ^ v.w;
+	}
+	if (acc == 0x12345677u) atomicAdd(sink, 1ull); // keeps the loads alive
+}
+
+extern "C" int dbgk_measure_gather_bandwidth(dbgk_handle *h, size_t bytes, uint64_t n_accesses, double *gbps, double *gaccesses_per_s)
+{
+	if (!h || !gbps || bytes < (1u << 20) || n_accesses < 1024) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	void *a = nullptr;
+	unsigned long long *sink = nullptr;
+	if (hipMalloc(&a, bytes) != hipSuccess) return DBGK_ERR_NOMEM;
+	if (hipMalloc(&sink, 8) != hipSuccess) {
+		(void)hipFree(a);
+		return DBGK_ERR_NOMEM;
+	}
+	const uint32_t per_group = 64;
+	const uint64_t groups = (n_accesses + per_group - 1) / per_group;
+	const uint64_t blocks = (groups * 4 + kBlock - 1) / kBlock;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(sink, 0, 8, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_random_gather64, dim3((unsigned)std::min<uint64_t>(blocks, 1u << 20)), dim3(kBlock), 0, h->stream, (const uint4 *)a, (uint64_t)(bytes >> 6), 4u,
+		                   sink); // warm-up (page tables)
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipEventRecord(e0, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_random_gather64, dim3((unsigned)blocks), dim3(kBlock), 0, h->stream, (const uint4 *)a, (uint64_t)(bytes >> 6), per_group, sink);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	float ms = 0.f;
+	if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+	(void)hipFree(a);
+	(void)hipFree(sink);
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (e != hipSuccess) return hip_fail(e, "measure_gather_bandwidth", __LINE__);
+	const double done = (double)(blocks * (kBlock / 4)) * per_group;
+	*gbps = done * 64.0 / (ms * 1e-3) / 1e9;
+	if (gaccesses_per_s) *gaccesses_per_s = done / (ms * 1e-3) / 1e9;
+	return DBGK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // several GPUs in one process
 // ---------------------------------------------------------------------------------------------

@@ -405,6 +405,9 @@ void *dbgk_stream(dbgk_handle *h);
 
 /* device-to-device copy bandwidth probe (GB/s) used as the measured-HBM denominator             */
 int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int iters, double *gbps);
+/* random 64-byte gather over a buffer of `bytes` (the practical random-access ceiling of the engines
+ * that touch one random node per k-mer occurrence): n_accesses sectors fetched, GB/s and G sectors/s             */
+int dbgk_measure_gather_bandwidth(dbgk_handle *h, size_t bytes, uint64_t n_accesses, double *gbps, double *gaccesses_per_s);
 
 int dbgk_device_count(void);
 int dbgk_abi_version(void);
