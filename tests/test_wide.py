@@ -400,3 +400,28 @@ def test_wide_records_path_equal_length_reads_PARITY_UNPINNED_above_k32(capi, or
         assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (len(reads), total, len(want))
         assert np.array_equal(g.wide_export_sorted(), want)
         assert g.digest() == oracle.wide_digest(want)
+
+
+@pytest.mark.gpu
+def test_wide_full_size_cfg5_share_records_equal_atomics_PARITY_UNPINNED(capi):
+    """BASELINE cfg5 at the size bench.py runs it (one GPU's eighth: 75 M x 150 bp, k = 63, 6.6 G k-mers, 1.6 G slots):
+    no CPU restatement can follow here, so the check is that the two forms of the engine -- fused atomics and
+    partitioned records, each equal to the restatement at small sizes -- arrive at the same node multiset (count,
+    order-independent digest, link-depth histogram), and that the record path repeats it on a reused handle"""
+    n_reads, G, slots = 75_000_000, 375_000_000, 1_600_000_000
+    P = capi.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    size = capi.find_next_prime_ref(slots)
+    got = {}
+    for name, expected in (("atomic", 0), ("records", n_reads * 88)):
+        with capi.Graph(k=63, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=expected) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            for rep in range(2 if name == "records" else 1):
+                g.reset()
+                g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+                st = g.finalize()
+                res = (int(st.count), int(st.stored_kmers), int(st.total_kmers), g.digest(), [int(x) for x in g.link_stats(2).depth_stat])
+                assert got.setdefault(name, res) == res
+            d_bases.free()
+            d_off.free()
+    assert got["atomic"][1] == n_reads * 88
+    assert got["atomic"] == got["records"]
