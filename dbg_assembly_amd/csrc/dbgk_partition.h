@@ -523,8 +523,8 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // is 0 (poly-A / poly-T): rare, the caller then feeds the key-0 side node.
 // WIDE_D: how hash / size is computed -- 0: size < 2^31 (one multiply-high with a 32-bit remainder fix-up), 1: size < 2^32
 // (two 2-by-1 division steps), 2: any size (64-bit multiply-high by floor(2^64 / size), 64-bit remainder)
-template <int WIDE_D, int NPOS = 16>
-__device__ __forceinline__ bool l1_positions(ScatterLds &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
+template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds>
+__device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
 {
 	// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
@@ -602,6 +602,71 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
 	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 	scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+}
+
+// LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
+// of the GLOBAL table).  With several hundred buckets a 16 K-record tile holds only a few dozen records per bucket and
+// the wave-per-bucket copy-out above issues one mostly empty store per bucket (level 1 at n1 = 1023: 10.6 ms against 5.5
+// at n1 = 143).  Here a tile is 8 records per thread, every staged record carries a 16-bit bucket tag, and the copy-out
+// walks the sorted stage linearly, every lane busy -- its cost no longer depends on the number of buckets.
+struct ScatterLds8 {
+	static constexpr int kThreads = kL1Threads;
+	static constexpr int kRecords = kL1Threads * 8;
+	static constexpr int kMaxB = kL1MaxB;
+	static constexpr int kBpt = kL1MaxB / kL1Threads;
+	using Desc = uint32_t;
+	uint64_t stage[kRecords];
+	uint32_t hist[kL1MaxB + 64];
+	uint32_t lbase[kL1MaxB];
+	uint32_t desc[kL1MaxB];
+	uint32_t wave_tot[kL1Threads / 64];
+	uint16_t bucket_of[kRecords];
+};
+
+template <int DBG>
+__device__ __forceinline__ void l1_scatter_tail_linear(ScatterLds8 &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
+                                                       const uint32_t (&bkt)[16])
+{
+	lds_barrier(); // hist complete
+	uint64_t rec[8];
+#pragma unroll
+	for (int u = 0; u < 8; u++) rec[u] = L.stage[u * kL1Threads + tid];
+	uint32_t my_gbase[ScatterLds8::kBpt];
+	const uint32_t sub = blockIdx.x % G.n_sub;
+	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
+	const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u]; // (read now: the next tile zeroes the histogram while slower waves still copy out)
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t b = bkt[u] >> 16;
+		if (b < (uint32_t)kL1MaxB) {
+			const uint32_t at = L.lbase[b] + (bkt[u] & 0xFFFFu);
+			L.stage[at] = rec[u];
+			L.bucket_of[at] = (uint16_t)b;
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < ScatterLds8::kBpt; j++) L.desc[ScatterLds8::kBpt * tid + j] = my_gbase[j];
+	lds_barrier();
+	if (DBG != 2) {
+		uint64_t *out = P.l1 + (uint64_t)sub * G.cap1; // bucket b lives at out + b * n_sub * cap1
+		// (two neighbouring records per lane and 16-byte stores where both fall into one bucket were measured slower: with
+		// many buckets most pairs straddle a boundary -- 8.5 against 7.75 ms at n1 = 1023, 6.80 against 6.65 at n1 = 143)
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			const uint32_t p = (uint32_t)u * kL1Threads + fresh_tid();
+			if (p >= total) continue;
+			const uint64_t rcd = L.stage[p];
+			const uint32_t b = L.bucket_of[p];
+			const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
+			if (off < G.cap1) {
+				out[(uint64_t)b * G.n_sub * G.cap1 + off] = rcd;
+			} else { // the bucket is full: records beyond its capacity go to the overflow list
+				push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+			}
+		}
+	}
+	// (no barrier here, as above: the next tile meets its first barrier before any record is parked in the stage buffer again,
+	// and lbase / desc / bucket_of are only rewritten after its scan)
 }
 
 template <bool HAS_DEAD, int DBG = 0, int WIDE_D = 0>
@@ -686,6 +751,10 @@ struct UniformLds {
 	ScatterLds s;
 	uint32_t pk[kPkWords];
 };
+struct UniformLds8 {
+	ScatterLds8 s;
+	uint32_t pk[kPkWords];
+};
 
 __device__ __forceinline__ uint32_t funnel_left(uint32_t hi, uint32_t lo, uint32_t sh) // ({hi,lo} << sh) >> 32, sh in 0..30 (even)
 {
@@ -715,13 +784,17 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // longest read of the batch, L holds its length), a read's own offset and length come from `offsets`, and
 // the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
 // length -- the host compares n_reads * Q * C lane slots with the n_bases positions of the flat kernel.
-template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false>
+// LIN: the linear form (C = 8 windows per lane, ScatterLds8, l1_scatter_tail_linear) for many level-1 buckets
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
+	static_assert(!LIN || C == 8, "the linear form stages 8 records per thread");
+	using ULds = typename std::conditional<LIN, UniformLds8, UniformLds>::type;
+	using SLds = typename std::conditional<LIN, ScatterLds8, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	UniformLds &UL = *reinterpret_cast<UniformLds *>(lds_raw);
-	ScatterLds &L = UL.s;
+	ULds &UL = *reinterpret_cast<ULds *>(lds_raw);
+	SLds &L = UL.s;
 	const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 	const uint32_t k = (uint32_t)rb.k;
 	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;
@@ -788,7 +861,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
 		uint32_t bkt[16];
 #pragma unroll
-		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[ScatterLds::kBpt * tid + j] = 0;
+		for (int j = 0; j < SLds::kBpt; j++) L.hist[SLds::kBpt * tid + j] = 0;
 		lds_barrier();
 		const uint64_t p = raw.p;                        // flat position of the lane's first window
 		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
@@ -815,7 +888,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
 			c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
 		}
-		const bool zero_seen = l1_positions<WIDE_D, C>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		const bool zero_seen = l1_positions<WIDE_D, C, SLds>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile
 		r0 += stride_r;
@@ -831,7 +904,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			continue;
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
-		l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
+		if constexpr (LIN) l1_scatter_tail_linear<DBG>(L, G, P, ctr, tid, bkt);
+		else l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
 		raw = nxt;
 	}
 }
