@@ -977,7 +977,7 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 		// Many level-1 buckets (big tables; every rank of a multi-GPU job partitions by the GLOBAL table's buckets): the linear
 		// form, 8 windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear: n1 = 143: 5.50 / 6.65,
 		// 257 (cfg3 share): 16.9 / 17.6, 287: 6.34 / 6.77, 573: 8.08 / 7.50, 1023: 10.55 / 7.75.  DBGK_L1_LINEAR=0/1 forces the choice.
-		static const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
+		const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1; // (read per batch: tests switch it)
 		const uint64_t Q8 = (W + 7u) / 8u;
 		const bool fits = Q8 < 2048 && n_reads * Q8 < (1ull << 32) && ((uint64_t)kL1Threads / Q8 + 2) * L + 96 <= (uint64_t)kPkWords * 16;
 		if (fits && (force == 1 || (force < 0 && h->geom.n1 > 448u))) {

@@ -484,6 +484,31 @@ def test_full_size_cfg2_bench_workload_equals_the_cpu_oracle(capi):
         assert got == (gold["total_reads"], gold["total_kmers"], gold["total_kmers"], gold["count"], gold["digest"], gold["depth_stat"]), engine
 
 
+@pytest.mark.parametrize("slots,force", [(4_290_000_000, None), (600_000_000, "1"), (4_290_000_000, "0")])
+def test_full_size_cfg2_reads_into_many_level1_buckets(capi, monkeypatch, slots, force):
+    """What every rank of an 8-GPU job runs: cfg2's reads partitioned by the level-1 buckets of a 4.29 G-slot table
+    (n1 = 1023), where the equal-length level-1 kernel takes its LINEAR form (8 windows per lane, bucket tags, linear
+    copy-out).  The node multiset does not depend on the table size: count, digest and DepthStat == the full-size oracle
+    record; the same with the form forced on the bench's own table and forced off on the big one"""
+    import json
+    import os
+    if force is not None:
+        monkeypatch.setenv("DBGK_L1_LINEAR", force)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_full.json")))
+    n_reads = gold["n_reads"]
+    P = capi.synth_params(gold["genome_len"], 150, cfg=2)
+    with capi.Graph(k=gold["k"], table_slots=capi.find_next_prime_ref(slots), max_read_len=250, engine=capi.ENGINE_PARTITION,
+                    expected_kmers=n_reads * 120) as g:
+        d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+        g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        st = g.finalize()
+        assert g.timings().uniform_launches == 1
+        got = (int(st.total_reads), int(st.total_kmers), int(st.count), g.digest(), [int(x) for x in g.link_stats(2).depth_stat])
+        d_bases.free()
+        d_off.free()
+    assert got == (gold["total_reads"], gold["total_kmers"], gold["count"], gold["digest"], gold["depth_stat"])
+
+
 # ------------------------------------------------------------------------------------------------
 # sharded table: N handles on ONE GPU stand in for N ranks; the all-to-all is done with in-process
 # device copies.  Validates slot-range ownership end to end on real hardware.
