@@ -626,9 +626,12 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_UNIFORM_ATTRS(0);
 	DBGK_UNIFORM_ATTRS(1);
 	DBGK_UNIFORM_ATTRS(2);
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 0, 8, false, true>), sizeof(UniformLds8));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 1, 8, false, true>), sizeof(UniformLds8));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 2, 8, false, true>), sizeof(UniformLds8));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 0, 8, false, true>), sizeof(UniformLdsLin<8>));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 1, 8, false, true>), sizeof(UniformLdsLin<8>));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 2, 8, false, true>), sizeof(UniformLdsLin<8>));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 0, 12, false, true>), sizeof(UniformLdsLin<12>));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 1, 12, false, true>), sizeof(UniformLdsLin<12>));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 2, 12, false, true>), sizeof(UniformLdsLin<12>));
 #undef DBGK_UNIFORM_ATTRS
 	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
 	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
@@ -952,9 +955,9 @@ extern "C" int dbgk_resize_table(dbgk_handle *h, uint64_t new_slots)
 // Returns 0 = flat kernel, 1 = equal, 2 = ragged; fills U.
 // lin (out): the linear level-1 form (8 windows per lane, linear copy-out) is to be used -- many level-1 buckets
 static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_max, uint64_t n_reads, uint64_t n_bases, int has_long,
-                        UniformGeom &U, bool &c15, bool &lin)
+                        UniformGeom &U, bool &c15, bool &lin, bool &lin12)
 {
-	lin = false;
+	lin = lin12 = false;
 	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
 	static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
 	if (off || dbg_mode || has_long || n_reads == 0) return 0;
@@ -975,16 +978,21 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	if (uniform_len > 0) {
 		if (n_bases != n_reads * L) return 0;
 		// Many level-1 buckets (big tables; every rank of a multi-GPU job partitions by the GLOBAL table's buckets): the linear
-		// form, 8 windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear: n1 = 143: 5.50 / 6.65,
-		// 257 (cfg3 share): 16.9 / 17.6, 287: 6.34 / 6.77, 573: 8.08 / 7.50, 1023: 10.55 / 7.75.  DBGK_L1_LINEAR=0/1 forces the choice.
+		// form, 12 (or 8) windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear with 8 / with 12
+		// windows: n1 = 143: 5.57 / 6.76 / 6.05, 573: 8.13 / 7.57 / 6.81, 1023: 10.61 / 7.76 / 6.99 (287: 6.34 / 6.77 / -).
+		// DBGK_L1_LINEAR=0/1 forces the choice.
 		const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1; // (read per batch: tests switch it)
-		const uint64_t Q8 = (W + 7u) / 8u;
-		const bool fits = Q8 < 2048 && n_reads * Q8 < (1ull << 32) && ((uint64_t)kL1Threads / Q8 + 2) * L + 96 <= (uint64_t)kPkWords * 16;
-		if (fits && (force == 1 || (force < 0 && h->geom.n1 > 448u))) {
+		// 12 or 8 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: both none -> 12)
+		const uint64_t q12 = (W + 11u) / 12u, q8 = (W + 7u) / 8u;
+		lin12 = q12 * 12u - W <= q8 * 8u - W;
+		if (const char *e = getenv("DBGK_L1_LINEAR_C")) lin12 = atoi(e) == 12; // measurements
+		const uint64_t QL = lin12 ? q12 : q8;
+		const bool fits = QL < 2048 && n_reads * QL < (1ull << 32) && ((uint64_t)kL1Threads / QL + 2) * L + 96 <= (uint64_t)kPkWords * 16;
+		if (fits && (force == 1 || (force < 0 && h->geom.n1 > 320u))) {
 			lin = true;
-			U.Q = (uint32_t)Q8;
+			U.Q = (uint32_t)QL;
 			U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
-			U.n_lanes = n_reads * Q8;
+			U.n_lanes = n_reads * QL;
 		}
 		return 1;
 	}
@@ -1028,7 +1036,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	// (nearly) equal-length reads does without them, so for such a batch only the statistics are taken.  A device
 	// batch tells its shape only after those statistics: the bitmaps follow in a second pass if they are needed.
 	UniformGeom U{};
-	bool c15 = false, lin8 = false;
+	bool c15 = false, lin8 = false, lin12 = false;
 	int umode = -1; // not decided yet
 	auto mark_bits = [&](int with_stats) -> int {
 		HIPCHK(hipMemsetAsync(d_start, 0, words * 4, h->stream));
@@ -1040,7 +1048,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	const bool wrec = h->wide && h->wpart && !h->wbuilt; // WIDE handle that is still collecting records
 	WUniformGeom WU{};
 	auto decide_umode = [&]() {
-		return wrec ? wide_uniform_mode(h, uniform_len, n_reads, n_bases, has_long, WU) : uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15, lin8);
+		return wrec ? wide_uniform_mode(h, uniform_len, n_reads, n_bases, has_long, WU) : uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15, lin8, lin12);
 	};
 	const bool may_skip_bits = (h->part && !h->seed) || wrec;
 	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) umode = decide_umode();
@@ -1132,11 +1140,13 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);          \
 		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
 	} while (0)
-#define DBGK_LAUNCH_UNIFORM8(WIDE)                                                                                                                      \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, 8, false, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds8), h->stream, rb, U, \
+#define DBGK_LAUNCH_UNIFORM8(WIDE, CC)                                                                                                                      \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-		if (lin8) {
-			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1); else DBGK_LAUNCH_UNIFORM8(0);
+		if (lin8 && lin12) {
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12); else DBGK_LAUNCH_UNIFORM8(0, 12);
+		} else if (lin8) {
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8); else DBGK_LAUNCH_UNIFORM8(0, 8);
 		} else if (wide == 2) DBGK_LAUNCH_UNIFORM_W(2);
 		else if (wide == 1) DBGK_LAUNCH_UNIFORM_W(1);
 		else DBGK_LAUNCH_UNIFORM_W(0);

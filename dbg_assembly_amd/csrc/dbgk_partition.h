@@ -607,11 +607,12 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 // LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
 // of the GLOBAL table).  With several hundred buckets a 16 K-record tile holds only a few dozen records per bucket and
 // the wave-per-bucket copy-out above issues one mostly empty store per bucket (level 1 at n1 = 1023: 10.6 ms against 5.5
-// at n1 = 143).  Here a tile is 8 records per thread, every staged record carries a 16-bit bucket tag, and the copy-out
+// at n1 = 143).  Here a tile is 8 or 12 records per thread, every staged record carries a 16-bit bucket tag, and the copy-out
 // walks the sorted stage linearly, every lane busy -- its cost no longer depends on the number of buckets.
-struct ScatterLds8 {
+template <int C> // C = records per thread and tile: 8 or 12
+struct ScatterLdsLin {
 	static constexpr int kThreads = kL1Threads;
-	static constexpr int kRecords = kL1Threads * 8;
+	static constexpr int kRecords = kL1Threads * C;
 	static constexpr int kMaxB = kL1MaxB;
 	static constexpr int kBpt = kL1MaxB / kL1Threads;
 	using Desc = uint32_t;
@@ -623,20 +624,21 @@ struct ScatterLds8 {
 	uint16_t bucket_of[kRecords];
 };
 
-template <int DBG>
-__device__ __forceinline__ void l1_scatter_tail_linear(ScatterLds8 &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
+template <int DBG, int C>
+__device__ __forceinline__ void l1_scatter_tail_linear(ScatterLdsLin<C> &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
                                                        const uint32_t (&bkt)[16])
 {
+	using ScatterLds8 = ScatterLdsLin<C>;
 	lds_barrier(); // hist complete
-	uint64_t rec[8];
+	uint64_t rec[C];
 #pragma unroll
-	for (int u = 0; u < 8; u++) rec[u] = L.stage[u * kL1Threads + tid];
+	for (int u = 0; u < C; u++) rec[u] = L.stage[u * kL1Threads + tid];
 	uint32_t my_gbase[ScatterLds8::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub;
 	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 	const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u]; // (read now: the next tile zeroes the histogram while slower waves still copy out)
 #pragma unroll
-	for (int u = 0; u < 8; u++) {
+	for (int u = 0; u < C; u++) {
 		const uint32_t b = bkt[u] >> 16;
 		if (b < (uint32_t)kL1MaxB) {
 			const uint32_t at = L.lbase[b] + (bkt[u] & 0xFFFFu);
@@ -652,7 +654,7 @@ __device__ __forceinline__ void l1_scatter_tail_linear(ScatterLds8 &L, const Par
 		// (two neighbouring records per lane and 16-byte stores where both fall into one bucket were measured slower: with
 		// many buckets most pairs straddle a boundary -- 8.5 against 7.75 ms at n1 = 1023, 6.80 against 6.65 at n1 = 143)
 #pragma unroll
-		for (int u = 0; u < 8; u++) {
+		for (int u = 0; u < C; u++) {
 			const uint32_t p = (uint32_t)u * kL1Threads + fresh_tid();
 			if (p >= total) continue;
 			const uint64_t rcd = L.stage[p];
@@ -751,8 +753,9 @@ struct UniformLds {
 	ScatterLds s;
 	uint32_t pk[kPkWords];
 };
-struct UniformLds8 {
-	ScatterLds8 s;
+template <int C>
+struct UniformLdsLin {
+	ScatterLdsLin<C> s;
 	uint32_t pk[kPkWords];
 };
 
@@ -784,14 +787,14 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // longest read of the batch, L holds its length), a read's own offset and length come from `offsets`, and
 // the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
 // length -- the host compares n_reads * Q * C lane slots with the n_bases positions of the flat kernel.
-// LIN: the linear form (C = 8 windows per lane, ScatterLds8, l1_scatter_tail_linear) for many level-1 buckets
+// LIN: the linear form (C = 8 or 12 windows per lane, ScatterLdsLin<C>, l1_scatter_tail_linear) for many level-1 buckets
 template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
-	static_assert(!LIN || C == 8, "the linear form stages 8 records per thread");
-	using ULds = typename std::conditional<LIN, UniformLds8, UniformLds>::type;
-	using SLds = typename std::conditional<LIN, ScatterLds8, ScatterLds>::type;
+	static_assert(!LIN || C == 8 || C == 12, "the linear form stages 8 or 12 records per thread");
+	using ULds = typename std::conditional<LIN, UniformLdsLin<LIN ? C : 8>, UniformLds>::type;
+	using SLds = typename std::conditional<LIN, ScatterLdsLin<LIN ? C : 8>, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	ULds &UL = *reinterpret_cast<ULds *>(lds_raw);
 	SLds &L = UL.s;
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			continue;
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
-		if constexpr (LIN) l1_scatter_tail_linear<DBG>(L, G, P, ctr, tid, bkt);
+		if constexpr (LIN) l1_scatter_tail_linear<DBG, C>(L, G, P, ctr, tid, bkt);
 		else l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
 		raw = nxt;
 	}
