@@ -626,12 +626,15 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_UNIFORM_ATTRS(0);
 	DBGK_UNIFORM_ATTRS(1);
 	DBGK_UNIFORM_ATTRS(2);
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 0, 8, false, true>), sizeof(UniformLdsLin<8>));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 1, 8, false, true>), sizeof(UniformLdsLin<8>));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 2, 8, false, true>), sizeof(UniformLdsLin<8>));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 0, 12, false, true>), sizeof(UniformLdsLin<12>));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 1, 12, false, true>), sizeof(UniformLdsLin<12>));
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, 2, 12, false, true>), sizeof(UniformLdsLin<12>));
+#define DBGK_LIN_ATTRS(W)                                                                          \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, false, true>), sizeof(UniformLdsLin<8>));   \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, true, true>), sizeof(UniformLdsLin<8>));    \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, false, true>), sizeof(UniformLdsLin<12>)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, true, true>), sizeof(UniformLdsLin<12>))
+	DBGK_LIN_ATTRS(0);
+	DBGK_LIN_ATTRS(1);
+	DBGK_LIN_ATTRS(2);
+#undef DBGK_LIN_ATTRS
 #undef DBGK_UNIFORM_ATTRS
 	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
 	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
@@ -975,28 +978,29 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	U.Q = (uint32_t)Q;
 	U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
 	U.n_lanes = n_reads * Q;
-	if (uniform_len > 0) {
-		if (n_bases != n_reads * L) return 0;
-		// Many level-1 buckets (big tables; every rank of a multi-GPU job partitions by the GLOBAL table's buckets): the linear
-		// form, 12 (or 8) windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear with 8 / with 12
-		// windows: n1 = 143: 5.57 / 6.76 / 6.05, 573: 8.13 / 7.57 / 6.81, 1023: 10.61 / 7.76 / 6.99 (287: 6.34 / 6.77 / -).
-		// DBGK_L1_LINEAR=0/1 forces the choice.
-		const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1; // (read per batch: tests switch it)
-		// 12 or 8 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: both none -> 12)
-		const uint64_t q12 = (W + 11u) / 12u, q8 = (W + 7u) / 8u;
-		lin12 = q12 * 12u - W <= q8 * 8u - W;
-		if (const char *e = getenv("DBGK_L1_LINEAR_C")) lin12 = atoi(e) == 12; // measurements
-		const uint64_t QL = lin12 ? q12 : q8;
-		const bool fits = QL < 2048 && n_reads * QL < (1ull << 32) && ((uint64_t)kL1Threads / QL + 2) * L + 96 <= (uint64_t)kPkWords * 16;
-		if (fits && (force == 1 || (force < 0 && h->geom.n1 > 320u))) {
-			lin = true;
-			U.Q = (uint32_t)QL;
-			U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
-			U.n_lanes = n_reads * QL;
-		}
-		return 1;
+	int mode;
+	if (uniform_len > 0) mode = n_bases == n_reads * L ? 1 : 0;
+	else mode = (double)(n_reads * Q * C) <= 0.93 * (double)n_bases ? 2 : 0; // mostly full-length reads: the ragged form
+	if (mode == 0) return 0;
+	// Many level-1 buckets (big tables; every rank of a multi-GPU job partitions by the GLOBAL table's buckets): the linear
+	// form, 12 (or 8) windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear with 8 / with 12
+	// windows: n1 = 143: 5.57 / 6.76 / 6.05, 573: 8.13 / 7.57 / 6.81, 1023: 10.61 / 7.76 / 6.99 (287: 6.34 / 6.77 / -).
+	// DBGK_L1_LINEAR=0/1 forces the choice.
+	const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1; // (read per batch: tests switch it)
+	// 12 or 8 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: both none -> 12)
+	const uint64_t q12 = (W + 11u) / 12u, q8 = (W + 7u) / 8u;
+	lin12 = q12 * 12u - W <= q8 * 8u - W;
+	if (const char *e = getenv("DBGK_L1_LINEAR_C")) lin12 = atoi(e) == 12; // measurements
+	const uint64_t QL = lin12 ? q12 : q8, CL = lin12 ? 12 : 8;
+	bool fits = QL < 2048 && n_reads * QL < (1ull << 32) && ((uint64_t)kL1Threads / QL + 2) * L + 96 <= (uint64_t)kPkWords * 16;
+	if (mode == 2) fits = fits && (double)(n_reads * QL * CL) <= 0.93 * (double)n_bases;
+	if (fits && (force == 1 || (force < 0 && h->geom.n1 > 320u))) {
+		lin = true;
+		U.Q = (uint32_t)QL;
+		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
+		U.n_lanes = n_reads * QL;
 	}
-	return (double)(n_reads * Q * C) <= 0.93 * (double)n_bases ? 2 : 0;
+	return mode;
 }
 
 // WIDE record path: can this batch take the equal-length level-1 kernel (k_wide_scatter_l1_uniform)?
@@ -1140,13 +1144,17 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);          \
 		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
 	} while (0)
-#define DBGK_LAUNCH_UNIFORM8(WIDE, CC)                                                                                                                      \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
+#define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-		if (lin8 && lin12) {
-			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12); else DBGK_LAUNCH_UNIFORM8(0, 12);
+		if (lin8 && lin12 && ragged) {
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12, true); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12, true); else DBGK_LAUNCH_UNIFORM8(0, 12, true);
+		} else if (lin8 && lin12) {
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12, false); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12, false); else DBGK_LAUNCH_UNIFORM8(0, 12, false);
+		} else if (lin8 && ragged) {
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8, true); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8, true); else DBGK_LAUNCH_UNIFORM8(0, 8, true);
 		} else if (lin8) {
-			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8); else DBGK_LAUNCH_UNIFORM8(0, 8);
+			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8, false); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8, false); else DBGK_LAUNCH_UNIFORM8(0, 8, false);
 		} else if (wide == 2) DBGK_LAUNCH_UNIFORM_W(2);
 		else if (wide == 1) DBGK_LAUNCH_UNIFORM_W(1);
 		else DBGK_LAUNCH_UNIFORM_W(0);
