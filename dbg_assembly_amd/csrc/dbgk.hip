@@ -139,6 +139,18 @@ struct dbgk_handle {
 	PartGeom geom;
 	PartStore store;
 	uint32_t *tile_prefix = nullptr; // [n_ranks * B + 1] level-2 tile plan
+	// THREE-LEVEL partition for tables whose level-1 buckets hold 4096 regions (2^33 slots and more): level 2
+	// runs as two passes of the same kernel -- MID: every level-1 bucket into fan_mid = n2 / 64 mid buckets (store `mid`,
+	// laid out like the level-1 store of a table with r - log2(fan_mid)), FINAL: every mid bucket into its 64 final buckets,
+	// written exactly where the two-level form puts them, so the build is the same.  One more pass over the records instead
+	// of ~3500 reservation atomics per 8192-record tile.
+	bool three = false;
+	uint32_t fan_mid = 0;
+	PartGeom g_mid, g_fin;
+	PartStore s_mid, s_fin;
+	uint64_t *mid = nullptr;
+	uint32_t *cnt_mid = nullptr;
+	uint32_t *tile_prefix2 = nullptr; // [nb_own * fan_mid + 1]
 	hipStream_t stream2 = nullptr;   // finalize: region build of bucket chunk c runs here while level 2 of chunk c+1 runs on `stream`
 	std::vector<hipEvent_t> chunk_ev; // level 2 of chunk c finished
 	hipEvent_t join_ev = nullptr;
@@ -252,6 +264,7 @@ static void free_partition_stores(dbgk_handle *h)
 {
 	for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
 	                (void *)h->store.spill, (void *)h->store.ovf_n, (void *)h->tile_prefix, (void *)h->store.hh, (void *)h->region_cursor,
+	                (void *)h->mid, (void *)h->cnt_mid, (void *)h->tile_prefix2,
 	                (void *)h->inbox, (void *)h->inbox_cnt, (void *)h->store.outgoing, (void *)h->store.outgoing_n})
 		if (p) (void)hipFree(p);
 	memset(&h->store, 0, sizeof h->store);
@@ -259,6 +272,9 @@ static void free_partition_stores(dbgk_handle *h)
 	h->region_cursor = nullptr;
 	h->inbox = nullptr;
 	h->inbox_cnt = nullptr;
+	h->mid = nullptr;
+	h->cnt_mid = nullptr;
+	h->tile_prefix2 = nullptr;
 }
 
 static void free_wide_partition(dbgk_handle *h)
@@ -328,6 +344,7 @@ static int clear_record_store(dbgk_handle *h)
 	}
 	HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
 	HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
+	if (h->three) HIPCHK(hipMemsetAsync(h->cnt_mid, 0, (size_t)h->geom.nb_own * h->fan_mid * 4, h->stream));
 	HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
 	if (h->store.hh) HIPCHK(hipMemsetAsync(h->store.hh, 0, h->store.hh_size * sizeof(Node), h->stream));
 	HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
@@ -574,9 +591,36 @@ static int plan_partition(dbgk_handle *h)
 	const double per_slot = (double)expected / (double)h->size;
 	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05 / (double)G.n_sub) + 65536 / G.n_sub + (G.n_sub > 1 ? 8192 : 0); // per sub-store
 	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
+	G.r_rec = r;
+	G.l2_shift = 0;
 	h->tslots = G.slot_hi - G.slot_lo;
 	h->sharded = want_shard;
 	h->part = true;
+	static const bool no_three = getenv("DBGK_THREE_LEVEL") && atoi(getenv("DBGK_THREE_LEVEL")) == 0; // measurements
+	// measured with cfg2's 1.2 G records, level 2 alone: n2 = 4096 (8.6 G slots) 17.6 ms in one pass, 9.7 ms in two;
+	// n2 = 2048 (5 G slots) 6.9 ms in one pass, 9.5 in two -- so only the 4096-way fan-out is split
+	h->three = G.n2 > 2048u && !no_three;
+	if (h->three) {
+		h->fan_mid = G.n2 / 64u; // 64
+		uint32_t lg = 0;
+		while ((1u << lg) < h->fan_mid) lg++;
+		const uint64_t cap_mid = (uint64_t)(per_slot * (double)n_ranks * (double)(1ull << (r - lg)) * 1.08) + 8192;
+		h->g_mid = G;
+		h->g_mid.n2 = h->fan_mid;
+		h->g_mid.l2_shift = 6;      // the low 6 bits of the final-bucket index are left to the final pass
+		h->g_mid.cap2 = cap_mid;
+		h->g_fin = G;
+		h->g_fin.n_ranks = 1;       // its input is this handle's own mid store
+		h->g_fin.rank = 0;
+		h->g_fin.n_sub = 1;
+		h->g_fin.r = r - lg;
+		h->g_fin.n1 = G.n1 * h->fan_mid;
+		h->g_fin.B = G.nb_own * h->fan_mid;
+		h->g_fin.b_lo = G.b_lo * h->fan_mid;
+		h->g_fin.nb_own = G.nb_own * h->fan_mid;
+		h->g_fin.n2 = 64;
+		h->g_fin.cap1 = cap_mid;
+	}
 	return DBGK_OK;
 }
 
@@ -616,6 +660,20 @@ static int setup_partition(dbgk_handle *h)
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	h->store_capacity = expected;
+	if (h->three) {
+		const size_t n_mid = (size_t)G.nb_own * h->fan_mid;
+		if (hipMalloc(&h->mid, n_mid * h->g_mid.cap2 * 8) != hipSuccess || hipMalloc(&h->cnt_mid, n_mid * 4) != hipSuccess ||
+		    hipMalloc(&h->tile_prefix2, (n_mid + 1) * 4) != hipSuccess) {
+			g_last_error = "hipMalloc of the mid-level record store failed";
+			return DBGK_ERR_NOMEM;
+		}
+		h->s_mid = P;           // reads the inbox like level 2, writes the mid store
+		h->s_mid.l2 = h->mid;
+		h->s_mid.cnt2 = h->cnt_mid;
+		h->s_fin = P;           // reads the mid store, writes the final buckets where level 2 would
+		h->s_fin.inbox = h->mid;
+		h->s_fin.inbox_cnt = h->cnt_mid;
+	}
 #define DBGK_UNIFORM_ATTRS(W)                                                  \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true>), sizeof(UniformLds));  \
@@ -1386,6 +1444,13 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 template <int DBG>
 static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 {
+	if (h->three) { // mid pass, plan of the mid buckets filled so far, final pass (see the handle's comment)
+		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->g_mid, h->s_mid, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->g_fin, h->s_fin, h->tile_prefix2);
+		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->g_fin, h->s_fin, h->tile_prefix2, h->d_ctr,
+		                   j0 * h->fan_mid, j1 * h->fan_mid);
+		return;
+	}
 	if (h->geom.n2 > 2048u) // tables of 2^33 slots and more
 		hipLaunchKernelGGL((k_scatter_l2<0, 4096>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<4096>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else if (h->geom.n2 > (uint32_t)kMaxBuckets) // 2^32 .. 2^33 slots

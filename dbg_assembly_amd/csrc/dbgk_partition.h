@@ -94,6 +94,10 @@ struct PartGeom {
 	uint32_t b_lo, nb_own;
 	uint32_t n_regions_own;
 	uint64_t slot_lo, slot_hi;
+	uint32_t r_rec;      // the r of the RECORD format: q = (record >> 6) >> r_rec.  == r except in the final pass of a three-level
+	                     // partition, whose buckets are finer than the level-1 buckets the records were made for
+	uint32_t l2_shift;   // level-2 passes: bucket of a record = (record >> (6 + 12 + l2_shift)) & (n2 - 1); 0 except in the MID
+	                     // pass of a three-level partition (tables of 2^33 slots and more, see launch_l2 in dbgk.hip)
 	uint32_t kf;         // KFREQ through this engine: a record is one occurrence of the key, its neighbour fields are
 	                     // fixed (lb = 0, rb = none), so the A counter of l_link is the saturating occurrence count
 };
@@ -124,7 +128,7 @@ __device__ __forceinline__ uint64_t record_key(uint64_t rec, uint32_t b1, const 
 {
 	const uint64_t v = rec >> 6;
 	const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
-	return hash_code_inverse((v >> G.r) * G.size + slot);
+	return hash_code_inverse((v >> G.r_rec) * G.size + slot);
 }
 
 __device__ __forceinline__ void push_overflow(const PartStore &P, uint64_t key, uint32_t lb, uint32_t rb, Counters *ctr)
@@ -281,7 +285,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				const uint32_t p = (uint32_t)u * LDS::kThreads + (uint32_t)t;
 				if (p >= total) continue;
 				const uint64_t rcd = L.stage[p];
-				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits)) & (n_buckets - 1u);
+				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits + G.l2_shift)) & (n_buckets - 1u);
 				const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
 				if (DBG == 3) {
 					out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + off) & 4095ull)] = rcd;
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore
 		for (int u = 0; u < 16; u++) {
 			rec[u] = nxt[u];
 			// an all-ones word is never a record: the neighbour fields only take the values 0..4
-			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits)) & (G.n2 - 1u));
+			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits + G.l2_shift)) & (G.n2 - 1u));
 		}
 		l2_load_tile(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
 		scatter_tile<16, DBG, true>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
