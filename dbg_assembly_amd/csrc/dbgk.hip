@@ -685,6 +685,10 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_UNIFORM_ATTRS(1);
 	DBGK_UNIFORM_ATTRS(2);
 #define DBGK_LIN_ATTRS(W)                                                                          \
+	DBGK_LDS_ATTR((k_extract_scatter_lin<false, W>), sizeof(ScatterLdsLin<8>));                   \
+	DBGK_LDS_ATTR((k_extract_scatter_lin<true, W>), sizeof(ScatterLdsLin<8>));                    \
+	DBGK_LIN_ATTRS_U(W)
+#define DBGK_LIN_ATTRS_U(W)                                                                          \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, false, true>), sizeof(UniformLdsLin<8>));   \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, true, true>), sizeof(UniformLdsLin<8>));    \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, false, true>), sizeof(UniformLdsLin<12>)); \
@@ -693,6 +697,7 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LIN_ATTRS(1);
 	DBGK_LIN_ATTRS(2);
 #undef DBGK_LIN_ATTRS
+#undef DBGK_LIN_ATTRS_U
 #undef DBGK_UNIFORM_ATTRS
 	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
 	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
@@ -1224,7 +1229,18 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu()); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
 		const int wide_d = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
-		if (wide_d == 2 && has_long)
+		const int force_lin = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
+		if (!dbg_mode && (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u))) { // many level-1 buckets: the linear form
+#define DBGK_LAUNCH_FLAT_LIN(DEAD, WD)                                                                                                       \
+	hipLaunchKernelGGL((k_extract_scatter_lin<DEAD, WD>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLdsLin<8>), h->stream, rb, h->geom, h->store, \
+	                   h->d_ctr)
+			if (has_long) {
+				if (wide_d == 2) DBGK_LAUNCH_FLAT_LIN(true, 2); else if (wide_d == 1) DBGK_LAUNCH_FLAT_LIN(true, 1); else DBGK_LAUNCH_FLAT_LIN(true, 0);
+			} else {
+				if (wide_d == 2) DBGK_LAUNCH_FLAT_LIN(false, 2); else if (wide_d == 1) DBGK_LAUNCH_FLAT_LIN(false, 1); else DBGK_LAUNCH_FLAT_LIN(false, 0);
+			}
+#undef DBGK_LAUNCH_FLAT_LIN
+		} else if (wide_d == 2 && has_long)
 			hipLaunchKernelGGL((k_extract_scatter<true, 0, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (wide_d == 2)
 			hipLaunchKernelGGL((k_extract_scatter<false, 0, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);

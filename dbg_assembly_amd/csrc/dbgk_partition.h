@@ -735,6 +735,68 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 	}
 }
 
+// The flat kernel in its LINEAR form (many level-1 buckets, see ScatterLdsLin): a lane's 16 positions are handled as two
+// tiles of 8; between them the chunk state moves on by 8 positions.
+template <bool HAS_DEAD, int WIDE_D = 0>
+__global__ __launch_bounds__(kL1Threads) void k_extract_scatter_lin(ReadBatch rb, PartGeom G, PartStore P, Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	using LDS = ScatterLdsLin<8>;
+	LDS &L = *reinterpret_cast<LDS *>(lds_raw);
+	const uint64_t n_chunks = (rb.n_bases + 15u) >> 4;
+	const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;
+	const uint32_t rc_shift = 2u * k - 2u;
+	const uint32_t rel_mask = (1u << G.r) - 1u, q_shift = G.r + 6u;
+	auto interior = [&](uint64_t tile) { return ((tile + 1u) * kL1Threads + 2u) * 16u <= rb.n_bases; };
+	auto fetch = [&](uint64_t tile) {
+		const uint64_t ch = tile * kL1Threads + fresh_tid();
+		if (tile >= n_tiles) return RawChunk{};
+		return interior(tile) ? load_raw<HAS_DEAD, false>(rb, ch, n_chunks) : load_raw<HAS_DEAD, true>(rb, ch, n_chunks);
+	};
+	RawChunk raw = fetch(blockIdx.x);
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t chunk = tile * kL1Threads + fresh_tid();
+		Chunk16 c = decode_chunk16<HAS_DEAD>(raw, rb, chunk);
+		if (chunk >= n_chunks) c.valid = 0u;
+		raw = fetch(tile + gridDim.x); // in flight during both tiles
+		bool zero_any = false;
+#pragma unroll 1
+		for (uint32_t half = 0; half < 2u; half++) {
+			const uint32_t tid = fresh_tid();
+			uint32_t bkt[16];
+#pragma unroll
+			for (int j = 0; j < LDS::kBpt; j++) L.hist[LDS::kBpt * tid + j] = 0;
+			lds_barrier();
+			Chunk16 h8 = c; // the 8 positions of this tile
+			h8.valid &= 0xFFu;
+			h8.has_l = (h8.has_l & 0xFFu) | 0xFF00u; // (positions 8..15 are not this tile's: never "fixed up")
+			h8.has_r = (h8.has_r & 0xFFu) | 0xFF00u;
+			zero_any = l1_positions<WIDE_D, 8, LDS>(L, G, h8, tid, head_mask, rc_shift, rel_mask, q_shift, bkt) || zero_any;
+			// move on by 8 positions: the 8 entering bases are the top half of nb
+			c.kbit = ((c.kbit << 16) | (uint64_t)(c.nb >> 16)) & head_mask;
+			c.rc = revcomp_kbit(c.kbit, (int)k);
+			c.lw <<= 16;
+			c.nb <<= 16;
+			c.valid >>= 8;
+			c.has_l >>= 8;
+			c.has_r >>= 8;
+			l1_scatter_tail_linear<0, 8>(L, G, P, ctr, tid, bkt);
+		}
+		if (zero_any && chunk < n_chunks) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
+			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
+#pragma unroll 1
+			for (uint32_t i = 0; i < 16; i++) {
+				const Triple tr = next_triple<HAS_DEAD>(w, i, rb.k, rb.n_bases);
+				if (tr.valid && tr.key == 0ull)
+					links_cas_observe(&ctr->polyA_links, *reinterpret_cast<volatile unsigned long long *>(&ctr->polyA_links),
+					                  G.kf ? 0u : tr.lb, G.kf ? 4u : tr.rb);
+			}
+		}
+	}
+}
+
 // ---- level 1 for batches of EQUAL-LENGTH reads ----------------------------------------------------
 // The flat kernel above gives every lane 16 consecutive base positions, so a fifth of the positions of
 // 150-base reads at k = 31 are windows that straddle a read boundary (hashed, divided, ranked in a dummy
