@@ -2,6 +2,7 @@
 """bench.py -- k-mer hashing throughput of the MI355X path on BASELINE.json's metric.
 
   python bench.py --gpus 1 --steps K --warmup W            (single process)
+  python bench.py --gpus N ...                              (starts its own N ranks: a torch.distributed.run child)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one whole pass of the hot path over one batch of synthetic reads that is already
@@ -186,8 +187,28 @@ def golden_cfg2(args, world, n_reads, genome_len):
     return gold
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks ourselves --
+    a fresh `python -m torch.distributed.run` child (one process per GPU over RCCL), its stdout (rank 0's one JSON
+    line) relayed, its exit status returned.  This process never imports torch or touches HIP, so nothing that
+    initialised a GPU is ever replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     # stdout carries ONE line, the result.  RCCL prints a version banner to stdout when a communicator is
     # created (any time up to the first point-to-point transfer), so file descriptor 1 is pointed at
     # stderr for the whole run and the JSON line is written to the saved original.
@@ -302,7 +323,8 @@ def main():
         if got != want:
             sys.exit("bench.py: the graph built in the timed loop differs from tests/golden/cfg2_full.json "
                      "(count/kmers/digest %r, expected %r)" % (got[:3], want[:3]))
-        verified = "count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (CPU oracle, full size)"
+        verified = ("count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (full size; CPU oracle"
+                    + (", confirmed by the real reference" if gold.get("confirmed_by") else "") + ")")
     value_incl_h2d = None
     if world == 1 and not multi and not args.no_h2d and args.config != "cfg5" and not (debug_mode or debug_l2):
         import numpy as np

@@ -11,8 +11,12 @@
 // parity artefact: every non-null slot's (kmer, l_link, r_link), sorted by kmer.
 //
 // Sub-commands
-//   ref_dbg build [-k -r -f -t -i -l -e -b as in main.cpp:166] [-d dump.txt] [-T table.img] [-q] <reads.lib>
+//   ref_dbg build [-k -r -f -t -i -l -e -b as in main.cpp:166] [-d dump.txt] [-T table.img] [-S] [-q] <reads.lib>
 //                 -T writes the raw table image (size, count, node array, nul_flag): the slot LAYOUT
+//                 -S adds "digest" (order-independent sum over the non-null slots, the definition of
+//                    dbgk_digest in include/dbgk.h) and "depth_stat" (histogram of the 8 link counters of
+//                    every node, get_next_kmer_depth kmerSet.cpp:341-344) to the JSON line: the full-size
+//                    record tests/golden/cfg2_full.json is confirmed against it (make_cfg2_full.py --ref)
 //   ref_dbg kat                        known-answer values of the codec / hash helpers
 //   ref_dbg prime <n> [<n> ...]        find_next_prime(n)
 #include "DBGgraph.h"
@@ -23,13 +27,21 @@
 #include <vector>
 #include <algorithm>
 
+static inline uint64_t mix64(uint64_t x)   // splitmix64 finaliser (ours: the digest of include/dbgk.h, not reference code)
+{
+	uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
 static int cmd_build(int argc, char **argv)
 {
 	std::string dump_path, image_path;
-	int quiet = 0;
+	int quiet = 0, summary = 0;
 	int c;
 	optind = 1;
-	while ((c = getopt(argc, argv, "k:r:f:t:i:l:e:b:d:T:q")) != -1) {
+	while ((c = getopt(argc, argv, "k:r:f:t:i:l:e:b:d:T:Sq")) != -1) {
 		switch (c) {
 			case 'k': KmerSize = atoi(optarg); break;
 			case 'r': maxReadLen = atoi(optarg); break;
@@ -41,6 +53,7 @@ static int cmd_build(int argc, char **argv)
 			case 'b': BufferNum = atoi(optarg); break;
 			case 'd': dump_path = optarg; break;
 			case 'T': image_path = optarg; break;
+			case 'S': summary = 1; break;
 			case 'q': quiet = 1; break;
 			default: return 2;
 		}
@@ -59,11 +72,29 @@ static int cmd_build(int argc, char **argv)
 	double wall = std::chrono::duration<double>(t1 - t0).count();
 
 	printf("{\"reads\": %llu, \"kmers\": %llu, \"count\": %llu, \"size\": %llu, \"max\": %llu, "
-	       "\"conflict\": %llu, \"threads\": %d, \"wall_s\": %.6f}\n",
+	       "\"conflict\": %llu, \"threads\": %d, \"wall_s\": %.6f",
 	       (unsigned long long)Total_reads_num, (unsigned long long)Kmer_total_num,
 	       (unsigned long long)kset->count, (unsigned long long)kset->size,
 	       (unsigned long long)kset->max, (unsigned long long)kset->count_conflict,
 	       threadNum, wall);
+	if (summary) {
+		uint64_t digest = 0, nodes = 0;
+		std::vector<long long> depth(256, 0);
+		for (uint64_t i = 0; i < kset->size; i++) {
+			if (is_entity_null(kset->nul_flag, i)) continue;
+			const KmerNode &e = kset->array[i];
+			digest += mix64(e.kmer ^ mix64(((uint64_t)e.l_link << 32) | e.r_link));
+			for (uint8_t b = 0; b < 4; b++) {
+				depth[get_next_kmer_depth(e.l_link, b)]++;
+				depth[get_next_kmer_depth(e.r_link, b)]++;
+			}
+			nodes++;
+		}
+		printf(", \"nonnull_slots\": %llu, \"digest\": %llu, \"depth_stat\": [", (unsigned long long)nodes, (unsigned long long)digest);
+		for (int d = 0; d < 256; d++) printf("%s%lld", d ? ", " : "", depth[d]);
+		printf("]");
+	}
+	printf("}\n");
 
 	if (!image_path.empty()) {
 		FILE *fp = fopen(image_path.c_str(), "wb");

@@ -3,7 +3,11 @@
 k-mer total, order-independent digest and DepthStat of the graph, computed by the CPU oracle
 (oracle/dbg_oracle.c, pinned to the real reference by the other fixtures in this directory) --
 tests/test_gpu_parity.py and bench.py compare the GPU result at full size with it.
-    python tests/golden/make_cfg2_full.py [threads]      (CPU only; ~5 min, ~10 GB of RAM)"""
+    python tests/golden/make_cfg2_full.py [threads]      (CPU only; ~5 min, ~10 GB of RAM)
+    python tests/golden/make_cfg2_full.py --ref [threads]
+        runs the REAL reference (oracle/_ref/ref_dbg build -S, compiled in place from /root/reference by oracle/Makefile)
+        on the same 10 M reads written as one-line FASTA, asserts reads / k-mer total / count / digest / DepthStat equal
+        the committed record and stamps it "confirmed_by": the full-size record is then pinned to the reference itself."""
 import ctypes as C
 import json
 import os
@@ -19,7 +23,40 @@ from oracle import oracle_py as O  # noqa: E402
 N_READS, GENOME, K = 10_000_000, 50_000_000, 31
 
 
+def confirm_with_reference(threads):
+    import subprocess
+    import tempfile
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_full.json")
+    with open(path) as fh:
+        gold = json.load(fh)
+    assert O.have_ref(), "oracle/_ref/ref_dbg is missing: make -C oracle ref (needs /root/reference)"
+    P = O.synth_params(GENOME, 150, cfg=2)
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        fa = os.path.join(tmp, "cfg2.fa")
+        O.lib().orc_synth_write_file(C.byref(P), 0, N_READS, os.fsencode(fa), 2, 0)
+        libf = os.path.join(tmp, "reads.lib")
+        with open(libf, "w") as fh:
+            fh.write(fa + "\n")
+        print("reads written (%.1f GB) %.0f s" % (os.path.getsize(fa) / 1e9, time.time() - t0), flush=True)
+        cmd = [O.REF_BIN, "build", "-k", str(K), "-r", "250", "-f", "2", "-t", str(threads), "-i", "0.4", "-l", "0.7",
+               "-e", "10", "-b", "10000", "-S", "-q", libf]
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    js = json.loads(out.strip().splitlines()[-1])
+    got = (js["reads"], js["kmers"], js["count"], js["nonnull_slots"], js["digest"], js["depth_stat"])
+    want = (gold["total_reads"], gold["total_kmers"], gold["count"], gold["count"], gold["digest"], gold["depth_stat"])
+    assert got == want, "the real reference disagrees with tests/golden/cfg2_full.json: %r vs %r" % (got[:5], want[:5])
+    gold["confirmed_by"] = ("ref_dbg (the real reference, DBG_contig/{seqKmer,kmerSet,DBGgraph,gzstream}.cpp compiled in place) "
+                            "build -k 31 -t %d -i 0.4 -b 10000 -S on the same 10 M reads as one-line FASTA: reads, k-mer total, "
+                            "count, digest and DepthStat identical; its wall %.0f s" % (threads, js["wall_s"]))
+    with open(path, "w") as fh:
+        json.dump(gold, fh, indent=1)
+    print("confirmed by the real reference in %.0f s (its build: %.0f s)" % (time.time() - t0, js["wall_s"]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--ref":
+        return confirm_with_reference(int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     L = O.lib()
     P = O.synth_params(GENOME, 150, cfg=2)
