@@ -644,7 +644,8 @@ static int setup_partition(dbgk_handle *h)
 	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
 	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) == hipSuccess &&
 	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->tile_prefix, (n_entries + 1) * 4) == hipSuccess &&
-	          hipMalloc(&h->region_cursor, kMaxBuildLaunches * sizeof(unsigned int)) == hipSuccess &&
+	          hipMalloc(&h->region_cursor, ((size_t)kMaxBuildLaunches + 2 + G.n_regions_own) * sizeof(unsigned int)) == hipSuccess && // + redo cursor, count, list
+
 	          hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.outgoing_n, 8) == hipSuccess;
 	if (ok && h->sharded)
 		ok = hipMalloc(&h->inbox, l1_bytes) == hipSuccess && hipMalloc(&h->inbox_cnt, n_entries * 4) == hipSuccess;
@@ -679,8 +680,13 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true>), sizeof(UniformLds));  \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, true>), sizeof(UniformLds));  \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter<true, 0, W>), sizeof(ScatterLds));              \
 	DBGK_LDS_ATTR((k_extract_scatter<false, 0, W>), sizeof(ScatterLds))
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<1, 0, 15, false>), sizeof(UniformLds)); // timing experiments (DBGK_DEBUG_MODE)
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<2, 0, 15, false>), sizeof(UniformLds));
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<3, 0, 15, false>), sizeof(UniformLds));
 	DBGK_UNIFORM_ATTRS(0);
 	DBGK_UNIFORM_ATTRS(1);
 	DBGK_UNIFORM_ATTRS(2);
@@ -708,13 +714,14 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 2048>), sizeof(ScatterLdsL2T<2048>));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 4096>), sizeof(ScatterLdsL2T<4096>));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_build_regions<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BuildLds)));
+#define DBGK_BUILD_ATTR(...) DBGK_LDS_ATTR((k_build_regions<__VA_ARGS__>), sizeof(BuildLds))
+	DBGK_BUILD_ATTR(0, false, false, false); DBGK_BUILD_ATTR(0, true, false, false); DBGK_BUILD_ATTR(0, false, true, false); DBGK_BUILD_ATTR(0, true, true, false);
+	DBGK_BUILD_ATTR(0, false, false, true);  DBGK_BUILD_ATTR(0, true, false, true);  DBGK_BUILD_ATTR(0, false, true, true);  DBGK_BUILD_ATTR(0, true, true, true);
+	DBGK_BUILD_ATTR(0, false, false, false, true); DBGK_BUILD_ATTR(0, true, false, false, true); DBGK_BUILD_ATTR(0, false, true, false, true);
+	DBGK_BUILD_ATTR(0, true, true, false, true);
+	DBGK_BUILD_ATTR(1, false, false, false); DBGK_BUILD_ATTR(2, false, false, false); DBGK_BUILD_ATTR(3, false, false, false);
+	DBGK_BUILD_ATTR(1, false, false, true);  DBGK_BUILD_ATTR(2, false, false, true);  DBGK_BUILD_ATTR(3, false, false, true);
+#undef DBGK_BUILD_ATTR
 	return DBGK_OK;
 }
 
@@ -1026,7 +1033,8 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	lin = lin12 = false;
 	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
 	static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-	if (off || dbg_mode || has_long || n_reads == 0) return 0;
+	if (off || has_long || n_reads == 0) return 0;
+	if (dbg_mode && (uniform_len != 150 || h->cfg.kmer_size != 31 || h->geom.size >= (1ull << 31))) return 0; // debug builds: cfg2's shape only
 	const uint64_t L = uniform_len > 0 ? (uint64_t)uniform_len : len_max, k = (uint64_t)h->cfg.kmer_size;
 	if (L > (uint64_t)h->cfg.max_read_len || L < k + 63 || L >= (1ull << 24)) return 0;
 	const uint32_t W = (uint32_t)(L - k + 1);
@@ -1041,6 +1049,13 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	U.Q = (uint32_t)Q;
 	U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
 	U.n_lanes = n_reads * Q;
+	U.lq = 0;
+	U.tile_blocks = 0; // 0: no regular tiles
+	if ((Q & (Q - 1)) == 0 && Q <= (uint64_t)kL1Threads && (((uint64_t)kL1Threads / Q) * L) % 16 == 0 &&
+	    ((uint64_t)kL1Threads / Q) * L / 16 + 8 <= (uint64_t)kPkWords) {
+		while ((1ull << U.lq) < Q) U.lq++;
+		U.tile_blocks = (uint32_t)(((uint64_t)kL1Threads / Q) * L / 16);
+	}
 	int mode;
 	if (uniform_len > 0) mode = n_bases == n_reads * L ? 1 : 0;
 	else mode = (double)(n_reads * Q * C) <= 0.93 * (double)n_bases ? 2 : 0; // mostly full-length reads: the ragged form
@@ -1059,6 +1074,7 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	if (mode == 2) fits = fits && (double)(n_reads * QL * CL) <= 0.93 * (double)n_bases;
 	if (fits && (force == 1 || (force < 0 && h->geom.n1 > 320u))) {
 		lin = true;
+		U.tile_blocks = 0;
 		U.Q = (uint32_t)QL;
 		U.qmagic = ((1u << 22) + U.Q - 1u) / U.Q;
 		U.n_lanes = n_reads * QL;
@@ -1193,8 +1209,6 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
-		const uint64_t n_tiles = (U.n_lanes + kL1Threads - 1) / kL1Threads;
-		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu());
 		const int wide = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
 		const bool ragged = umode == 2;
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
@@ -1210,7 +1224,42 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 #define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-		if (lin8 && lin12 && ragged) {
+		static const int dbg_mode_u = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
+		static const bool no_reg = getenv("DBGK_L1_NO_REG") != nullptr; // A/B: the general form everywhere
+		bool rest_only = false;
+		if (!dbg_mode_u && !no_reg && umode == 1 && !lin8 && U.tile_blocks) {
+			// regular tiles: kL1Threads / Q whole reads each, from a 16-byte boundary; the reads behind the last whole tile
+			// (fewer than kL1Threads / Q) go through the general form below
+			const uint64_t reads_per_tile = (uint64_t)kL1Threads / U.Q, full_tiles = n_reads / reads_per_tile;
+			if (full_tiles) {
+				UniformGeom UR = U;
+				UR.n_lanes = full_tiles * kL1Threads;
+				ReadBatch rr = rb;
+				rr.n_bases = full_tiles * reads_per_tile * U.L;
+				const int grid_r = (int)std::min<uint64_t>(full_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu());
+#define DBGK_LAUNCH_REG(WIDE, CC)                                                                                                                  \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds), h->stream, rr, \
+	                   UR, d_offsets, h->geom, h->store, h->d_ctr)
+				if (c15) { if (wide == 2) DBGK_LAUNCH_REG(2, 15); else if (wide == 1) DBGK_LAUNCH_REG(1, 15); else DBGK_LAUNCH_REG(0, 15); }
+				else { if (wide == 2) DBGK_LAUNCH_REG(2, 16); else if (wide == 1) DBGK_LAUNCH_REG(1, 16); else DBGK_LAUNCH_REG(0, 16); }
+#undef DBGK_LAUNCH_REG
+				const uint64_t done_reads = full_tiles * reads_per_tile;
+				rb.bases += done_reads * U.L;
+				rb.n_bases -= done_reads * U.L;
+				U.n_lanes = (n_reads - done_reads) * U.Q;
+				rest_only = U.n_lanes == 0;
+			}
+		}
+		const uint64_t n_tiles_rest = (U.n_lanes + kL1Threads - 1) / kL1Threads;
+		const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_rest, 1), (uint64_t)h->n_cu * l1_wgs_per_cu());
+		if (rest_only) {
+		} else if (dbg_mode_u == 1)   // timing experiments on cfg2's shape (C = 15, equal lengths, size < 2^31): results are wrong
+			hipLaunchKernelGGL((k_extract_scatter_uniform<1, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
+		else if (dbg_mode_u == 2)
+			hipLaunchKernelGGL((k_extract_scatter_uniform<2, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
+		else if (dbg_mode_u == 3)
+			hipLaunchKernelGGL((k_extract_scatter_uniform<3, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
+		else if (lin8 && lin12 && ragged) {
 			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12, true); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12, true); else DBGK_LAUNCH_UNIFORM8(0, 12, true);
 		} else if (lin8 && lin12) {
 			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12, false); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12, false); else DBGK_LAUNCH_UNIFORM8(0, 12, false);
@@ -1475,23 +1524,58 @@ static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 		hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 }
 
+static RedoList redo_list(dbgk_handle *h)
+{
+	return RedoList{h->region_cursor + kMaxBuildLaunches + 2, h->region_cursor + kMaxBuildLaunches + 1, h->geom.n_regions_own};
+}
+
+// FAST form of the insert (four records per thread in flight, plain adds on the link words, regions whose counters pass 255
+// left to the exact pass) unless DBGK_BUILD_EXACT=1 asks for the saturating CAS loops everywhere
+static bool build_fast()
+{
+	static const bool exact = getenv("DBGK_BUILD_EXACT") && atoi(getenv("DBGK_BUILD_EXACT")) != 0;
+	return !exact;
+}
+
 template <int DBG>
 static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions, unsigned int *cursor)
 {
 	static const int per_cu = getenv("DBGK_BUILD_PER_CU") ? std::max(1, atoi(getenv("DBGK_BUILD_PER_CU"))) : 2; // tuning knob
 	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * (uint32_t)per_cu); // persistent: two 66-KiB workgroups fit a CU
-	if (h->kfreq && h->incr)
-		hipLaunchKernelGGL((k_build_regions<0, true, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
-		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
-	else if (h->kfreq)
-		hipLaunchKernelGGL((k_build_regions<0, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store,
-		                   reinterpret_cast<Node *>(h->counts), h->d_ctr, first_region, n_regions, cursor);
-	else if (h->incr && DBG == 0)
-		hipLaunchKernelGGL((k_build_regions<0, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table,
-		                   h->d_ctr, first_region, n_regions, cursor);
-	else
-		hipLaunchKernelGGL(k_build_regions<DBG>, dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, h->table, h->d_ctr,
-		                   first_region, n_regions, cursor);
+	const RedoList redo = redo_list(h);
+	Node *counts = reinterpret_cast<Node *>(h->counts);
+#define DBGK_BUILD(D, KF, INCR, FAST, TABLE) \
+	hipLaunchKernelGGL((k_build_regions<D, KF, INCR, FAST>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, TABLE, h->d_ctr, \
+	                   first_region, n_regions, cursor, redo)
+	if (build_fast()) {
+		if (h->kfreq && h->incr) DBGK_BUILD(0, true, true, true, counts);
+		else if (h->kfreq) DBGK_BUILD(0, true, false, true, counts);
+		else if (h->incr && DBG == 0) DBGK_BUILD(0, false, true, true, h->table);
+		else DBGK_BUILD(DBG, false, false, true, h->table);
+	} else {
+		if (h->kfreq && h->incr) DBGK_BUILD(0, true, true, false, counts);
+		else if (h->kfreq) DBGK_BUILD(0, true, false, false, counts);
+		else if (h->incr && DBG == 0) DBGK_BUILD(0, false, true, false, h->table);
+		else DBGK_BUILD(DBG, false, false, false, h->table);
+	}
+#undef DBGK_BUILD
+}
+
+// the exact pass over the regions the fast launches flagged (normally none: the kernel finds an empty list and returns)
+static void launch_build_redo(dbgk_handle *h, hipStream_t stream)
+{
+	const uint32_t grid = (uint32_t)h->n_cu * 2u;
+	const RedoList redo = redo_list(h);
+	unsigned int *cursor = h->region_cursor + kMaxBuildLaunches;
+	Node *counts = reinterpret_cast<Node *>(h->counts);
+#define DBGK_REDO(KF, INCR, TABLE) \
+	hipLaunchKernelGGL((k_build_regions<0, KF, INCR, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, TABLE, \
+	                   h->d_ctr, 0u, 0u, cursor, redo)
+	if (h->kfreq && h->incr) DBGK_REDO(true, true, counts);
+	else if (h->kfreq) DBGK_REDO(true, false, counts);
+	else if (h->incr) DBGK_REDO(false, true, h->table);
+	else DBGK_REDO(false, false, h->table);
+#undef DBGK_REDO
 }
 
 // Level 2 is bound by the memory system (8 waves per CU and 72 KiB of LDS reach the same time as a
@@ -1511,7 +1595,7 @@ static int part_plan(dbgk_handle *h)
 	}
 	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->geom, h->store, h->tile_prefix);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemsetAsync(h->region_cursor, 0, kMaxBuildLaunches * sizeof(unsigned int), h->stream)); // one work cursor per build launch
+	HIPCHK(hipMemsetAsync(h->region_cursor, 0, (kMaxBuildLaunches + 2) * sizeof(unsigned int), h->stream)); // one work cursor per build launch, + the exact pass's cursor and count
 	h->cursors_used = 0;
 	int rc = span_begin(h, PH_L2_BUILD_WALL, h->wall_span);
 	if (rc) return rc;
@@ -1611,6 +1695,7 @@ static int build_from_records(dbgk_handle *h)
 	h->zero_pending = false; // every slot has just been written
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
+	if (build_fast()) launch_build_redo(h, h->stream); // regions with a link counter beyond 255: rebuilt exactly (before their spill nodes are merged)
 	if (h->kfreq) {
 		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap, 0,
 		                   reinterpret_cast<uint32_t *>(h->counts));

@@ -812,6 +812,11 @@ struct UniformGeom {
 	uint32_t Q;          // lanes per read = ceil(W / C), < 2048; C = 16 or 15 windows per lane, whichever wastes fewer slots
 	uint32_t qmagic;     // ceil(2^22 / Q): (x * qmagic) >> 22 == x / Q for x < 2048 + Q
 	uint64_t n_lanes;    // n_reads * Q
+	// REGULAR tiles (k_extract_scatter_uniform<..., REG = true>): equal-length reads whose lane count Q divides the tile (a
+	// power of two) and whose tile -- kL1Threads / Q whole reads -- is a multiple of 16 bytes: every tile starts at a
+	// 16-byte boundary on a read start, its byte range and every lane's place in it are the same for all tiles
+	uint32_t lq;            // log2(Q)
+	uint32_t tile_blocks;   // 16-byte blocks of a tile = (kL1Threads / Q) * L / 16
 };
 
 constexpr int kPkWords = 1792 * kTileThreads / 1024; // packed words of one tile's byte range: <= 1024 lanes * 16 (1 + (k - 1) / W) bases + slack
@@ -854,11 +859,15 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
 // length -- the host compares n_reads * Q * C lane slots with the n_bases positions of the flat kernel.
 // LIN: the linear form (C = 8 or 12 windows per lane, ScatterLdsLin<C>, l1_scatter_tail_linear) for many level-1 buckets
-template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false>
+// REG: regular tiles (see UniformGeom) -- the per-tile address arithmetic (64-bit read offsets, divisions by Q, guarded loads)
+// collapses to a few 32-bit operations; the host launches this form over the whole tiles of a batch and the general form over
+// the reads that are left
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	static_assert(!LIN || C == 8 || C == 12, "the linear form stages 8 or 12 records per thread");
+	static_assert(!REG || (!RAGGED && !LIN), "regular tiles: equal-length reads, wave-per-bucket form");
 	using ULds = typename std::conditional<LIN, UniformLdsLin<LIN ? C : 8>, UniformLds>::type;
 	using SLds = typename std::conditional<LIN, ScatterLdsLin<LIN ? C : 8>, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -895,6 +904,17 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		raw.n_blocks = raw.cc = raw.W = 0;
 		if (tile >= n_tiles) return raw;
 		const uint32_t t = fresh_tid();
+		if constexpr (REG) { // every tile: kL1Threads / Q whole reads from a 16-byte boundary, all of them inside the buffer
+			raw.B0 = tile * ((uint64_t)U.tile_blocks * 16u);
+			raw.n_blocks = U.tile_blocks;
+			const uint4 *blocks = reinterpret_cast<const uint4 *>(rb.bases + raw.B0);
+			if (t < raw.n_blocks) raw.a = blocks[t];
+			if (t + kL1Threads < raw.n_blocks) raw.b = blocks[t + kL1Threads];
+			raw.cc = t & (U.Q - 1u);
+			raw.p = raw.B0 + (t >> U.lq) * U.L + (uint32_t)C * raw.cc;
+			raw.W = U.W;
+			return raw;
+		}
 		// the tile's byte range: from one base before its first lane's first window to the end of its last lane's window
 		// RAGGED: a tile may start in the empty tail lanes of a read shorter than C * c_first; the range then
 		// starts at the next read (the first live lane's window), never past it
@@ -933,7 +953,10 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		for (int j = 0; j < SLds::kBpt; j++) L.hist[SLds::kBpt * tid + j] = 0;
 		lds_barrier();
 		const uint64_t p = raw.p;                        // flat position of the lane's first window
-		const uint64_t s0 = p ? p - 1u : 0u;             // the packed stream starts one base earlier (left neighbour)
+		// the packed stream starts one base earlier (left neighbour) -- except at position 0, and (regular tiles, whose byte
+		// range starts ON a read start) for a read's first chunk, whose first window has no left neighbour anyway
+		const bool no_prev = REG ? raw.cc == 0u : p == 0u;
+		const uint64_t s0 = no_prev ? p : p - 1u;
 		const uint32_t first_w = (uint32_t)C * raw.cc;   // index of the lane's first window inside its read
 		const bool live = first_w < raw.W;               // (raw.W == 0 for lanes beyond the batch)
 		Chunk16 c;
@@ -943,9 +966,9 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			const uint32_t x0 = UL.pk[d], x1 = UL.pk[d + 1], x2 = UL.pk[d + 2], x3 = UL.pk[d + 3], x4 = UL.pk[d + 4];
 			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
 			// stream Y starts at position p (X starts at p - 1 unless p == 0)
-			const uint32_t adv = p ? 2u : 0u;
+			const uint32_t adv = no_prev ? 0u : 2u;
 			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
-			c.lw = p ? X0 : (X0 >> 2); // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
+			c.lw = no_prev ? (X0 >> 2) : X0; // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
 			c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
 			c.rc = revcomp_kbit(c.kbit, (int)k);
 			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
@@ -1101,6 +1124,15 @@ struct BuildLds {
 	unsigned long long links[kRegionSlots + kSpillSlots];
 	unsigned long long red[kBuildThreads / 64];
 	uint32_t next_region;
+	uint32_t redo;                 // FAST build: some counter of the current region overflowed its byte, the region goes to the exact pass
+};
+
+// Regions the FAST build could not finish (a link counter passed 255, or the region and its spill area were full): rebuilt from
+// their records by the exact form of the kernel (saturating LDS CAS) after all fast launches of the step.
+struct RedoList {
+	uint32_t *list;        // local region indices
+	unsigned int *n;       // appended so far
+	uint32_t cap;
 };
 
 // DBG (DBGK_DEBUG_BUILD, timing experiments, results are wrong): 1 = clear + load only, 2 = no emit,
@@ -1113,11 +1145,20 @@ struct BuildLds {
 // there by k_merge_spill) is a foreign blocker: it keeps its slot, takes no record of this region (its
 // records go to its home region, run off that region's end again and are merged by k_merge_spill) and is
 // left untouched by the emit.  KF + INCR: counts[key] += the occurrences of this flush, saturating.
-template <int DBG = 0, bool KF = false, bool INCR = false>
+// FAST: the insert keeps four records per thread in flight and never loops on a counter.  A slot is probed with ONE
+// unconditional ds_cmpst (compare 0, swap in the identity: returns 0 = claimed, the identity = found, anything else = occupied
+// by another key -- a read and a claim in one LDS round trip, four of them issued back to back), and the two observed neighbour
+// counters are bumped with ONE fire-and-forget-style ds_add_rtn_u64 on the link word.  A plain add cannot saturate, so its
+// return value is checked instead: if the byte it bumped already held 255 (kmerSet.cpp:253-273 stops there) the region is
+// flagged, emits NOTHING (no table slots, no spill nodes, no counts, no overflow records) and is appended to `redo`; the exact
+// form of this kernel (FAST = false: saturating CAS loops, FROM_LIST = true) rebuilds the flagged regions from their records
+// afterwards.  Exact for any input; a region pays twice only when one of its k-mers has a neighbour seen more than 255 times.
+template <int DBG = 0, bool KF = false, bool INCR = false, bool FAST = false, bool FROM_LIST = false>
 __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, PartStore P, Node *__restrict__ table,
                                                                   Counters *__restrict__ ctr, uint32_t first_region, uint32_t n_regions,
-                                                                  unsigned int *__restrict__ cursor)
+                                                                  unsigned int *__restrict__ cursor, RedoList redo)
 {
+	static_assert(!(FAST && FROM_LIST), "the exact pass is what the list is for");
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	BuildLds &L = *reinterpret_cast<BuildLds *>(lds_raw);
 	const int t = (int)fresh_tid();
@@ -1146,7 +1187,12 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	auto grab = [&]() { // one region index per workgroup, broadcast through LDS
 		if (t == 0) {
 			const unsigned int k = atomicAdd(cursor, 1u);
-			L.next_region = k < n_regions ? first_region + k : kNone;
+			if (FROM_LIST) {
+				const unsigned int n_list = *redo.n < redo.cap ? *redo.n : redo.cap; // complete: every fast launch has finished
+				L.next_region = k < n_list ? redo.list[k] : kNone;
+			} else {
+				L.next_region = k < n_regions ? first_region + k : kNone;
+			}
 		}
 	};
 
@@ -1171,6 +1217,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		L.ident[i] = 0ull;
 		L.links[i] = 0ull;
 	}
+	if (t == 0) L.redo = 0u;
 	grab();
 	lds_barrier();
 	uint32_t f = __builtin_amdgcn_readfirstlane(L.next_region); // scalar: everything derived from it stays in SGPRs
@@ -1183,6 +1230,8 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	uint64_t recs[kBatch];
 	load_batch(f, 0, recs);
 	uint32_t n_new = 0, n_conf = 0; // per thread: far below 2^32
+	uint32_t n_new_r = 0, n_conf_r = 0; // FAST: of the current region, committed only when the region is emitted
+	bool ovf = false;                   // FAST: this thread saw a counter overflow (or a full region) in the current region
 
 	while (f != kNone) {
 		const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits)); // f = LOCAL final bucket == local region index == (slot - slot_lo) >> 12
@@ -1200,6 +1249,81 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) x ^= recs[u];
 			if (x == 0x1234567ull) table[t].kmer = x;
+		} else if constexpr (FAST) {
+			uint32_t idx[kBatch];
+			unsigned long long got[kBatch];
+			bool probing[kBatch];
+			// first probe of all four records: the claims are in flight together
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				idx[u] = (uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u);
+				// (a lane without a record compares against all-ones, which no slot ever holds: a plain read)
+#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 3
+				got[u] = (recs[u] >> 6) + 1ull; // timing experiment: no claims (results are wrong)
+#else
+				got[u] = atomicCAS(&L.ident[idx[u]], recs[u] != ~0ull ? 0ull : ~0ull, (recs[u] >> 6) + 1ull);
+#endif
+			}
+			bool any = false;
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				const bool live = recs[u] != ~0ull;
+				const unsigned long long id = (recs[u] >> 6) + 1ull;
+				n_new_r += (live && got[u] == 0ull && idx[u] < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
+				probing[u] = live && got[u] != 0ull && got[u] != id;
+				idx[u] += probing[u] ? 1u : 0u;
+				n_conf_r += probing[u] ? 1u : 0u;
+				any = any || probing[u];
+			}
+			// the records whose home slot holds another key walk on one after the other: plain reads, a claim only where a slot is
+			// seen empty (an LDS instruction costs the same whatever its lane count -- profiles/ubench/lds_rate.hip: 2.6 ns per
+			// 64-bit read, 8 ns per 64-bit compare-swap and CU -- so the four-wide claims above are not repeated here)
+#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 1
+			any = false; // timing experiment: no miss loops (results are wrong)
+#endif
+			if (any) {
+#pragma unroll
+				for (int u = 0; u < kBatch; u++) {
+					const unsigned long long id = (recs[u] >> 6) + 1ull;
+					bool on = probing[u];
+					uint32_t at = idx[u];
+					while (on) { // ONE exit, no breaks
+						unsigned long long cur = L.ident[at];
+						if (cur == 0ull) {
+							const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
+							cur = prev == 0ull ? id : prev;
+							n_new_r += (prev == 0ull && at < region_len) ? 1u : 0u;
+						}
+						const bool hit = cur == id;
+						at += hit ? 0u : 1u;
+						n_conf_r += hit ? 0u : 1u;
+						const bool lost = at >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full:
+						ovf = ovf || lost;                                                  // the exact pass sends it to the overflow list
+						on = !hit && !lost;
+					}
+					idx[u] = at < (uint32_t)(kRegionSlots + kSpillSlots) ? at : 0u;
+				}
+			}
+			// +1 on the observed neighbour bytes, both dwords with one add; the returned word tells whether a byte was already 255
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				const bool live = recs[u] != ~0ull;
+				const uint32_t lb = (uint32_t)(recs[u] >> 3) & 7u, rb = (uint32_t)recs[u] & 7u;
+				const uint32_t dl = (live && lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (live && rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
+#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 2
+				got[u] = dl + dr; // timing experiment: no adds (results are wrong)
+#else
+				got[u] = atomicAdd(&L.links[idx[u]], ((unsigned long long)dr << 32) | dl);
+#endif
+			}
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				const bool live = recs[u] != ~0ull;
+				const uint32_t lb = (uint32_t)(recs[u] >> 3) & 7u, rb = (uint32_t)recs[u] & 7u;
+				const uint32_t ml = (live && lb != 4u) ? (0xFFu << (24u - 8u * lb)) : 0u, mr = (live && rb != 4u) ? (0xFFu << (24u - 8u * rb)) : 0u;
+				const uint32_t lo = (uint32_t)got[u], hi = (uint32_t)(got[u] >> 32);
+				ovf = ovf || (ml && (lo & ml) == ml) || (mr && (hi & mr) == mr);
+			}
 		} else {
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
@@ -1246,8 +1370,22 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			}
 		}
 		if (last_of_region) {
-			lds_barrier();
-			if (DBG != 1 && DBG != 2) {
+			bool redo_region = false;
+			if constexpr (FAST) {
+				if (ovf) L.redo = 1u;
+				lds_barrier();
+				redo_region = __builtin_amdgcn_readfirstlane(L.redo) != 0u;
+				if (!redo_region) { n_new += n_new_r; n_conf += n_conf_r; }
+				else if (t == 0) {
+					const unsigned int j = atomicAdd(redo.n, 1u);
+					if (j < redo.cap) redo.list[j] = f; else atomicOr(&ctr->error, 2u);
+				}
+				n_new_r = n_conf_r = 0u;
+				ovf = false;
+			} else {
+				lds_barrier();
+			}
+			if (DBG != 1 && DBG != 2 && !redo_region) {
 				// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot)); the LDS
 				// image is cleared on the way for the next region.
 				// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
@@ -1301,6 +1439,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			grab(); // the region after the one whose first batch is already in flight
 			lds_barrier(); // the image is empty again, next_region is visible
 			f_after = __builtin_amdgcn_readfirstlane(L.next_region);
+			if (FAST && t == 0) L.redo = 0u; // (every thread has read it: that happened before its emit, i.e. before the barrier above)
 			if (INCR && !KF) load_image(f_nxt); // the region whose records come next
 			lds_barrier();
 		}
