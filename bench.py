@@ -47,6 +47,9 @@ CONFIGS = {"cfg2": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, tab
                         workload="cfg5 share of one GPU: synthetic 75 M x 150 bp reads (30x of 375 Mb; the stated job is 600 M reads of a 3 Gb "
                                  "genome on 8 GPUs), 0.1% subst, 0.01% N, k=63, 128-bit keys, 32-byte nodes (WIDE engine, PARITY UNPINNED: the "
                                  "reference stops at k=31)"),
+           "cfg4": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, table_slots=0, synth_cfg=2, kmer=17,
+                        workload="cfg4: correct_error k-mer frequency table, k=17 (4^17 saturating byte counters, 16 GiB), of cfg2's reads "
+                                 "(10 M x 150 bp per GPU, 0.5% subst, 0.01% N); counted through the partitioned records (KFREQ engine)"),
            "cfg3": dict(reads_per_gpu=25_000_000, genome_per_gpu=125_000_000, table_slots=1_075_000_000, synth_cfg=3,
                         workload="cfg3: synthetic 200 M x 150 bp reads of a 1 Gb genome at N=8 (25 M reads, 125 Mb, 1.075 G slots per GPU; "
                                  "fewer GPUs run that share of it), 0.5% subst, 0.01% N, k=31, ONE table over all GPUs")}
@@ -57,12 +60,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the weak-scaling line): BASELINE configs[1] PER GPU -- 10 M x 150 bp reads, 50 Mb of genome "
                          "and 600 M table slots per GPU; cfg3: BASELINE configs[2] split over the GPUs that are there -- 25 M reads, "
                          "125 Mb of genome and 1.075 G slots per GPU, i.e. at N = 8 the stated job: 200 M reads of a 1 Gb genome "
                          "into ONE table of 8.6 G slots (~5.6 G nodes); cfg5: one GPU's share of BASELINE configs[4] (k = 63, WIDE engine, "
-                         "single GPU only)")
+                         "single GPU only); cfg4: BASELINE configs[3], the correct_error k-mer frequency table (k = 17) of cfg2's reads, "
+                         "KFREQ engine; N > 1: every GPU counts its reads, the tables are combined by a saturating reduce-scatter")
     ap.add_argument("--reads-per-gpu", type=int, default=None)
     ap.add_argument("--genome-per-gpu", type=int, default=None)
     ap.add_argument("--kmer", type=int, default=None)
@@ -91,6 +95,8 @@ def parse_args():
         args.kmer = CONFIGS[args.config].get("kmer", 31)
     if args.config == "cfg5":
         args.engine = 5   # capi.ENGINE_WIDE
+    if args.config == "cfg4":
+        args.engine = 3   # capi.ENGINE_KFREQ
     return args
 
 
@@ -205,6 +211,158 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def cpu_baseline_kfreq(args, genome_len):
+    """The producer of the correct_error frequency table (`kmerfreq`) is not part of the reference, so the CPU figure next
+    to cfg4 is the oracle's restatement of the counting (extraction pinned to the reference; numpy accumulation), one
+    thread, on a bounded sample.  Checker code, timed NEXT TO the GPU path."""
+    from oracle import oracle_py as O
+    n = min(args.cpu_sample_reads, 2_000_000)
+    P = O.synth_params(genome_len, 150, cfg=CONFIGS["cfg4"]["synth_cfg"])
+    bases, offsets = O.synth_reads(P, 0, n)
+    t0 = time.perf_counter()
+    import numpy as np
+    keys = []
+    raw = bases.tobytes()
+    for i in range(n):
+        km, _, _ = O.parse_read(raw[int(offsets[i]):int(offsets[i + 1])], args.kmer, 250)
+        keys.append(km)
+    uniq, cnt = np.unique(np.concatenate(keys), return_counts=True)
+    dt = time.perf_counter() - t0
+    return {"value": n * (150 - args.kmer + 1) / dt / 1e6, "unit": "M k-mers/s", "cores": 1, "kind": "port",
+            "host": "%s, %d logical CPUs" % (cpu_model(), os.cpu_count() or 0),
+            "sample": "first %d reads of the N=1 workload (%d k-mers, %d distinct canonical), oracle extraction + numpy.unique, reads pre-loaded, "
+                      "wall %.2f s (the reference holds no producer of this table: SURVEY 8(c))" % (n, n * (150 - args.kmer + 1), len(uniq), dt)}
+
+
+def main_kfreq(args, result_out):
+    """--config cfg4: one step = reset (zero the 4^k counters) + extract every k-mer of the resident reads into records,
+    partition them, aggregate every region in LDS, emit counts[key] + the table summary.  N > 1: every rank counts its own
+    reads into a whole table, then the tables are combined by the saturating reduce-scatter of multigpu.kfreq_reduce
+     inside the timed step."""
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import kfreq_reduce, wrap_device_memory
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    multi = world > 1
+    if multi:
+        dist.init_process_group("nccl", device_id=device)
+    n_reads, k = args.reads_per_gpu, args.kmer
+    kpr = 150 - k + 1
+    genome_len = args.genome_per_gpu * world
+    P = capi.synth_params(genome_len, 150, cfg=CONFIGS["cfg4"]["synth_cfg"])
+    g = capi.Graph(k=k, table_slots=0, max_read_len=250, device=local_rank, engine=capi.ENGINE_KFREQ, expected_kmers=n_reads * kpr)
+    d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)
+
+    def step():
+        g.reset()
+        g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+        st = g.finalize()
+        if multi:
+            kfreq_reduce(g, device)
+        return st
+
+    def fence():
+        g.sync()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    g.sync()
+    g.reset_timings()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tm = g.timings()
+    ms_per_step = dt / args.steps * 1e3
+    kmers_step = int(st.stored_kmers)
+    distinct = int(st.count)
+    # after the timed region (N = 1): the same reads through the OTHER counting path (atomics on the byte table) must give the
+    # same table -- both are pinned against the oracle at smaller sizes (tests/test_kfreq.py); here at full size
+    verified = None
+    if not multi:
+        ptr, n_counts = g.kfreq_device_counts()
+        mine = wrap_device_memory(ptr, n_counts, device).view(torch.int64)
+        sum_a = int(mine.sum().item()) & ((1 << 64) - 1)
+        xor_a = int(torch.bitwise_xor(mine[0::2], mine[1::2]).sum().item()) & ((1 << 64) - 1)
+        with capi.Graph(k=k, table_slots=0, max_read_len=250, device=local_rank, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
+            g2.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st2 = g2.finalize()
+            ptr2, _ = g2.kfreq_device_counts()
+            other = wrap_device_memory(ptr2, n_counts, device).view(torch.int64)
+            same = bool(torch.equal(mine, other))
+            sum_b = int(other.sum().item()) & ((1 << 64) - 1)
+        if not same or (int(st2.count), int(st2.stored_kmers)) != (distinct, kmers_step) or sum_a != sum_b:
+            sys.exit("bench.py cfg4: the partitioned count differs from the atomic count of the same reads")
+        verified = ("the 4^%d-byte table of the last timed step == the table the atomic kernel builds from the same reads (byte for byte), "
+                    "%d distinct canonical k-mers; both paths are pinned to the oracle in tests/test_kfreq.py" % (k, distinct))
+        del mine, other, xor_a
+    if rank == 0:
+        b_alg = 150.0 / kpr + 2.0   # SURVEY 8(d): bases + one counter byte read + one written
+        achieved = kmers_step * b_alg / (ms_per_step * 1e-3) / 1e9
+        l1_ms, l2_ms, build_ms, wall_ms = tm.insert_ms / args.steps, tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
+        own = {"k_extract_scatter_uniform": kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * 16.0,
+               "k_build_regions(KF)": kmers_step * 8.0 + distinct * 1.0}
+        ms = {"k_extract_scatter_uniform": l1_ms, "k_scatter_l2": l2_ms, "k_build_regions(KF)": build_ms}
+        copy_bw = None
+        if world == 1:
+            try:
+                copy_bw = g.copy_bandwidth(1 << 30, 10)
+            except Exception as e:  # noqa: BLE001
+                print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
+        own_total = sum(own.values()) + 2.0 * 4 ** k   # + zeroing the table at reset and the summary pass over it
+        out = {"metric": "M k-mers/s counted (k=%d, 150 bp)" % k, "value": kmers_step * world / (dt / args.steps) / 1e6, "unit": "M k-mers/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": CONFIGS["cfg4"]["workload"], "reads_per_gpu": n_reads, "kmers_per_gpu": kmers_step,
+                          "table_bytes": 4 ** k, "distinct_canonical_kmers": distinct if not multi else None, "engine": "kfreq (partitioned records)",
+                          "parallelism": "single GPU" if not multi else
+                                         "reads sharded by record x%d, whole tables per GPU, saturating reduce-scatter of the counters" % world},
+               "roofline": {"bound": "hbm", "kernel": "whole step: reset -> " + " -> ".join(ms) + " -> table summary", "achieved": achieved,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
+                            "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step, "traffic": None,
+                            "own_bytes_per_step": own_total,
+                            "own_traffic_ratio": own_total / (kmers_step * b_alg),
+                            "note": "the algorithmic figure (3.12 B per k-mer: a byte counter read and written) is what a table small enough to "
+                                    "stay cached would cost; the 16 GiB table is random-access, so the path moves 8-byte records instead "
+                                    "(own_bytes_per_step, incl. zeroing and summarising the table): own_traffic_ratio times the algorithmic bytes",
+                            "l2_build_wall_ms": wall_ms,
+                            "kernels": {kn: {"ms_per_step": ms[kn], "own_bytes_per_step": own[kn],
+                                             "own_GBs": own[kn] / (ms[kn] * 1e-3) / 1e9 if ms[kn] > 0 else None} for kn in ms}},
+               "phases_ms_per_step": {"mark": tm.mark_ms / args.steps, "insert": l1_ms, "partition": l2_ms, "build": build_ms,
+                                      "partition_and_build_wall": wall_ms, "merge": tm.fixup_ms / args.steps, "finalize": tm.finalize_ms / args.steps},
+               "verified": verified}
+        if world == 1:
+            out["copy_bandwidth_GBs"] = copy_bw
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_kfreq(args, genome_len)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
+    d_bases.free()
+    d_off.free()
+    g.close()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -215,6 +373,8 @@ def main():
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    if args.config == "cfg4":
+        return main_kfreq(args, result_out)
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
