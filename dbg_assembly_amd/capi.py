@@ -36,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [("kmer_size", C.c_int32), ("max_read_len", C.c_int32), ("table_slots", C.c_uint64),
                 ("device_id", C.c_int32), ("engine", C.c_int32), ("max_batch_bases", C.c_uint64),
                 ("expected_kmers", C.c_uint64), ("shard_count", C.c_uint32), ("shard_index", C.c_uint32),
-                ("flags", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("flags", C.c_uint64), ("n_passes", C.c_uint64), ("reserved", C.c_uint64 * 1)]
 
 
 class ShardInfo(C.Structure):
@@ -98,6 +98,11 @@ SYMBOLS = [
     ("dbgk_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_wide_partition_export", _i, [_vp, C.c_uint32, _vp, _u64, _vp]),
     ("dbgk_wide_merge_nodes", _i, [_vp, _vp, _u64]),
+    ("dbgk_wide_pass_info", _i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("dbgk_wide_begin_pass", _i, [_vp, C.c_uint32]),
+    ("dbgk_wide_end_pass", _i, [_vp]),
+    ("dbgk_shard_side_export", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("dbgk_shard_side_clear", _i, [_vp]),
     ("dbgk_seed_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_seed_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -203,10 +208,10 @@ class Graph:
     """One GPU-resident k-mer graph under construction (thin wrapper over a dbgk_handle)."""
 
     def __init__(self, k, table_slots, max_read_len=250, device=0, engine=ENGINE_AUTO, max_batch_bases=0,
-                 expected_kmers=0, shard_count=0, shard_index=0, flags=0):
+                 expected_kmers=0, shard_count=0, shard_index=0, flags=0, n_passes=0):
         self._h = None
         cfg = Config(k, max_read_len, table_slots, device, engine, max_batch_bases, expected_kmers,
-                     shard_count, shard_index, flags)
+                     shard_count, shard_index, flags, n_passes)
         h = C.c_void_p()
         _chk(lib().dbgk_create(C.byref(cfg), C.byref(h)), "dbgk_create")
         self._h = h
@@ -340,8 +345,9 @@ class Graph:
         assert got.value == n, (got.value, n)
         return out
 
-    def wide_export_host_table(self):
-        size = self.table_slots
+    def wide_export_host_table(self, size=None):
+        """size: the handle's slots (a shard: the slots of its range, default the whole table)"""
+        size = self.table_slots if size is None else int(size)
         array = np.zeros(size, dtype=NODE32_DTYPE)
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_wide_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_wide_export_host_table")
@@ -426,6 +432,26 @@ class Graph:
 
     def shard_merge(self, d_nodes, n, is_triple=False, from_previous_shard=False):
         _chk(lib().dbgk_shard_merge(self._h, d_nodes, n, int(is_triple), int(from_previous_shard)), "dbgk_shard_merge")
+
+    # ---- WIDE through records: passes over the input, the side table of a shard
+    def wide_pass_info(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _chk(lib().dbgk_wide_pass_info(self._h, C.byref(a), C.byref(b)), "dbgk_wide_pass_info")
+        return a.value, b.value
+
+    def wide_begin_pass(self, p):
+        _chk(lib().dbgk_wide_begin_pass(self._h, p), "dbgk_wide_begin_pass")
+
+    def wide_end_pass(self):
+        _chk(lib().dbgk_wide_end_pass(self._h), "dbgk_wide_end_pass")
+
+    def shard_side_export(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().dbgk_shard_side_export(self._h, C.byref(p), C.byref(n)), "dbgk_shard_side_export")
+        return p.value, n.value
+
+    def shard_side_clear(self):
+        _chk(lib().dbgk_shard_side_clear(self._h), "dbgk_shard_side_clear")
 
     def add_polyA(self, l_link, r_link):
         _chk(lib().dbgk_add_polyA(self._h, l_link, r_link), "dbgk_add_polyA")

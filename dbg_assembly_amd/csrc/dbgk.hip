@@ -116,6 +116,20 @@ struct dbgk_handle {
 	WPartStore wstore;
 	uint32_t *w_tile_prefix = nullptr;
 	unsigned int *w_cursor = nullptr;
+	// shards and passes of the wide record path (WPartGeom): `wmulti` handles follow the strict protocol
+	// begin_pass -> pushes -> [exchange] -> end_pass, ..., finalize; nothing streams through the atomic kernels
+	bool wmulti = false;          // sharded and / or several passes
+	bool wpass_open = false;      // a pass has been begun and not ended
+	bool wplanned = false;        // level-2 tile plan of the current pass made
+	uint32_t wnext = 0;           // own-bucket indices [0, wnext) of the current pass have been built
+	uint32_t wpasses_done = 0;
+	ull2 *winbox = nullptr;       // sharded: [n_l1][cap1] records of my buckets from every rank
+	uint32_t *winbox_cnt = nullptr;
+	dbgk_node32 *w_side_out = nullptr;      // [kWideSideSlots + 1] dbgk_shard_side_export
+	unsigned long long *w_side_n = nullptr;
+	unsigned long long wsaved_totals[2] = {0, 0}; // total_kmers, stored_kmers before a repeated pass over the input
+	uint64_t wsaved_reads = 0;
+	uint32_t shard_rank = 0;      // shard_index of a sharded handle (any engine)
 	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
@@ -281,11 +295,16 @@ static void free_wide_partition(dbgk_handle *h)
 {
 	WPartStore &P = h->wstore;
 	for (void *p : {(void *)P.l1, (void *)P.cnt1, (void *)P.l2, (void *)P.cnt2, (void *)P.ovf, (void *)P.spill, (void *)P.ovf_n, (void *)h->w_tile_prefix,
-	                (void *)h->w_cursor})
+	                (void *)h->w_cursor, (void *)h->winbox, (void *)h->winbox_cnt, (void *)P.outgoing, (void *)P.outgoing_n, (void *)h->w_side_out,
+	                (void *)h->w_side_n})
 		if (p) (void)hipFree(p);
 	memset(&P, 0, sizeof P);
 	h->w_tile_prefix = nullptr;
 	h->w_cursor = nullptr;
+	h->winbox = nullptr;
+	h->winbox_cnt = nullptr;
+	h->w_side_out = nullptr;
+	h->w_side_n = nullptr;
 }
 
 static void free_handle(dbgk_handle *h)
@@ -361,21 +380,43 @@ static int clear_record_store(dbgk_handle *h)
 #define DBGK_LDS_ATTR(KERNEL, BYTES) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
 
 // ---- WIDE through radix-partitioned records (dbgk_wide_partition.h) ---------------------------------
-// geometry: level-1 bucket = slot >> r with n1 = ceil(size / 2^r) <= 1024, final bucket = slot >> 11 (one 2048-slot
-// region), n2 = 2^(r - 11) <= 2048; the second half of a record holds q = hash / size, r slot bits, 6 neighbour bits
-static bool plan_wide_partition(dbgk_handle *h)
+// geometry: level-1 bucket = slot >> r, final bucket = slot >> 11 (one 2048-slot region), n2 = 2^(r - 11) <= 2048; the second
+// half of a record holds q = hash / size, r slot bits, 6 neighbour bits.  The level-1 kernel fans out to at most 1024 store
+// entries per pass: rank x own-bucket index inside the pass's window (WPartGeom).  One rank, one pass, n1 <= 1024: the
+// round-2 form.  *err: the configuration ASKS for shards / passes and cannot have them.
+static bool plan_wide_partition(dbgk_handle *h, bool *err)
 {
+	*err = false;
 	static const bool off = getenv("DBGK_WIDE_DIRECT") != nullptr; // always the atomic kernels
-	if (off || h->cfg.expected_kmers == 0 || h->size < (1ull << 26) || h->size > (1ull << 32)) return false;
+	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
+	const bool want_shard = h->cfg.shard_count >= 1;
+	const uint32_t want_passes = (uint32_t)h->cfg.n_passes;
+	auto refuse = [&](const char *why) {
+		if (want_shard || want_passes > 1) {
+			g_last_error = why;
+			*err = true;
+		}
+		return false;
+	};
+	if (off || h->cfg.expected_kmers == 0) return refuse("a sharded / multi-pass WIDE handle needs expected_kmers > 0 (the record path)");
+	if (h->size < (1ull << 26) || h->size >= (1ull << 34)) return refuse("the WIDE record path needs 2^26 <= table_slots < 2^34");
+	if (want_shard && h->cfg.shard_index >= n_ranks) return refuse("shard_index >= shard_count");
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
 	uint32_t r = 21;
 	if (const char *e = getenv("DBGK_WIDE_R")) r = (uint32_t)std::max(kWRegionBits + 1, std::min(22, atoi(e)));
-	while (((h->size + (1ull << r) - 1) >> r) > 1024ull) r++;
+	if (!want_shard && want_passes <= 1)
+		while (r < 22u && ((h->size + (1ull << r) - 1) >> r) > 1024ull) r++; // one pass if the fan-out allows it
 	while (r > (uint32_t)kWRegionBits + 1u && qbits + (int)r + 6 > 64) r--;
 	const uint64_t n1 = (h->size + (1ull << r) - 1) >> r;
-	if (n1 > 1024ull || (1u << (r - kWRegionBits)) > 2048u || qbits + (int)r + 6 > 64) return false;
+	if ((1u << (r - kWRegionBits)) > 2048u || qbits + (int)r + 6 > 64 || n1 >= 65536ull) return refuse("no feasible wide record geometry for this table size");
+	const uint32_t B = (uint32_t)((n1 + n_ranks - 1) / n_ranks);
+	// passes: at least as many as keep the level-1 fan-out (ranks x buckets of a pass) within 1024
+	uint32_t n_passes = std::max<uint32_t>(1u, want_passes);
+	while ((uint64_t)n_ranks * ((B + n_passes - 1) / n_passes) > 1024ull) n_passes++;
+	if (n_passes > B) return refuse("shard_count too large for this table size");
+	if (n_passes > 1 && !want_shard && want_passes <= 1 && getenv("DBGK_WIDE_NO_AUTO_PASSES")) return false;
 	WPartGeom &G = h->wgeom;
 	memset(&G, 0, sizeof G);
 	G.size = h->size;
@@ -385,10 +426,29 @@ static bool plan_wide_partition(dbgk_handle *h)
 	G.n1 = (uint32_t)n1;
 	G.n2 = 1u << (r - kWRegionBits);
 	G.n_regions = (uint32_t)((h->size + kWRegionSlots - 1) >> kWRegionBits);
-	const double per_slot = (double)h->cfg.expected_kmers / (double)h->size;
-	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05) + 65536;
-	G.cap2 = (uint64_t)(per_slot * (double)kWRegionSlots * 1.25) + 512;
-	G.chunk_buckets = (G.n1 + 7u) / 8u;
+	G.n_ranks = n_ranks;
+	G.rank = want_shard ? h->cfg.shard_index : 0;
+	G.B = B;
+	G.bmagic = (uint32_t)(((1ull << 32) + B - 1) / B);
+	G.b_lo = std::min(G.rank * B, G.n1);
+	G.nb_own = std::min(B, G.n1 - G.b_lo);
+	if (G.nb_own == 0) return refuse("shard_count too large for this table size");
+	G.n_passes = n_passes;
+	G.Bp = (B + n_passes - 1) / n_passes;
+	G.pass = 0;
+	G.pass_j0 = 0;
+	G.n_l1 = n_ranks * G.Bp;
+	G.slot_lo = (uint64_t)G.b_lo << r;
+	G.slot_hi = std::min<uint64_t>(h->size, ((uint64_t)G.b_lo + G.nb_own) << r);
+	// expected_kmers = occurrences THIS handle extracts (per pass over its input); a region receives the global density
+	const double per_slot_mine = (double)h->cfg.expected_kmers / (double)h->size;
+	G.cap1 = (uint64_t)(per_slot_mine * (double)(1ull << r) * 1.05) + 65536;
+	G.cap2 = (uint64_t)(per_slot_mine * (double)n_ranks * (double)kWRegionSlots * 1.25) + 512;
+	G.chunk_buckets = (G.Bp + 7u) / 8u;
+	h->wmulti = want_shard || n_passes > 1;
+	h->sharded = n_ranks > 1;
+	h->shard_rank = G.rank;
+	h->tslots = G.slot_hi - G.slot_lo;
 	return true;
 }
 
@@ -398,20 +458,27 @@ static int setup_wide_partition(dbgk_handle *h)
 	WPartStore &P = h->wstore;
 	memset(&P, 0, sizeof P);
 	P.ovf_cap = h->cfg.expected_kmers / 16 + (1ull << 20);
-	P.spill_cap = (uint64_t)G.n_regions * 8 + (1ull << 16);
-	const size_t l1_bytes = (size_t)G.n1 * G.cap1 * 16, l2_bytes = (size_t)G.chunk_buckets * G.n2 * G.cap2 * 16;
-	const bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
-	                hipMalloc(&P.cnt1, (size_t)G.n1 * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.chunk_buckets * G.n2 * 4) == hipSuccess &&
-	                hipMalloc(&P.ovf, P.ovf_cap * sizeof(dbgk_node32)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(dbgk_node32)) == hipSuccess &&
-	                hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->w_tile_prefix, ((size_t)G.n1 + 1) * 4) == hipSuccess &&
-	                hipMalloc(&h->w_cursor, 4) == hipSuccess;
+	P.spill_cap = (uint64_t)((h->tslots + kWRegionSlots - 1) >> kWRegionBits) * 8 + (1ull << 16);
+	P.outgoing_cap = 1ull << 16;
+	const size_t l1_bytes = (size_t)G.n_l1 * G.cap1 * 16, l2_bytes = (size_t)G.chunk_buckets * G.n2 * G.cap2 * 16;
+	bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
+	          hipMalloc(&P.cnt1, (size_t)G.n_l1 * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.chunk_buckets * G.n2 * 4) == hipSuccess &&
+	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(dbgk_node32)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(dbgk_node32)) == hipSuccess &&
+	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->w_tile_prefix, ((size_t)G.n_l1 + 1) * 4) == hipSuccess &&
+	          hipMalloc(&h->w_cursor, 4) == hipSuccess && hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(dbgk_node32)) == hipSuccess &&
+	          hipMalloc(&P.outgoing_n, 8) == hipSuccess && hipMalloc(&h->w_side_out, ((size_t)kWideSideSlots + 1) * sizeof(dbgk_node32)) == hipSuccess &&
+	          hipMalloc(&h->w_side_n, 8) == hipSuccess;
+	if (ok && h->sharded) ok = hipMalloc(&h->winbox, l1_bytes) == hipSuccess && hipMalloc(&h->winbox_cnt, (size_t)G.n_l1 * 4) == hipSuccess;
 	if (!ok) {
 		(void)hipGetLastError();
 		g_last_error = "hipMalloc of the wide record stores failed";
 		return DBGK_ERR_NOMEM;
 	}
-	HIPCHK(hipMemsetAsync(P.cnt1, 0, (size_t)G.n1 * 4, h->stream));
+	P.inbox = h->sharded ? h->winbox : P.l1;
+	P.inbox_cnt = h->sharded ? h->winbox_cnt : P.cnt1;
+	HIPCHK(hipMemsetAsync(P.cnt1, 0, (size_t)G.n_l1 * 4, h->stream));
 	HIPCHK(hipMemsetAsync(P.ovf_n, 0, 16, h->stream));
+	HIPCHK(hipMemsetAsync(P.outgoing_n, 0, 8, h->stream));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 0>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 0>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 1>), sizeof(WL1Lds));
@@ -426,6 +493,7 @@ static int setup_wide_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR(k_wide_build_regions, sizeof(WBuildLds));
 	h->store_capacity = h->cfg.expected_kmers;
 	h->pending_kmers = 0;
+	h->wpass_open = true; // pass 0 is open from the start
 	return DBGK_OK;
 }
 
@@ -433,57 +501,149 @@ static int setup_wide_partition(dbgk_handle *h)
 static int wide_ensure_zero(dbgk_handle *h)
 {
 	if (!h->wzero_pending) return DBGK_OK;
-	HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+	HIPCHK(hipMemsetAsync(h->wnodes, 0, h->tslots * sizeof(WNode), h->stream));
 	h->wzero_pending = false;
 	return DBGK_OK;
 }
 
-// records -> table.  Afterwards the handle is an ordinary WIDE handle: whatever is pushed later goes through the
-// atomic kernels onto the table built here.
-static int wide_build_from_records(dbgk_handle *h)
+// own-bucket indices of the current pass that exist on this rank (the last rank / pass may have fewer)
+static uint32_t wide_pass_buckets(const dbgk_handle *h)
 {
-	if (!h->wpart || h->wbuilt) return DBGK_OK;
+	const WPartGeom &G = h->wgeom;
+	return G.pass_j0 >= G.nb_own ? 0u : std::min(G.Bp, G.nb_own - G.pass_j0);
+}
+
+static int wide_plan_pass(dbgk_handle *h)
+{
+	if (h->wplanned) return DBGK_OK;
+	hipLaunchKernelGGL(k_wide_l2_plan, dim3(1), dim3(1024), 0, h->stream, h->wgeom, h->wstore.inbox_cnt, h->w_tile_prefix);
+	HIPCHK(hipGetLastError());
+	h->wplanned = true;
+	h->wnext = 0;
+	return DBGK_OK;
+}
+
+// level 2 + region build of the own-bucket indices [j0, j1) of the current pass, chunk by chunk of level-1 buckets
+// through the (small) level-2 store
+static int wide_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1)
+{
 	const WPartGeom &G = h->wgeom;
 	const WPartStore &P = h->wstore;
 	TimedSpan sp;
 	int rc = DBGK_OK;
-	hipLaunchKernelGGL(k_wide_l2_plan, dim3(1), dim3(1024), 0, h->stream, G, P.cnt1, h->w_tile_prefix);
-	HIPCHK(hipGetLastError());
-	// chunk by chunk of level-1 buckets: level 2 into the (small) level-2 store, then the regions of those buckets
-	for (uint32_t j0 = 0; j0 < G.n1; j0 += G.chunk_buckets) {
-		const uint32_t j1 = std::min(j0 + G.chunk_buckets, G.n1);
+	for (uint32_t c0 = j0; c0 < j1; c0 += G.chunk_buckets) {
+		const uint32_t c1 = std::min(c0 + G.chunk_buckets, j1);
 		rc = span_begin(h, PH_PARTITION, sp);
 		if (rc) return rc;
 		HIPCHK(hipMemsetAsync(P.cnt2, 0, (size_t)G.chunk_buckets * G.n2 * 4, h->stream));
 		if (G.n2 > 1024u)
-			hipLaunchKernelGGL(k_wide_scatter_l2<2048>, dim3(h->n_cu & ~7), dim3(kWL2Threads), sizeof(WL2Lds<2048>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, j0, j1);
+			hipLaunchKernelGGL(k_wide_scatter_l2<2048>, dim3(h->n_cu & ~7), dim3(kWL2Threads), sizeof(WL2Lds<2048>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, c0, c1);
 		else
-			hipLaunchKernelGGL(k_wide_scatter_l2<1024>, dim3((h->n_cu * 2) & ~7), dim3(kWL2Threads), sizeof(WL2Lds<1024>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, j0, j1);
+			hipLaunchKernelGGL(k_wide_scatter_l2<1024>, dim3((h->n_cu * 2) & ~7), dim3(kWL2Threads), sizeof(WL2Lds<1024>), h->stream, G, P, h->w_tile_prefix, h->d_ctr, c0, c1);
 		HIPCHK(hipGetLastError());
 		rc = span_end(h, sp);
 		if (rc) return rc;
-		const uint32_t r0 = j0 * G.n2, r1 = std::min(j1 * G.n2, G.n_regions);
-		if (r1 <= r0) continue;
+		const uint32_t n_regions = (c1 - c0) * G.n2;
 		rc = span_begin(h, PH_BUILD, sp);
 		if (rc) return rc;
 		HIPCHK(hipMemsetAsync(h->w_cursor, 0, 4, h->stream));
-		hipLaunchKernelGGL(k_wide_build_regions, dim3(std::min<uint32_t>(r1 - r0, (uint32_t)h->n_cu * 3u)), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P,
-		                   h->wnodes, h->d_ctr, h->w_cursor, r0, r1 - r0);
+		hipLaunchKernelGGL(k_wide_build_regions, dim3(std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 3u)), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P,
+		                   h->wnodes, h->d_ctr, h->w_cursor, c0, n_regions);
 		HIPCHK(hipGetLastError());
 		rc = span_end(h, sp);
 		if (rc) return rc;
 	}
-	h->wzero_pending = false; // every slot has just been written
-	rc = span_begin(h, PH_FIXUP, sp);
+	h->wnext = j1;
+	return DBGK_OK;
+}
+
+// the rest of the current pass: whatever the caller has not built by ranges
+static int wide_end_pass(dbgk_handle *h)
+{
+	if (!h->wpass_open) return DBGK_OK;
+	if (h->sharded && !h->exchanged) {
+		g_last_error = "sharded WIDE handle: exchange the level-1 buckets of this pass (dbgk_shard_buffers) and call dbgk_shard_mark_exchanged first";
+		return DBGK_ERR_STATE;
+	}
+	int rc = wide_plan_pass(h);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_wide_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.spill, &P.ovf_n[1], P.spill_cap, h->wref(), h->d_ctr);
-	hipLaunchKernelGGL(k_wide_insert_obs, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.ovf, &P.ovf_n[0], P.ovf_cap, h->wref(), h->d_ctr);
+	const uint32_t nb = wide_pass_buckets(h);
+	if (h->wnext < nb) {
+		rc = wide_build_range(h, h->wnext, nb);
+		if (rc) return rc;
+	}
+	if (h->wgeom.pass > 0) { // the input was read again: its totals were counted in pass 0
+		HIPCHK(hipMemcpyAsync(&h->d_ctr->total_kmers, h->wsaved_totals, 16, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		h->total_reads = h->wsaved_reads;
+	}
+	h->wpass_open = false;
+	h->wpasses_done = h->wgeom.pass + 1;
+	h->pending_kmers = 0;
+	return DBGK_OK;
+}
+
+static int wide_begin_pass(dbgk_handle *h, uint32_t p)
+{
+	WPartGeom &G = h->wgeom;
+	if (h->wpass_open || p != h->wpasses_done || p >= G.n_passes) {
+		g_last_error = "dbgk_wide_begin_pass: passes run in order, each ended (dbgk_wide_end_pass) before the next begins";
+		return DBGK_ERR_STATE;
+	}
+	G.pass = p;
+	G.pass_j0 = p * G.Bp;
+	HIPCHK(hipMemsetAsync(h->wstore.cnt1, 0, (size_t)G.n_l1 * 4, h->stream));
+	if (p > 0) {
+		HIPCHK(hipMemcpyAsync(h->wsaved_totals, &h->d_ctr->total_kmers, 16, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		h->wsaved_reads = h->total_reads;
+	}
+	h->wpass_open = true;
+	h->wplanned = false;
+	h->exchanged = false;
+	h->wnext = 0;
+	h->pending_kmers = 0;
+	return DBGK_OK;
+}
+
+// after the last pass: region spill-over nodes and bucket-overflow observations through the atomic kernels
+static int wide_finish_records(dbgk_handle *h)
+{
+	const WPartGeom &G = h->wgeom;
+	const WPartStore &P = h->wstore;
+	TimedSpan sp;
+	h->wzero_pending = false; // every slot has just been written
+	int rc = span_begin(h, PH_FIXUP, sp);
+	if (rc) return rc;
+	if (h->wmulti && G.n_ranks > 1) {
+		// spill nodes stay in the shard unless they run off its end (-> outgoing); overflow observations may belong to any
+		// shard: the caller exchanges them (dbgk_shard_overflow)
+		hipLaunchKernelGGL(k_wide_merge_sharded, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.spill, &P.ovf_n[1], (uint64_t)0, P.spill_cap, 0, 0, G, P, h->wnodes,
+		                   h->d_ctr);
+	} else {
+		hipLaunchKernelGGL(k_wide_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.spill, &P.ovf_n[1], P.spill_cap, h->wref(), h->d_ctr);
+		hipLaunchKernelGGL(k_wide_insert_obs, dim3(h->n_cu), dim3(kBlock), 0, h->stream, P.ovf, &P.ovf_n[0], P.ovf_cap, h->wref(), h->d_ctr);
+	}
 	HIPCHK(hipGetLastError());
 	rc = span_end(h, sp);
 	if (rc) return rc;
 	h->wbuilt = true;
 	h->pending_kmers = 0;
 	return DBGK_OK;
+}
+
+// records -> table (one rank, one pass).  Afterwards the handle is an ordinary WIDE handle: whatever is pushed later goes
+// through the atomic kernels onto the table built here.
+static int wide_build_from_records(dbgk_handle *h)
+{
+	if (!h->wpart || h->wbuilt) return DBGK_OK;
+	if (h->wmulti) {
+		g_last_error = "the record store of a sharded / multi-pass WIDE handle is full: expected_kmers too small (or more passes needed)";
+		return DBGK_ERR_CAPACITY;
+	}
+	int rc = wide_end_pass(h);
+	if (rc) return rc;
+	return wide_finish_records(h);
 }
 
 static int reset_state(dbgk_handle *h)
@@ -494,10 +654,18 @@ static int reset_state(dbgk_handle *h)
 			h->wzero_pending = true;
 			h->wbuilt = false;
 			h->pending_kmers = 0;
-			HIPCHK(hipMemsetAsync(h->wstore.cnt1, 0, (size_t)h->wgeom.n1 * 4, h->stream));
+			h->wgeom.pass = 0;
+			h->wgeom.pass_j0 = 0;
+			h->wpass_open = true;
+			h->wplanned = false;
+			h->wnext = 0;
+			h->wpasses_done = 0;
+			h->exchanged = false;
+			HIPCHK(hipMemsetAsync(h->wstore.cnt1, 0, (size_t)h->wgeom.n_l1 * 4, h->stream));
 			HIPCHK(hipMemsetAsync(h->wstore.ovf_n, 0, 16, h->stream));
+			HIPCHK(hipMemsetAsync(h->wstore.outgoing_n, 0, 8, h->stream));
 		} else {
-			HIPCHK(hipMemsetAsync(h->wnodes, 0, h->size * sizeof(WNode), h->stream));
+			HIPCHK(hipMemsetAsync(h->wnodes, 0, h->tslots * sizeof(WNode), h->stream));
 		}
 		HIPCHK(hipMemsetAsync(h->wside, 0, kWideSideSlots * sizeof(WNode), h->stream));
 	} else if (h->kfreq && !h->part) {
@@ -575,6 +743,7 @@ static int plan_partition(dbgk_handle *h)
 	G.n_final = (uint32_t)((h->size + kRegionSlots - 1) >> kRegionBits);
 	G.n_ranks = n_ranks;
 	G.rank = want_shard ? h->cfg.shard_index : 0;
+	h->shard_rank = G.rank;
 	G.B = (G.n1 + n_ranks - 1) / n_ranks;
 	G.n_sub = kSubStores;
 	G.b_lo = std::min(G.rank * G.B, G.n1);
@@ -731,7 +900,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	*out = nullptr;
 	const bool wide = cfg->engine == DBGK_ENGINE_WIDE;
 	if (cfg->kmer_size < 1 || cfg->kmer_size > (wide ? 63 : 32)) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100); WIDE: 128-bit keys
-	if (wide && (cfg->shard_count || cfg->flags)) return DBGK_ERR_ARG;
+	if (wide && cfg->flags) return DBGK_ERR_ARG;
 	if (cfg->max_read_len < cfg->kmer_size) return DBGK_ERR_ARG;
 	const bool kfreq = cfg->engine == DBGK_ENGINE_KFREQ;
 	if (kfreq && cfg->kmer_size > 18) return DBGK_ERR_ARG; // 4^18 bytes = 64 GiB
@@ -809,12 +978,14 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 			return fail(DBGK_ERR_NOMEM);
 		}
 	} else if (wide) {
-		if (hipMalloc(&h->wnodes, h->size * sizeof(WNode)) != hipSuccess || hipMalloc(&h->wside, kWideSideSlots * sizeof(WNode)) != hipSuccess) {
+		bool werr = false;
+		h->wpart = plan_wide_partition(h, &werr); // input size known: records first, the table region by region (a shard: its slot range only)
+		if (werr) return fail(DBGK_ERR_ARG);
+		if (hipMalloc(&h->wnodes, h->tslots * sizeof(WNode)) != hipSuccess || hipMalloc(&h->wside, kWideSideSlots * sizeof(WNode)) != hipSuccess) {
 			g_last_error = "hipMalloc of the wide k-mer table failed";
 			return fail(DBGK_ERR_NOMEM);
 		}
-		if (plan_wide_partition(h)) { // input size known: records first, the table in one pass at the end
-			h->wpart = true;
+		if (h->wpart) {
 			const int wrc = setup_wide_partition(h);
 			if (wrc != DBGK_OK) return fail(wrc);
 		}
@@ -1497,7 +1668,7 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 	out->total_kmers = c.total_kmers;
 	out->stored_kmers = c.stored_kmers;
 	// + the key-0 node, always present (DBGgraph.cpp:418); of a sharded table only shard 0 reports it
-	out->count = c.n_new + ((h->sharded && h->geom.rank != 0) ? 0 : 1);
+	out->count = c.n_new + ((h->sharded && h->shard_rank != 0) ? 0 : 1);
 	if (h->seed) out->count = c.n_new + (c.polyA_links ? 1 : 0); // key 0 is an ordinary key of the seed index
 	out->count_conflict = c.n_conflict;
 	out->table_slots = h->tslots;
@@ -1732,7 +1903,20 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (h->wpart && !h->finalized) {
-		if (!h->wbuilt && h->pending_kmers > 0) {
+		if (h->wmulti) { // shards / passes: the current pass is completed here, all passes must have run
+			if (h->wpass_open) {
+				rc = wide_end_pass(h);
+				if (rc) return rc;
+			}
+			if (h->wpasses_done != h->wgeom.n_passes) {
+				g_last_error = "dbgk_finalize: this WIDE handle reads its input in several passes (dbgk_wide_pass_info) and not all of them have run";
+				return DBGK_ERR_STATE;
+			}
+			if (!h->wbuilt) {
+				rc = wide_finish_records(h);
+				if (rc) return rc;
+			}
+		} else if (!h->wbuilt && h->pending_kmers > 0) {
 			rc = wide_build_from_records(h);
 			if (rc) return rc;
 		}
@@ -1987,7 +2171,7 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 	hipError_t e = hipMemsetAsync(d_out, 0, 16, h->stream);
 	if (e == hipSuccess) {
 		if (h->wide)
-			hipLaunchKernelGGL(k_wide_digest, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, d_out);
+			hipLaunchKernelGGL(k_wide_digest, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, h->wside, d_out);
 		else
 			hipLaunchKernelGGL(k_digest, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, d_out);
 		e = hipGetLastError();
@@ -1996,7 +2180,7 @@ extern "C" int dbgk_digest(dbgk_handle *h, uint64_t *digest)
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	(void)hipFree(d_out);
 	if (e != hipSuccess) return hip_fail(e, "digest", __LINE__);
-	*digest = res[0] + ((h->sharded && h->geom.rank != 0) ? 0ull : node_digest(0ull, h->h_ctr->polyA_links));
+	*digest = res[0] + ((h->sharded && h->shard_rank != 0) ? 0ull : node_digest(0ull, h->h_ctr->polyA_links));
 	return DBGK_OK;
 }
 
@@ -2015,11 +2199,11 @@ extern "C" int dbgk_link_stats_device(dbgk_handle *h, int32_t cutoff, dbgk_link_
 	hipError_t e = hipMemsetAsync(d_out, 0, bytes, h->stream);
 	if (e == hipSuccess) {
 		if (h->wide)
-			hipLaunchKernelGGL(k_wide_link_stats, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, (int)cutoff,
-			                   (uint64_t)h->h_ctr->polyA_links, d_out);
+			hipLaunchKernelGGL(k_wide_link_stats, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, h->wside, (int)cutoff,
+			                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->shard_rank != 0) ? 0 : 1, d_out);
 		else
 			hipLaunchKernelGGL(k_link_stats, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->table, h->tslots, (int)cutoff,
-			                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->geom.rank != 0) ? 0 : 1, d_out);
+			                   (uint64_t)h->h_ctr->polyA_links, (h->sharded && h->shard_rank != 0) ? 0 : 1, d_out);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(res, d_out, bytes, hipMemcpyDeviceToHost, h->stream);
@@ -2134,9 +2318,12 @@ extern "C" int dbgk_wide_export_sorted(dbgk_handle *h, dbgk_node32 *out, uint64_
 	int rc = use_device(h);
 	if (rc) return rc;
 	const uint64_t n = h->h_ctr->n_new; // non-zero keys (main + side table)
-	*n_out = n + 1;
-	if (capacity < n + 1) return DBGK_ERR_CAPACITY;
-	out[0] = dbgk_node32{0, 0, (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu), (uint32_t)(h->h_ctr->polyA_links >> 32), 0}; // key 0 sorts first
+	const uint64_t z = (h->sharded && h->shard_rank != 0) ? 0 : 1; // of a sharded table only shard 0 reports the key-0 node
+	*n_out = n + z;
+	if (capacity < n + z) return DBGK_ERR_CAPACITY;
+	if (z) out[0] = dbgk_node32{0, 0, (uint32_t)(h->h_ctr->polyA_links & 0xFFFFFFFFu), (uint32_t)(h->h_ctr->polyA_links >> 32), 0}; // key 0 sorts first
+	out += z;
+	out -= 1; // (the code below writes out[1 ..])
 	if (n == 0) return DBGK_OK;
 	dbgk_node32 *d_out = nullptr;
 	unsigned long long *d_cursor = nullptr;
@@ -2148,7 +2335,7 @@ extern "C" int dbgk_wide_export_sorted(dbgk_handle *h, dbgk_node32 *out, uint64_
 	unsigned long long found = 0;
 	hipError_t e = hipMemsetAsync(d_cursor, 0, 8, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_wide_compact, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, d_out, d_cursor, n);
+		hipLaunchKernelGGL(k_wide_compact, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, h->wside, d_out, d_cursor, n);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) e = hipMemcpyAsync(&found, d_cursor, 8, hipMemcpyDeviceToHost, h->stream);
@@ -2174,11 +2361,11 @@ extern "C" int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, d
 {
 	if (!h || !array || !nul_flag) return DBGK_ERR_ARG;
 	if (!h->wide || !h->finalized) return DBGK_ERR_STATE;
-	if (host_size != h->size) {
-		g_last_error = "dbgk_wide_export_host_table: host_size must be the handle's table_slots";
+	if (host_size != h->tslots) {
+		g_last_error = "dbgk_wide_export_host_table: host_size must be the handle's table_slots (a shard: the slots of its range)";
 		return DBGK_ERR_ARG;
 	}
-	if (h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
+	if (!h->sharded && h->h_ctr->n_new + 1 > host_size) return DBGK_ERR_TABLE_FULL;
 	int rc = use_device(h);
 	if (rc) return rc;
 	dbgk_node32 *d_img = nullptr;
@@ -2189,7 +2376,7 @@ extern "C" int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, d
 		(void)hipFree(d_img);
 		return DBGK_ERR_NOMEM;
 	}
-	hipLaunchKernelGGL(k_wide_image, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, d_img, d_flags);
+	hipLaunchKernelGGL(k_wide_image, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, d_img, d_flags);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(array, d_img, host_size * sizeof(dbgk_node32), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
@@ -2198,6 +2385,7 @@ extern "C" int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, d
 	(void)hipFree(d_img);
 	(void)hipFree(d_flags);
 	if (e != hipSuccess) return hip_fail(e, "wide_export_host_table", __LINE__);
+	if (h->sharded) return DBGK_OK; // a shard's slice as it is: side-table nodes and the key-0 node are placed over the WHOLE table by the caller
 	auto place = [&](dbgk_node32 nd) { // add_node_to_kmerset's rule (kmerSet.cpp:253-273): first slot without a flag on the key's chain
 		uint64_t hc = dbgk_wide::hash128(dbgk_wide::Key128{nd.kmer_hi, nd.kmer_lo}) % host_size;
 		while (nul_flag[hc >> 3] & (uint8_t)(128u >> (hc & 7u))) hc = (hc + 1 == host_size) ? 0 : hc + 1;
@@ -2223,7 +2411,7 @@ extern "C" int dbgk_wide_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk
 	std::vector<unsigned long long> hc(n_parts, 0);
 	hipError_t e = hipMemsetAsync(d_counts, 0, n_parts * 8, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, n_parts, d_counts,
+		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, h->wside, n_parts, d_counts,
 		                   (unsigned long long *)nullptr, (dbgk_node32 *)nullptr, (uint64_t)0);
 		e = hipGetLastError();
 	}
@@ -2253,7 +2441,7 @@ extern "C" int dbgk_wide_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk
 	e = hipMemcpyAsync(d_counts, cursors.data(), n_parts * 8, hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->wnodes, h->size, h->wside, n_parts,
+		hipLaunchKernelGGL(k_wide_partition, dim3(grid_for(h, h->tslots)), dim3(kBlock), 0, h->stream, h->wnodes, h->tslots, h->wside, n_parts,
 		                   (unsigned long long *)nullptr, d_counts, d_nodes, capacity);
 		e = hipGetLastError();
 	}
@@ -2540,9 +2728,29 @@ extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_han
 // ---------------------------------------------------------------------------------------------
 extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 {
-	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table
 	if (!h || !out) return DBGK_ERR_ARG;
+	if (h->wide) { // 16-byte records; the buffers are those of the CURRENT pass (dbgk_wide_pass_info)
+		if (!h->wpart || !h->wmulti) return DBGK_ERR_STATE;
+		const WPartGeom &G = h->wgeom;
+		memset(out, 0, sizeof(*out));
+		out->n_ranks = G.n_ranks;
+		out->rank = G.rank;
+		out->slot_lo = G.slot_lo;
+		out->slot_hi = G.slot_hi;
+		out->table_slots_global = h->size;
+		out->buckets_per_rank = G.Bp;
+		out->own_buckets = wide_pass_buckets(h);
+		out->bucket_bytes = G.cap1 * 16;
+		out->cnt_bucket_bytes = 4;
+		out->chunk_bytes = (uint64_t)G.Bp * G.cap1 * 16;
+		out->cnt_chunk_bytes = (uint64_t)G.Bp * 4;
+		out->d_send = h->wstore.l1;
+		out->d_send_cnt = h->wstore.cnt1;
+		out->d_recv = h->sharded ? (void *)h->winbox : (void *)h->wstore.l1;
+		out->d_recv_cnt = h->sharded ? (void *)h->winbox_cnt : (void *)h->wstore.cnt1;
+		return DBGK_OK;
+	}
 	if (!h->part) return DBGK_ERR_STATE;
 	const PartGeom &G = h->geom;
 	memset(out, 0, sizeof(*out));
@@ -2566,7 +2774,7 @@ extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 
 extern "C" int dbgk_shard_mark_exchanged(dbgk_handle *h)
 {
-	if (!h || !h->sharded) return DBGK_ERR_STATE;
+	if (!h || !(h->sharded || (h->wide && h->wmulti))) return DBGK_ERR_STATE;
 	h->exchanged = true;
 	return DBGK_OK;
 }
@@ -2574,6 +2782,12 @@ extern "C" int dbgk_shard_mark_exchanged(dbgk_handle *h)
 extern "C" int dbgk_shard_plan(dbgk_handle *h)
 {
 	if (!h) return DBGK_ERR_ARG;
+	if (h->wide) {
+		if (!h->wmulti || !h->wpass_open || h->finalized) return DBGK_ERR_STATE;
+		int wrc = use_device(h);
+		if (wrc) return wrc;
+		return wide_plan_pass(h);
+	}
 	if (!h->part || h->part_built || h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
@@ -2583,6 +2797,13 @@ extern "C" int dbgk_shard_plan(dbgk_handle *h)
 extern "C" int dbgk_shard_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1)
 {
 	if (!h) return DBGK_ERR_ARG;
+	if (h->wide) { // own-bucket indices of the current pass, in order
+		if (!h->wmulti || !h->wpass_open || !h->wplanned || h->finalized) return DBGK_ERR_STATE;
+		if (j0 != h->wnext || j1 < j0 || j1 > wide_pass_buckets(h)) return DBGK_ERR_ARG;
+		int wrc = use_device(h);
+		if (wrc) return wrc;
+		return j1 > j0 ? wide_build_range(h, j0, j1) : DBGK_OK;
+	}
 	if (!h->part || !h->part_planned || h->part_built || h->finalized) return DBGK_ERR_STATE;
 	if (j0 != h->next_bucket || j1 < j0 || j1 > h->geom.nb_own) return DBGK_ERR_ARG; // ranges are consumed in order, each bucket once
 	int rc = use_device(h);
@@ -2590,10 +2811,10 @@ extern "C" int dbgk_shard_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1)
 	return part_build_range(h, j0, j1, true);
 }
 
-static int shard_list(dbgk_handle *h, Node *list, unsigned long long *d_n, uint64_t cap, dbgk_node **d_nodes, uint64_t *n)
+static int shard_list(dbgk_handle *h, void *list, unsigned long long *d_n, uint64_t cap, dbgk_node **d_nodes, uint64_t *n)
 {
 	if (!h || !d_nodes || !n) return DBGK_ERR_ARG;
-	if (!h->part || !h->finalized) return DBGK_ERR_STATE;
+	if (!(h->part || (h->wide && h->wmulti)) || !h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
 	unsigned long long v = 0;
@@ -2601,25 +2822,33 @@ static int shard_list(dbgk_handle *h, Node *list, unsigned long long *d_n, uint6
 	HIPCHK(hipStreamSynchronize(h->stream));
 	*d_nodes = reinterpret_cast<dbgk_node *>(list);
 	*n = v < cap ? v : cap;
-	if (list == h->store.ovf) return DBGK_OK; // the surplus beyond the list was aggregated in the side table (dbgk_shard_heavy)
+	if (!h->wide && list == (void *)h->store.ovf) return DBGK_OK; // the surplus beyond the list was aggregated in the side table (dbgk_shard_heavy)
 	return v > cap ? DBGK_ERR_CAPACITY : DBGK_OK;
 }
 
+// (WIDE handles: the lists hold 32-byte dbgk_node32 entries -- nodes {hi, lo, l_link, r_link} / observations {hi, lo, lb, rb})
 extern "C" int dbgk_shard_outgoing(dbgk_handle *h, dbgk_node **d_nodes, uint64_t *n)
 {
 	if (!h) return DBGK_ERR_ARG;
+	if (h->wide) return shard_list(h, h->wstore.outgoing, h->wstore.outgoing_n, h->wstore.outgoing_cap, d_nodes, n);
 	return shard_list(h, h->store.outgoing, h->store.outgoing_n, h->store.outgoing_cap, d_nodes, n);
 }
 
 extern "C" int dbgk_shard_overflow(dbgk_handle *h, dbgk_node **d_triples, uint64_t *n)
 {
 	if (!h) return DBGK_ERR_ARG;
+	if (h->wide) return shard_list(h, h->wstore.ovf, &h->wstore.ovf_n[0], h->wstore.ovf_cap, d_triples, n);
 	return shard_list(h, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, d_triples, n);
 }
 
 extern "C" int dbgk_shard_heavy(dbgk_handle *h, dbgk_node **d_table, uint64_t *n_slots)
 {
 	if (!h || !d_table || !n_slots) return DBGK_ERR_ARG;
+	if (h->wide) { // no side table of aggregated surplus in the wide path: a full overflow list is DBGK_ERR_CAPACITY at finalize
+		*d_table = nullptr;
+		*n_slots = 0;
+		return (h->wmulti && h->finalized) ? DBGK_OK : DBGK_ERR_STATE;
+	}
 	if (!h->part || !h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
@@ -2634,18 +2863,93 @@ extern "C" int dbgk_shard_heavy(dbgk_handle *h, dbgk_node **d_table, uint64_t *n
 extern "C" int dbgk_shard_merge(dbgk_handle *h, const dbgk_node *d_nodes, uint64_t n, int is_triple, int from_previous_shard)
 {
 	if (!h || (n && !d_nodes)) return DBGK_ERR_ARG;
-	if (!h->sharded || !h->finalized) return DBGK_ERR_STATE;
+	if (!(h->sharded || (h->wide && h->wmulti)) || !h->finalized) return DBGK_ERR_STATE;
 	int rc = use_device(h);
 	if (rc) return rc;
 	if (n == 0) return DBGK_OK;
 	TimedSpan sp;
 	rc = span_begin(h, PH_FIXUP, sp);
 	if (rc) return rc;
+	if (h->wide) {
+		hipLaunchKernelGGL(k_wide_merge_sharded, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, reinterpret_cast<const dbgk_node32 *>(d_nodes),
+		                   (const unsigned long long *)nullptr, n, n, is_triple ? 1 : 0, from_previous_shard ? 1 : 0, h->wgeom, h->wstore, h->wnodes, h->d_ctr);
+		HIPCHK(hipGetLastError());
+		return span_end(h, sp);
+	}
 	hipLaunchKernelGGL(k_merge_sharded, dim3(grid_for(h, n)), dim3(kBlock), 0, h->stream, reinterpret_cast<const Node *>(d_nodes),
 	                   (const unsigned long long *)nullptr, n, n, is_triple ? 1 : 0, from_previous_shard ? 1 : 0, h->geom, h->store, h->table,
 	                   h->d_ctr);
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp);
+}
+
+extern "C" int dbgk_wide_pass_info(dbgk_handle *h, uint32_t *n_passes, uint32_t *passes_done)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->wide) return DBGK_ERR_STATE;
+	if (n_passes) *n_passes = h->wpart ? h->wgeom.n_passes : 1u;
+	if (passes_done) *passes_done = h->wpart ? h->wpasses_done : 0u;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_wide_begin_pass(dbgk_handle *h, uint32_t pass)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->wide || !h->wpart || h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (pass == 0 && h->wpass_open && h->wpasses_done == 0 && h->pending_kmers == 0) return DBGK_OK; // pass 0 is open after create / reset
+	return wide_begin_pass(h, pass);
+}
+
+extern "C" int dbgk_wide_end_pass(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->wide || !h->wpart || !h->wmulti || h->finalized || !h->wpass_open) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	return wide_end_pass(h);
+}
+
+extern "C" int dbgk_shard_side_export(dbgk_handle *h, dbgk_node32 **d_nodes, uint64_t *n)
+{
+	if (!h || !d_nodes || !n) return DBGK_ERR_ARG;
+	if (!h->wide || !h->wmulti || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	HIPCHK(hipMemsetAsync(h->w_side_n, 0, 8, h->stream));
+	hipLaunchKernelGGL(k_wide_side_export, dim3(16), dim3(kBlock), 0, h->stream, h->wside, h->d_ctr, h->w_side_out, h->w_side_n, (uint64_t)kWideSideSlots + 1);
+	HIPCHK(hipGetLastError());
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, h->w_side_n, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	*d_nodes = h->w_side_out;
+	*n = v + 1; // + the key-0 node in front
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_shard_side_clear(dbgk_handle *h)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (!h->wide || !h->wmulti || !h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	// the claims in the side table were counted as new keys of this handle: take them back with the table
+	HIPCHK(hipMemsetAsync(h->w_side_n, 0, 8, h->stream));
+	hipLaunchKernelGGL(k_wide_side_export, dim3(16), dim3(kBlock), 0, h->stream, h->wside, h->d_ctr, h->w_side_out, h->w_side_n, (uint64_t)kWideSideSlots + 1);
+	HIPCHK(hipGetLastError());
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, h->w_side_n, 8, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	Counters c;
+	HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	c.n_new -= v;
+	c.polyA_links = 0;
+	HIPCHK(hipMemcpyAsync(h->d_ctr, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemsetAsync(h->wside, 0, kWideSideSlots * sizeof(WNode), h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
 }
 
 extern "C" int dbgk_add_polyA(dbgk_handle *h, uint32_t l_link, uint32_t r_link)

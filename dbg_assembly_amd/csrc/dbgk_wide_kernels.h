@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_digest(const WNode *__restrict_
 
 // first pass of calculate_kmer_links (contig.cpp:119-181) on the wide table; layout of `out` as k_link_stats
 __global__ __launch_bounds__(kBlock) void k_wide_link_stats(const WNode *__restrict__ nodes, uint64_t size, const WNode *__restrict__ side, int cutoff,
-                                                            uint64_t polyA_links, unsigned long long *__restrict__ out)
+                                                            uint64_t polyA_links, int with_key0, unsigned long long *__restrict__ out)
 {
 	__shared__ unsigned int hist[256];
 	__shared__ unsigned long long red[kBlock / 64];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_link_stats(const WNode *__restr
 		const bool occ = i < size ? nd.lo != 0ull : nd.hi1 != 0ull;
 		if (occ) link_classes(nd.links, cutoff, hist, cls);
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) link_classes(polyA_links, cutoff, hist, cls); // the key-0 node
+	if (with_key0 && blockIdx.x == 0 && threadIdx.x == 0) link_classes(polyA_links, cutoff, hist, cls); // the key-0 node (of a sharded table: shard 0 only)
 	__syncthreads();
 	if (hist[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 #pragma unroll

@@ -35,23 +35,52 @@ constexpr int kWL2Records = kWL2Threads * 8;
 constexpr int kWBuildThreads = 512;              // three workgroups per CU (51 KiB of LDS each)
 
 struct WPartGeom {
-	uint64_t size;
+	uint64_t size;       // slots of the (GLOBAL) table: slot = hash128(key) % size
 	ModMagic magic;
 	Div32Magic div;      // size < 2^32: exact 64/32 division (dbgk_device.h)
 	uint32_t r;          // level-1 bucket = slot >> r
-	uint32_t n1;         // ceil(size / 2^r) <= 1024
+	uint32_t n1;         // ceil(size / 2^r): level-1 buckets of the whole table (any number, see passes)
 	uint32_t n2;         // 2^(r - 11)       <= 2048
 	uint32_t n_regions;  // ceil(size / 2048)
 	uint32_t chunk_buckets; // level-1 buckets whose final buckets the level-2 store holds at a time (level 2 and the build
 	                        // walk the level-1 buckets chunk by chunk: the level-2 store is 1/8 of the records, not all)
 	uint64_t cap1, cap2; // records per level-1 / final bucket
+	// SHARDS (several GPUs, dbgk_config.shard_count): rank d owns the level-1 buckets [d * B, (d + 1) * B) of the global table,
+	// i.e. the slot range [slot_lo, slot_hi), and holds only that part of the table (the device analogue of the reference's
+	// `kmer % threadNum` ownership, DBGgraph.cpp:148, as in the 64-bit engine).  n_ranks == 1: the whole table.
+	// PASSES: the level-1 kernel fans out to at most 1024 buckets and the record stores must fit the device, so a big job reads
+	// its input n_passes times (the way disk-based k-mer counters pass over their input once per set of partitions); pass p
+	// keeps the records of the own-bucket indices [p * Bp, (p + 1) * Bp) of EVERY rank and drops the rest, level 2 and the
+	// region build then complete those buckets.  n_passes == 1 and n_ranks == 1: level-1 store index == global bucket.
+	uint32_t n_ranks, rank;
+	uint32_t B;          // level-1 buckets per rank = ceil(n1 / n_ranks)
+	uint32_t bmagic;     // ceil(2^32 / B): (b * bmagic) >> 32 == b / B for b < 65536
+	uint32_t b_lo, nb_own; // this rank's buckets [b_lo, b_lo + nb_own)
+	uint32_t n_passes, pass;
+	uint32_t Bp;         // own-bucket indices per pass = ceil(B / n_passes)
+	uint32_t pass_j0;    // pass * Bp
+	uint32_t n_l1;       // n_ranks * Bp <= 1024: level-1 fan-out of a pass; store entry of (rank d, own index pass_j0 + jj) = d * Bp + jj
+	uint64_t slot_lo, slot_hi;
 };
+
+// global level-1 bucket of store entry e of the current pass
+__device__ __forceinline__ uint32_t wide_entry_bucket(uint32_t e, const WPartGeom &G)
+{
+	if (G.n_l1 == G.n1) return e; // one rank, one pass
+	const uint32_t d = e / G.Bp;
+	return d * G.B + G.pass_j0 + (e - d * G.Bp);
+}
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
 struct WPartStore {
-	ull2 *l1;                     // [n1][cap1]
-	uint32_t *cnt1;               // [n1] records appended (may exceed cap1: the excess went to ovf)
+	ull2 *l1;                     // [n_l1][cap1]: what this rank extracted in the current pass, by destination rank and own-bucket index
+	uint32_t *cnt1;               // [n_l1] records appended (may exceed cap1: the excess went to ovf)
+	const ull2 *inbox;            // [n_l1][cap1]: entry s * Bp + jj = rank s's records for MY bucket pass_j0 + jj (n_ranks == 1: == l1)
+	const uint32_t *inbox_cnt;    // [n_l1]
+	dbgk_node32 *outgoing;        // shards: nodes whose probe ran off the end of this shard, for the next rank
+	unsigned long long *outgoing_n;
+	uint64_t outgoing_cap;
 	ull2 *l2;                     // [chunk_buckets * n2][cap2]: the final buckets of ONE chunk of level-1 buckets at a time
 	uint32_t *cnt2;               // [chunk_buckets * n2]
 	dbgk_node32 *ovf;             // observations that found their bucket full: {hi, lo, lb, rb}
@@ -239,7 +268,16 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 			bucket = slot_lo >> G.r;
 		}
 		const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & K.rmask) << 6) | links;
-		const uint32_t b = (valid && key.lo != 0ull) ? bucket : 1024u + (tid & 63u);
+		// store entry of the bucket: (owner rank, own-bucket index inside this pass's window); other passes' buckets are dropped
+		uint32_t entry = bucket;
+		bool keep = true;
+		if (G.n_l1 != G.n1) {
+			const uint32_t d = (uint32_t)(((uint64_t)bucket * G.bmagic) >> 32);
+			const uint32_t jj = bucket - d * G.B - G.pass_j0;
+			keep = jj < G.Bp;
+			entry = d * G.Bp + jj;
+		}
+		const uint32_t b = (valid && key.lo != 0ull && keep) ? entry : 1024u + (tid & 63u);
 		L.stage[i * kWL1Threads + tid] = ull2{key.hi, w};
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 		// roll to the next position
@@ -262,7 +300,7 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 		if (fwd_strand ? nr : nl) rbb = 4u;
 		rec.y = (rec.y & ~63ull) | (lb << 3) | rbb;
 		if ((zero_lo >> i) & 1u) {
-			wide_insert(T, Key128{rec.x, 0ull}, lb, rbb, ctr, n_new, n_conf, full);
+			if (G.pass == 0u) wide_insert(T, Key128{rec.x, 0ull}, lb, rbb, ctr, n_new, n_conf, full); // (once per job: the input is read once per pass)
 		} else {
 			L.stage[i * kWL1Threads + tid] = rec;
 		}
@@ -277,7 +315,7 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 #pragma unroll
 	for (uint32_t i = 0; i < 8u; i++) rec[i] = L.stage[i * kWL1Threads + fresh_tid()];
 	uint32_t my_gbase[1];
-	scatter_reserve_scan(L, G.n1, P.cnt1, my_gbase);
+	scatter_reserve_scan(L, G.n_l1, P.cnt1, my_gbase);
 #pragma unroll
 	for (uint32_t i = 0; i < 8u; i++)
 		if ((bkt[i] >> 16) < 1024u) {
@@ -292,7 +330,7 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 	// instruction the same whatever its lane count (dbgk_partition.h)
 	{
 		const uint32_t t = fresh_tid();
-		const uint32_t total = L.lbase[G.n1 - 1u] + L.hist[G.n1 - 1u];
+		const uint32_t total = L.lbase[G.n_l1 - 1u] + L.hist[G.n_l1 - 1u];
 #pragma unroll
 		for (uint32_t u = 0; u < 8u; u++) {
 			const uint32_t p = u * kWL1Threads + t;
@@ -303,7 +341,7 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 			if (off < G.cap1) {
 				P.l1[(uint64_t)b * G.cap1 + off] = rcd;
 			} else { // the bucket is full
-				wide_push_overflow(P, wide_record_key(rcd, b, G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
+				wide_push_overflow(P, wide_record_key(rcd, wide_entry_bucket(b, G), G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
 			}
 		}
 	}
@@ -474,12 +512,25 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 }
 
 // ---- level 2 --------------------------------------------------------------------------------------
-// tile_prefix[b] = tiles of the level-1 buckets before b (kWL2Records records per tile), tile_prefix[n1] = all
-__global__ __launch_bounds__(1024) void k_wide_l2_plan(WPartGeom G, const uint32_t *__restrict__ cnt1, uint32_t *__restrict__ tile_prefix)
+// The inbox entries of the current pass flattened OWN-BUCKET-MAJOR, f = jj * n_ranks + s (records of rank s for my bucket
+// pass_j0 + jj): a range of own buckets is a contiguous range of tiles.  tile_prefix[f] = tiles (kWL2Records records each) of
+// the flat entries before f, tile_prefix[n_l1] = all.
+__device__ __forceinline__ uint32_t wide_flat_entry(const WPartGeom &G, uint32_t f, uint32_t &jj)
+{
+	jj = f / G.n_ranks;
+	return (f - jj * G.n_ranks) * G.Bp + jj;
+}
+
+__global__ __launch_bounds__(1024) void k_wide_l2_plan(WPartGeom G, const uint32_t *__restrict__ inbox_cnt, uint32_t *__restrict__ tile_prefix)
 {
 	__shared__ uint32_t wave_tot[16];
 	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-	const uint64_t filled = t < G.n1 ? (cnt1[t] < G.cap1 ? cnt1[t] : G.cap1) : 0ull;
+	uint64_t filled = 0;
+	if (t < G.n_l1) {
+		uint32_t jj;
+		const uint32_t e = wide_flat_entry(G, t, jj);
+		if (G.pass_j0 + jj < G.nb_own) filled = inbox_cnt[e] < G.cap1 ? inbox_cnt[e] : G.cap1; // (the last rank may own fewer buckets)
+	}
 	const uint32_t tiles = (uint32_t)((filled + kWL2Records - 1) / kWL2Records);
 	uint32_t inc = tiles;
 #pragma unroll
@@ -491,32 +542,35 @@ __global__ __launch_bounds__(1024) void k_wide_l2_plan(WPartGeom G, const uint32
 	__syncthreads();
 	uint32_t run = inc - tiles;
 	for (uint32_t w = 0; w < wave; w++) run += wave_tot[w];
-	if (t < G.n1) tile_prefix[t] = run;
-	if (t == G.n1 - 1u) tile_prefix[G.n1] = run + tiles;
+	if (t < G.n_l1) tile_prefix[t] = run;
+	if (t == G.n_l1 - 1u) tile_prefix[G.n_l1] = run + tiles;
 }
 
 template <int MAXB>
 __global__ __launch_bounds__(kWL2Threads) void k_wide_scatter_l2(WPartGeom G, WPartStore P, const uint32_t *__restrict__ tile_prefix, Counters *__restrict__ ctr,
-                                                                uint32_t j0, uint32_t j1) // the level-1 buckets [j0, j1) of this chunk
+                                                                uint32_t j0, uint32_t j1) // the own buckets pass_j0 + [j0, j1) of this chunk
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	WL2Lds<MAXB> &L = *reinterpret_cast<WL2Lds<MAXB> *>(lds_raw);
 	constexpr int kBpt = WL2Lds<MAXB>::kBpt;
-	const uint32_t first_tile = tile_prefix[j0], span = tile_prefix[j1] - first_tile;
+	const uint32_t f0 = j0 * G.n_ranks, f1 = j1 * G.n_ranks; // flat entries of the chunk
+	const uint32_t first_tile = tile_prefix[f0], span = tile_prefix[f1] - first_tile;
 	// XCD-aware tile order (see k_scatter_l2): XCD x takes the x-th eighth of the tile range, so that the appends to a
 	// final bucket come through ONE L2 and merge into full lines there
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, n_local = gridDim.x >> 3; // gridDim.x is a multiple of 8
 	const uint32_t lo_tile = first_tile + (uint32_t)(((uint64_t)span * xcd) >> 3), hi_tile = first_tile + (uint32_t)(((uint64_t)span * (xcd + 1u)) >> 3);
 	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
-		uint32_t lo = j0, hi = j1; // last bucket with tile_prefix[b] <= g (empty buckets repeat the prefix: take the last)
+		uint32_t lo = f0, hi = f1; // last flat entry with tile_prefix[f] <= g (empty entries repeat the prefix: take the last)
 		while (hi - lo > 1u) {
 			const uint32_t mid = (lo + hi) >> 1;
 			if (tile_prefix[mid] <= g) lo = mid; else hi = mid;
 		}
-		const uint32_t b1 = lo;
-		const uint64_t filled = P.cnt1[b1] < G.cap1 ? P.cnt1[b1] : G.cap1;
-		const uint64_t first = (uint64_t)(g - tile_prefix[b1]) * kWL2Records;
-		const ull2 *in = P.l1 + (uint64_t)b1 * G.cap1;
+		uint32_t jj;
+		const uint32_t e = wide_flat_entry(G, lo, jj);
+		const uint32_t b1 = G.b_lo + G.pass_j0 + jj; // global level-1 bucket
+		const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
+		const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kWL2Records;
+		const ull2 *in = P.inbox + (uint64_t)e * G.cap1;
 		const uint32_t t = fresh_tid();
 		ull2 rec[8];
 		uint32_t bkt[8];
@@ -534,7 +588,7 @@ __global__ __launch_bounds__(kWL2Threads) void k_wide_scatter_l2(WPartGeom G, WP
 		for (int u = 0; u < 8; u++) bkt[u] = (bkt[u] << 16) | ((bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u);
 		lds_barrier();
 		uint32_t my_gbase[kBpt];
-		scatter_reserve_scan(L, G.n2, P.cnt2 + (uint64_t)(b1 - j0) * G.n2, my_gbase);
+		scatter_reserve_scan(L, G.n2, P.cnt2 + (uint64_t)(jj - j0) * G.n2, my_gbase);
 #pragma unroll
 		for (int u = 0; u < 8; u++)
 			if ((bkt[u] >> 16) < (uint32_t)MAXB) L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(kWL2Threads) void k_wide_scatter_l2(WPartGeom G, WP
 			// the final bucket of a staged record can be recomputed from the record: walk the sorted stage linearly, one
 			// record per lane, every lane busy
 			const uint32_t total = L.lbase[G.n2 - 1u] + L.hist[G.n2 - 1u];
-			ull2 *out = P.l2 + (uint64_t)(b1 - j0) * G.n2 * G.cap2;
+			ull2 *out = P.l2 + (uint64_t)(jj - j0) * G.n2 * G.cap2;
 #pragma unroll
 			for (int u = 0; u < 8; u++) {
 				const uint32_t p = (uint32_t)u * kWL2Threads + t;
@@ -577,8 +631,10 @@ struct WBuildLds {
 // publishes hi + 1.  A record whose ident matches compares the high word too (two keys may share hash128): a lane
 // that finds it unpublished looks again -- the winner's store follows its CAS in program order, so lanes of one
 // wave never wait on each other, and another wave publishes without waiting for anybody.
+// `table` holds this handle's slot range [slot_lo, slot_hi); the launch covers the final buckets of the own buckets
+// pass_j0 + [j0, j0 + n_regions / n2) whose records level 2 has just put into the level-2 store.
 __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom G, WPartStore P, WNode *__restrict__ table, Counters *__restrict__ ctr,
-                                                                     unsigned int *__restrict__ cursor, uint32_t first_region, uint32_t n_regions)
+                                                                     unsigned int *__restrict__ cursor, uint32_t j0, uint32_t n_regions)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	WBuildLds &L = *reinterpret_cast<WBuildLds *>(lds_raw);
@@ -594,15 +650,15 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 	for (;;) {
 		if (t == 0) {
 			const unsigned int kx = atomicAdd(cursor, 1u);
-			L.next_region = kx < n_regions ? first_region + kx : kNone;
+			L.next_region = kx < n_regions ? kx : kNone;
 		}
 		lds_barrier(); // also: the image is empty
-		const uint32_t f = __builtin_amdgcn_readfirstlane(L.next_region);
-		if (f == kNone) break;
-		const uint32_t b1 = f >> (G.r - kWRegionBits);
-		const uint64_t region_slot0 = (uint64_t)f << kWRegionBits;
-		const uint32_t region_len = (uint32_t)((G.size - region_slot0 < (uint64_t)kWRegionSlots) ? G.size - region_slot0 : kWRegionSlots);
-		const uint32_t fl = f - first_region; // the level-2 store holds this chunk's final buckets only
+		const uint32_t fl = __builtin_amdgcn_readfirstlane(L.next_region); // final bucket inside the chunk's level-2 store
+		if (fl == kNone) break;
+		const uint32_t b1 = G.b_lo + G.pass_j0 + j0 + (fl >> (G.r - kWRegionBits)); // global level-1 bucket
+		const uint64_t region_slot0 = ((uint64_t)b1 << G.r) + ((uint64_t)(fl & (G.n2 - 1u)) << kWRegionBits); // global slot of the region's first entry
+		// (the table -- or this shard -- may end inside, or before, the last bucket's regions)
+		const uint32_t region_len = region_slot0 >= G.slot_hi ? 0u : (uint32_t)((G.slot_hi - region_slot0 < (uint64_t)kWRegionSlots) ? G.slot_hi - region_slot0 : kWRegionSlots);
 		const uint32_t filled = (uint32_t)(P.cnt2[fl] < G.cap2 ? P.cnt2[fl] : G.cap2);
 		const ull2 *in = P.l2 + (uint64_t)fl * G.cap2;
 		for (uint32_t base = 0; base < filled; base += kWBuildThreads) {
@@ -672,7 +728,7 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 				L.links[i] = 0ull;
 			}
 			if (i < region_len) {
-				ull2 *dst = reinterpret_cast<ull2 *>(&table[region_slot0 + i]);
+				ull2 *dst = reinterpret_cast<ull2 *>(&table[region_slot0 - G.slot_lo + i]);
 				dst[0] = ull2{nd.hi1, nd.lo};
 				dst[1] = ull2{nd.links, 0ull};
 			} else if (id) { // probed past the region end: merged after all regions exist
@@ -746,6 +802,107 @@ __global__ __launch_bounds__(kBlock) void k_wide_merge_spill(const dbgk_node32 *
 		if (b) atomicAdd(&ctr->n_conflict, b);
 	}
 	if (full) atomicOr(&ctr->error, 1u);
+}
+
+// ---- shards: probing confined to the handle's slot range -------------------------------------------------------------
+// wide_find_or_claim (dbgk_wide_kernels.h) on the shard-local array, without wrap-around: the local index, or ~0 when the
+// probe reaches slot_hi (the node then continues at the first slot of the next shard)
+__device__ __forceinline__ uint64_t wide_find_or_claim_range(WNode *nodes, uint64_t slot_lo, uint64_t slot_hi, Key128 key, uint64_t slot,
+                                                             uint64_t &links_guess, unsigned long long &n_new, unsigned long long &n_conf)
+{
+	uint64_t spins = 0;
+	while (slot < slot_hi) {
+		WNode *nd = &nodes[slot - slot_lo];
+		unsigned long long w0 = wload(&nd->lo);
+		if (w0 == 0ull) {
+			const unsigned long long prev = atomicCAS(&nd->lo, 0ull, (unsigned long long)key.lo);
+			if (prev == 0ull) {
+				wstore(&nd->hi1, key.hi + 1ull);
+				n_new++;
+				links_guess = 0ull;
+				return slot - slot_lo;
+			}
+			w0 = prev;
+		}
+		if (w0 == key.lo) {
+			const unsigned long long h1 = wload(&nd->hi1);
+			if (h1 == 0ull && ++spins < (1ull << 24)) continue; // its owner is about to publish the high word: look again
+			if (h1 == key.hi + 1ull) {
+				links_guess = wload(&nd->links);
+				return slot - slot_lo;
+			}
+		}
+		n_conf++;
+		slot++;
+	}
+	return ~0ull;
+}
+
+// Merge nodes (is_obs == 0: {hi, lo, l_link, r_link}) or single observations (is_obs == 1: {hi, lo, lb, rb}) into this shard.
+// An entry whose home slot lies in another shard is skipped unless start_foreign_at_lo (nodes handed over by the previous
+// shard continue their probe at this shard's first slot).  Nodes whose probe runs off the end of the shard are appended to
+// P.outgoing for the next rank.  A key-0 node is folded into the handle's side node; keys with a zero low word never come
+// this way (they are no records: side table, gathered onto rank 0 separately).
+__global__ __launch_bounds__(kBlock) void k_wide_merge_sharded(const dbgk_node32 *__restrict__ in, const unsigned long long *__restrict__ n_ptr, uint64_t n_direct,
+                                                               uint64_t cap, int is_obs, int start_foreign_at_lo, WPartGeom G, WPartStore P,
+                                                               WNode *__restrict__ table, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n_new = 0, n_conf = 0;
+	uint64_t n = n_ptr ? (uint64_t)*n_ptr : n_direct;
+	if (n > cap) n = cap;
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+		const dbgk_node32 nd = in[i];
+		const Key128 key{nd.kmer_hi, nd.kmer_lo};
+		const uint64_t add = is_obs ? dbgk_wide::observe(0ull, nd.l_link, nd.r_link) : ((uint64_t)nd.l_link | ((uint64_t)nd.r_link << 32));
+		if (dbgk_wide::is_zero(key)) {
+			links_cas_merge(&ctr->polyA_links, 0ull, add);
+			continue;
+		}
+		if (key.lo == 0ull) continue;
+		const uint64_t home = fast_mod(dbgk_wide::hash128(key), G.magic);
+		const bool mine = home >= G.slot_lo && home < G.slot_hi;
+		if (!mine && !start_foreign_at_lo) continue;
+		uint64_t guess;
+		const uint64_t idx = wide_find_or_claim_range(table, G.slot_lo, G.slot_hi, key, mine ? home : G.slot_lo, guess, n_new, n_conf);
+		if (idx == ~0ull) {
+			const unsigned long long j = atomicAdd(P.outgoing_n, 1ull);
+			if (j < P.outgoing_cap) {
+				dbgk_node32 o = nd;
+				o.l_link = (uint32_t)add;
+				o.r_link = (uint32_t)(add >> 32);
+				P.outgoing[j] = o;
+			} else {
+				atomicOr(&ctr->error, 2u);
+			}
+			continue;
+		}
+		links_cas_merge(&table[idx].links, guess, add);
+	}
+	const unsigned long long a = block_sum(n_new, red);
+	const unsigned long long b = block_sum(n_conf, red);
+	if (threadIdx.x == 0) {
+		if (a) atomicAdd(&ctr->n_new, a);
+		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+}
+
+// the side table (keys with a zero low word) and the key-0 links as a dense list of host-layout nodes: out[0] = the key-0 node
+// (always), then the occupied side slots; *n_out = entries written
+__global__ __launch_bounds__(kBlock) void k_wide_side_export(const WNode *__restrict__ side, const Counters *__restrict__ ctr, dbgk_node32 *__restrict__ out,
+                                                             unsigned long long *__restrict__ n_out, uint64_t cap)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		const unsigned long long links = ctr->polyA_links;
+		out[0] = dbgk_node32{0ull, 0ull, (uint32_t)links, (uint32_t)(links >> 32), 0ull};
+	}
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < kWideSideSlots; i += gridDim.x * kBlock) {
+		const WNode nd = side[i];
+		if (nd.hi1 == 0ull) continue;
+		const unsigned long long j = 1ull + atomicAdd(n_out, 1ull);
+		if (j < cap) out[j] = dbgk_node32{nd.hi1 - 1ull, 0ull, (uint32_t)nd.links, (uint32_t)(nd.links >> 32), 0ull};
+	}
 }
 
 } // namespace dbgk

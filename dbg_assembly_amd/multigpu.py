@@ -220,23 +220,23 @@ def _exchange_range(send, recv, info, j0, j1, world, rank, group):
     exchange_slices(pairs, rank, group)
 
 
-def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
-    """g: a sharded capi.Graph (shard_count == world, shard_index == rank) that has received all its
-    pushes.  Performs steps 1-5 and returns the global totals; afterwards g's table holds this
-    rank's slot range of the global table.  `wrap(ptr, nbytes, device)` turns the library's buffers
-    into tensors (default: zero-copy CUDA array interface; the gloo CPU test passes a host wrapper).
-    exchange_chunks <= 1: one all-to-all of the whole stores, then the build."""
-    wrap_device_memory = wrap or globals()["wrap_device_memory"]
+def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
+    """steps 1-2 for the level-1 record stores of the current step (64-bit engine) or pass (WIDE engine): all-reduce of the
+    per-bucket record counts, all-to-all of the fill counts and of the bucket stores in pieces, every piece built
+    (dbgk_shard_build_range) as soon as it has arrived.  verify: every rank checksums what it sends to each peer and what it
+    received from each peer (64-bit wrapping sums over the transferred slices) and the two sides are compared -- a transfer
+    that silently moved only part of a message (seen once on this RCCL build with a single 3.5 GB all_to_all_single) fails
+    loudly instead of building a wrong table.  Returns the number of records of the whole job in this step / pass."""
     on_gpu = torch.device(device).type == "cuda"
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     info = g.shard_info()
     assert info.n_ranks == world and info.rank == rank, (info.n_ranks, info.rank, world, rank)
     g.sync()
-    send = wrap_device_memory(info.d_send, world * info.chunk_bytes, device)
-    recv = wrap_device_memory(info.d_recv, world * info.chunk_bytes, device)
-    send_cnt = wrap_device_memory(info.d_send_cnt, world * info.cnt_chunk_bytes, device)
-    recv_cnt = wrap_device_memory(info.d_recv_cnt, world * info.cnt_chunk_bytes, device)
+    send = wrap(info.d_send, world * info.chunk_bytes, device)
+    recv = wrap(info.d_recv, world * info.chunk_bytes, device)
+    send_cnt = wrap(info.d_send_cnt, world * info.cnt_chunk_bytes, device)
+    recv_cnt = wrap(info.d_recv_cnt, world * info.cnt_chunk_bytes, device)
 
     # 1. per-bucket k-mer counts of the whole job
     bucket_counts = send_cnt.view(torch.int32).to(torch.int64)
@@ -245,15 +245,22 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
 
     # 2. the exchange
     dist.all_to_all_single(recv_cnt, send_cnt, group=group)
-    n_chunks = max(1, min(int(exchange_chunks), int(info.buckets_per_rank)))
+    # every own bucket must have received exactly what the all-reduce says the job holds for it (counts are capped by the
+    # bucket capacity on both sides alike): a wrong fill count would silently drop or invent records
+    B = int(info.buckets_per_rank)
+    per = int(info.cnt_chunk_bytes) // 4   # fill counters per rank chunk (buckets x sub-stores)
+    mine = recv_cnt.view(torch.int32).to(torch.int64).view(world, per).sum(dim=0)
+    want = bucket_counts.view(world, per)[rank]
+    if not bool(torch.equal(mine, want)):
+        raise RuntimeError("rank %d: the exchanged bucket fill counts disagree with the all-reduced totals" % rank)
+    n_chunks = max(1, min(int(exchange_chunks), B))
     if n_chunks <= 1:
-        _exchange_range(send, recv, info, 0, int(info.buckets_per_rank), world, rank, group)
+        _exchange_range(send, recv, info, 0, B, world, rank, group)
         if on_gpu:
             torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
     else:
         # every rank cuts the SAME bucket ranges (buckets_per_rank is common; ranks that own fewer
         # buckets build a shorter range but still take part in every transfer)
-        B = int(info.buckets_per_rank)
         per = (B + n_chunks - 1) // n_chunks
         ranges = [(j0, min(j0 + per, B)) for j0 in range(0, B, per)]
         arrived = []
@@ -273,28 +280,52 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
             own0, own1 = min(j0, int(info.own_buckets)), min(j1, int(info.own_buckets))
             if own1 > own0:
                 g.shard_build_range(own0, own1)  # queues level 2 + build on the library's streams and returns
-    g.shard_mark_exchanged()
-
-    # 3. build this rank's slot range
-    st = g.finalize()
-    local = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers))
-
-    # 4. hand-offs.  Overflow observations first: merging them can push further nodes off the end of a
-    # shard, so the outgoing lists are read only afterwards.
-    p_ovf, n_ovf = g.shard_overflow()
-    sizes = torch.tensor([n_ovf], dtype=torch.int64, device=device)
-    ovf_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(ovf_sizes, sizes, group=group)
-    ovf_sizes = torch.stack(ovf_sizes).cpu().numpy()[:, 0]
-    max_ovf = int(ovf_sizes.max())
-    if max_ovf:
-        mine = torch.zeros(max_ovf * NODE_BYTES, dtype=torch.uint8, device=device)
-        if n_ovf:
-            mine[:n_ovf * NODE_BYTES] = wrap_device_memory(p_ovf, n_ovf * NODE_BYTES, device)
-        lists = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(lists, mine, group=group)
+    if verify:
         if on_gpu:
-            torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
+            torch.cuda.synchronize()
+        cb = int(info.chunk_bytes)
+        sent = torch.stack([send[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
+        got = torch.stack([recv[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
+        theirs = torch.empty_like(sent)
+        dist.all_to_all_single(theirs, sent, group=group)   # theirs[p] = checksum of what rank p sent to me
+        if not bool(torch.equal(theirs, got)):
+            bad = [p for p in range(world) if int(theirs[p]) != int(got[p])]
+            raise RuntimeError("rank %d: the level-1 record buckets received from rank(s) %r differ from what was sent "
+                               "(a truncated or corrupted transfer)" % (rank, bad))
+    g.shard_mark_exchanged()
+    return records_global
+
+
+def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
+    """all-gather of one device list per rank (n entries of node_bytes): -> (sizes per rank, padded tensors per rank)"""
+    world = dist.get_world_size(group)
+    sizes = torch.tensor([n], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()[:, 0]
+    longest = int(all_sizes.max())
+    if not longest:
+        return all_sizes, None
+    mine = torch.zeros(longest * node_bytes, dtype=torch.uint8, device=device)
+    if n:
+        mine[:n * node_bytes] = wrap(ptr, n * node_bytes, device)
+    lists = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(lists, mine, group=group)
+    if on_gpu:
+        torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
+    return all_sizes, lists
+
+
+def _hand_offs(g, device, group, wrap, node_bytes):
+    """step 4: bucket-overflow observations offered to every rank, the aggregated surplus of heavy hitters broadcast, nodes
+    whose probe ran off the end of a shard handed to the next rank (ring).  Overflow observations first: merging them can
+    push further nodes off the end of a shard, so the outgoing lists are read only afterwards."""
+    on_gpu = torch.device(device).type == "cuda"
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    p_ovf, n_ovf = g.shard_overflow()
+    ovf_sizes, lists = _gather_lists(p_ovf, n_ovf, node_bytes, device, group, wrap, on_gpu)
+    if lists is not None:
         for src in range(world):
             if ovf_sizes[src]:
                 g.shard_merge(lists[src].data_ptr(), int(ovf_sizes[src]), is_triple=True)
@@ -307,27 +338,17 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     hh_sizes = torch.stack(hh_sizes).cpu().numpy()[:, 0]
     for src in range(world):
         if hh_sizes[src]:
-            nbytes = int(hh_sizes[src]) * NODE_BYTES
-            buf = wrap_device_memory(p_hh, nbytes, device).clone() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
+            nbytes = int(hh_sizes[src]) * node_bytes
+            buf = wrap(p_hh, nbytes, device).clone() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
             dist.broadcast(buf, src=src, group=group)
             if on_gpu:
                 torch.cuda.synchronize()
             g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))
             g.sync()
     p_out, n_out = g.shard_outgoing()
-    sizes = torch.tensor([n_out], dtype=torch.int64, device=device)
-    out_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(out_sizes, sizes, group=group)
-    out_sizes = torch.stack(out_sizes).cpu().numpy()[:, 0]
-    max_out = int(out_sizes.max())
-    if max_out:
-        mine = torch.zeros(max_out * NODE_BYTES, dtype=torch.uint8, device=device)
-        if n_out:
-            mine[:n_out * NODE_BYTES] = wrap_device_memory(p_out, n_out * NODE_BYTES, device)
-        lists = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(lists, mine, group=group)
-        if on_gpu:
-            torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
+    out_sizes, lists = _gather_lists(p_out, n_out, node_bytes, device, group, wrap, on_gpu)
+    handed = int(out_sizes.sum())
+    if lists is not None:
         prev = (rank - 1) % world
         if out_sizes[prev]:
             g.shard_merge(lists[prev].data_ptr(), int(out_sizes[prev]), from_previous_shard=True)
@@ -335,6 +356,26 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
             _, n_again = g.shard_outgoing()
             if n_again != n_out:
                 raise RuntimeError("a handed-over node left the next shard as well: shard (nearly) full")
+    return int(ovf_sizes.sum()), handed
+
+
+def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8, verify_exchange=False):
+    """g: a sharded capi.Graph (shard_count == world, shard_index == rank) that has received all its
+    pushes.  Performs steps 1-5 and returns the global totals; afterwards g's table holds this
+    rank's slot range of the global table.  `wrap(ptr, nbytes, device)` turns the library's buffers
+    into tensors (default: zero-copy CUDA array interface; the gloo CPU test passes a host wrapper).
+    exchange_chunks <= 1: one all-to-all of the whole stores, then the build."""
+    wrap = wrap or globals()["wrap_device_memory"]
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    records_global = _exchange_level1(g, device, group, wrap, exchange_chunks, verify_exchange)
+
+    # 3. build this rank's slot range
+    st = g.finalize()
+    local = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers))
+
+    # 4. hand-offs
+    n_ovf, n_handed = _hand_offs(g, device, group, wrap, NODE_BYTES)
 
     # 5. key-0 node onto rank 0, totals
     links = torch.tensor([int(st.polyA_l_link), int(st.polyA_r_link)], dtype=torch.int64, device=device)
@@ -351,7 +392,49 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8):
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global,
-            "handed_over_nodes": int(out_sizes.sum()), "overflow_observations": int(ovf_sizes.sum())}
+            "handed_over_nodes": n_handed, "overflow_observations": n_ovf}
+
+
+WIDE_NODE_BYTES = 32
+
+
+def wide_sharded_build(g, device, push_all, group=None, wrap=None, exchange_chunks=8, verify_exchange=False):
+    """The slot-range flow for 128-bit keys (k <= 63; WIDE engine through 16-byte records).  g: a sharded WIDE capi.Graph
+    (shard_count == world, shard_index == rank, expected_kmers > 0), reset.  push_all(g) pushes ALL of this rank's reads and is
+    called once per pass: a job whose records do not fit the level-1 fan-out (1024 buckets over all ranks) or the device reads
+    its input several times, each pass completing a part of every rank's slot range (dbgk_wide_begin_pass).  Per pass: steps
+    1-3 of sharded_finalize; then the hand-offs, and the few nodes that live outside the table (keys whose low word is 0, the
+    key-0 node: a side table per handle) are gathered onto rank 0.  Returns the global totals."""
+    wrap = wrap or globals()["wrap_device_memory"]
+    on_gpu = torch.device(device).type == "cuda"
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_passes, _ = g.wide_pass_info()
+    records_global = 0
+    for p in range(n_passes):
+        g.wide_begin_pass(p)
+        push_all(g)
+        records_global += _exchange_level1(g, device, group, wrap, exchange_chunks, verify_exchange)
+        g.wide_end_pass()
+    st = g.finalize()
+    local = (int(st.total_reads), int(st.total_kmers), int(st.stored_kmers))
+    n_ovf, n_handed = _hand_offs(g, device, group, wrap, WIDE_NODE_BYTES)
+    # side tables (keys with a zero low word) and key-0 links: onto rank 0, cleared everywhere else
+    p_side, n_side = g.shard_side_export()
+    side_sizes, lists = _gather_lists(p_side, n_side, WIDE_NODE_BYTES, device, group, wrap, on_gpu)
+    if rank == 0:
+        for src in range(1, world):
+            g.wide_merge_nodes(lists[src].data_ptr(), int(side_sizes[src]))
+        g.sync()
+    else:
+        g.shard_side_clear()
+    owned = g.refresh_stats()
+    tot = torch.tensor([local[0], local[1], local[2], int(owned.count)], dtype=torch.int64, device=device)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    tot = tot.cpu().numpy()
+    return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
+            "owned_count": int(owned.count), "records_global": records_global, "passes": n_passes,
+            "handed_over_nodes": n_handed, "overflow_observations": n_ovf}
 
 
 # ---- the k-mer frequency table on several GPUs (SURVEY 8(e)-4) -----------------------------------------------

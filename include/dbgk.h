@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DBGK_ABI_VERSION 3
+#define DBGK_ABI_VERSION 4
 
 /* status codes */
 #define DBGK_OK               0
@@ -57,11 +57,13 @@ typedef struct dbgk_handle dbgk_handle;
 #define DBGK_ENGINE_WIDE       5  /* k-mers of up to 63 bases: 128-bit keys, 32-byte nodes (include/dbgk_wide.h; the reference
                                      stops at k = 31, so this path is this build's own definition: parity unpinned for
                                      k > 32, identical to the reference's rules for k <= 32).  expected_kmers > 0 and
-                                     2^26 <= table_slots <= 2^32: 16-byte records are radix-partitioned and the table is built
-                                     region by region in LDS (2.7x faster; 16 bytes per occurrence + an eighth again must fit
-                                     the device; what does not fit the record store joins through the atomic kernels after
-                                     the build); otherwise fused extract + atomic insert.  Results through
-                                     dbgk_wide_export_*, dbgk_digest, dbgk_link_stats_device                            */
+                                     2^26 <= table_slots < 2^34: 16-byte records are radix-partitioned and the table is built
+                                     region by region in LDS (2.7x faster; 16 bytes per occurrence of a pass + an eighth again
+                                     must fit the device; with one shard and one pass what does not fit the record store joins
+                                     through the atomic kernels after the build); otherwise fused extract + atomic insert.
+                                     shard_count >= 1: slot-range shards of ONE table like the 64-bit engine (dbgk_shard_*);
+                                     big tables / small devices: several passes over the input (dbgk_wide_begin_pass).
+                                     Results through dbgk_wide_export_*, dbgk_digest, dbgk_link_stats_device            */
 #define DBGK_ENGINE_KFREQ      3  /* no graph: direct-addressed 4^k table of saturating 8-bit counts of
                                      canonical k-mers (the correct_error module's frequency table);
                                      table_slots is ignored, k <= 18.  expected_kmers > 0: the occurrences
@@ -89,7 +91,11 @@ typedef struct dbgk_config {
 	                              the exchange protocol, useful for testing it on one GPU)        */
 	uint32_t shard_index;      /* 0 .. shard_count-1                                               */
 	uint64_t flags;            /* DBGK_FLAG_*                                                      */
-	uint64_t reserved[2];
+	uint64_t n_passes;         /* DBGK_ENGINE_WIDE through records: read the input this many times, every pass
+	                              keeping the records of a part of the level-1 buckets (dbgk_wide_begin_pass);
+	                              0 = as few as the geometry needs (1 unless the table has more than 1024
+	                              level-1 buckets per pass, counted over all shards)                  */
+	uint64_t reserved[1];
 } dbgk_config;
 
 /* DIRECT engine only: remember for every key the position (in pushed bases, over all pushes) of its
@@ -236,6 +242,24 @@ int dbgk_wide_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node32 
  * allowed before and after dbgk_finalize (dbgk_refresh_stats recounts).                                        */
 int dbgk_wide_partition_export(dbgk_handle *h, uint32_t n_parts, dbgk_node32 *d_nodes, uint64_t capacity, uint64_t *counts);
 int dbgk_wide_merge_nodes(dbgk_handle *h, const dbgk_node32 *d_nodes, uint64_t n);
+/* WIDE through records, SHARDS and PASSES.  shard_count = N: N handles (one per GPU) hold ONE table of table_slots slots, rank d
+ * the slot range of its level-1 buckets -- the device analogue of the reference's `kmer % threadNum` ownership
+ * (DBGgraph.cpp:148), as for 64-bit keys; the protocol is dbgk_shard_buffers / _mark_exchanged / _plan / _build_range /
+ * _outgoing / _overflow / _merge below, with 16-byte records and 32-byte list entries (dbgk_node32: nodes {hi, lo, l_link, r_link},
+ * observations {hi, lo, lb, rb}).  Keys whose low word is 0 and the key-0 node live outside the table (a 4096-slot side table per
+ * handle): after dbgk_finalize they are gathered onto shard 0 -- dbgk_shard_side_export on every other shard (device list, the
+ * key-0 node first), dbgk_wide_merge_nodes of that list on shard 0, dbgk_shard_side_clear on the others.
+ * PASSES: the level-1 kernel fans out to at most 1024 buckets (counted over all shards) and a pass's records must fit the device,
+ * so a big job reads its input n_passes times, the way disk-based k-mer counters pass over their input once per set of
+ * partitions: for p in 0 .. n_passes-1 { dbgk_wide_begin_pass(p); push ALL reads; [exchange the buffers of dbgk_shard_buffers,
+ * dbgk_shard_mark_exchanged;] dbgk_wide_end_pass } then dbgk_finalize.  Pass p keeps the records of own-bucket indices
+ * [p * Bp, (p+1) * Bp) of every shard and completes those regions of the table; totals count the input once.  A handle with one
+ * shard and one pass needs none of these calls.                                                                           */
+int dbgk_wide_pass_info(dbgk_handle *h, uint32_t *n_passes, uint32_t *passes_done);
+int dbgk_wide_begin_pass(dbgk_handle *h, uint32_t pass);
+int dbgk_wide_end_pass(dbgk_handle *h);
+int dbgk_shard_side_export(dbgk_handle *h, dbgk_node32 **d_nodes, uint64_t *n);
+int dbgk_shard_side_clear(dbgk_handle *h);
 
 /* ---- KFREQ engine: the k-mer frequency table of the correct_error module --------
  * The reference only CONSUMES this table (its producer, `kmerfreq`, is not part of the repository):

@@ -1,0 +1,182 @@
+"""WIDE engine (128-bit keys) through 16-byte records with SLOT-RANGE SHARDS and several PASSES over the input
+(include/dbgk.h: dbgk_wide_begin_pass, dbgk_shard_*): what BASELINE cfg5 needs on 8 GPUs, exercised as N handles on ONE GPU
+with the all-to-all done by device copies.  PARITY UNPINNED above k = 32 (the reference stops at 31); the yardsticks are the
+independent checker (tests/wide_checker.py, small inputs), the CPU restatement, and at k <= 32 the pinned oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import wide_checker as W
+from test_wide_checker import _reads
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dbg_assembly_amd import capi as c
+    assert c.lib().dbgk_device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback exists)"
+    return c
+
+
+def build_wide_sharded(capi, reads_per_shard, k, size, n_passes, expected, max_read_len=250, pieces=1, oracle=None):
+    """-> (sorted nodes of the whole job, total k-mers, count, digest sum, per-shard host slices + side nodes)"""
+    n = len(reads_per_shard)
+    graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=expected, shard_count=n, shard_index=i,
+                         max_read_len=max_read_len, n_passes=n_passes, max_batch_bases=1 << 16) for i in range(n)]
+    try:
+        P, done = graphs[0].wide_pass_info()
+        assert done == 0 and P >= max(1, n_passes)
+        c0 = graphs[0]
+        for p in range(P):
+            for g, (bases, offsets) in zip(graphs, reads_per_shard):
+                g.wide_begin_pass(p)
+                g.push_reads(bases, offsets)
+                g.sync()
+            infos = [g.shard_info() for g in graphs]
+            for s in range(n):
+                for d in range(n):
+                    c0.memcpy_d2d(infos[d].d_recv_cnt + s * infos[d].cnt_chunk_bytes, infos[s].d_send_cnt + d * infos[s].cnt_chunk_bytes,
+                                  infos[s].cnt_chunk_bytes)
+            c0.sync()
+            B = infos[0].buckets_per_rank
+            per = -(-B // pieces)
+            for g in graphs:
+                g.shard_plan() if pieces > 1 else None
+            for j0 in range(0, B, per):
+                j1 = min(j0 + per, B)
+                for s in range(n):
+                    for d in range(n):
+                        c0.memcpy_d2d(infos[d].d_recv + s * infos[d].chunk_bytes + j0 * infos[d].bucket_bytes,
+                                      infos[s].d_send + d * infos[s].chunk_bytes + j0 * infos[s].bucket_bytes, (j1 - j0) * infos[s].bucket_bytes)
+                c0.sync()
+                if pieces > 1:
+                    for g, info in zip(graphs, infos):
+                        a, b = min(j0, info.own_buckets), min(j1, info.own_buckets)
+                        if b > a:
+                            g.shard_build_range(a, b)
+            for g in graphs:
+                g.shard_mark_exchanged()
+                g.wide_end_pass()
+        stats = [g.finalize() for g in graphs]
+        ovf = [g.shard_overflow() for g in graphs]
+        for (ptr, cnt) in ovf:
+            for g in graphs:
+                if cnt:
+                    g.shard_merge(ptr, cnt, is_triple=True)
+        out = [g.shard_outgoing() for g in graphs]
+        for s, (ptr, cnt) in enumerate(out):
+            if cnt:
+                graphs[(s + 1) % n].shard_merge(ptr, cnt, from_previous_shard=True)
+        for s in range(1, n):   # side tables and key-0 links onto shard 0
+            ptr, cnt = graphs[s].shard_side_export()
+            graphs[0].wide_merge_nodes(ptr, cnt)
+            graphs[0].sync()
+            graphs[s].shard_side_clear()
+        final = [g.refresh_stats() for g in graphs]
+        nodes = np.concatenate([g.wide_export_sorted() for g in graphs])
+        nodes = np.sort(nodes, order=["kmer_hi", "kmer_lo"])
+        digest = sum(g.digest() for g in graphs) % (1 << 64)
+        depth = np.sum([np.array(g.link_stats(2).depth_stat, dtype=np.int64) for g in graphs], axis=0)
+        slices = [g.wide_export_host_table(info.slot_hi - info.slot_lo) for g, info in zip(graphs, [g.shard_info() for g in graphs])]
+        return {"nodes": nodes, "total_kmers": sum(int(s.total_kmers) for s in stats), "total_reads": sum(int(s.total_reads) for s in stats),
+                "count": sum(int(f.count) for f in final), "digest": digest, "depth": depth, "slices": slices, "passes": P,
+                "n_overflow": sum(c for _, c in ovf), "n_outgoing": sum(c for _, c in out)}
+    finally:
+        for g in graphs:
+            g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,r,n_shards,n_passes,pieces", [(63, 250, 2, 1, 1), (33, 250, 3, 2, 1), (63, 120, 3, 3, 4), (47, 100, 2, 2, 1),
+                                                       (31, 250, 2, 2, 1), (63, 63, 2, 1, 2)])
+def test_wide_shards_and_passes_equal_independent_checker_PARITY_UNPINNED_above_k32(capi, oracle, k, r, n_shards, n_passes, pieces):
+    rng = random.Random(100 * k + 10 * n_shards + n_passes)
+    reads = _reads(rng, 400)
+    parts = [oracle.pack_reads(reads[i::n_shards]) for i in range(n_shards)]
+    nodes, want_total = W.build(reads, k, r)
+    want = W.as_sorted_nodes(nodes)
+    size = capi.find_next_prime_ref(1 << 26)
+    got = build_wide_sharded(capi, parts, k, size, n_passes, expected=sum(len(r_) for r_ in reads), max_read_len=r, pieces=pieces)
+    assert got["passes"] == n_passes
+    assert (got["total_reads"], got["total_kmers"], got["count"]) == (len(reads), want_total, len(want))
+    assert np.array_equal(got["nodes"], want.astype(capi.NODE32_DTYPE))
+    assert got["digest"] == oracle.wide_digest(want)
+    # the shards side by side + the nodes that live outside the table (zero low word, key 0) placed on their chains = ONE valid table
+    array = np.concatenate([a for a, _ in got["slices"]])
+    assert len(array) == size
+    flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+    occ = (array["kmer_lo"] != 0)
+    for node in want[(want["kmer_lo"] == 0)]:   # add_node_to_kmerset's rule (kmerSet.cpp:253-273) on the host, as the communicator's export does
+        hc = _hash128(int(node["kmer_hi"]), 0) % size
+        while occ[hc]:
+            hc = (hc + 1) % size
+        array[hc] = node
+        occ[hc] = True
+    flags = np.packbits(np.concatenate([occ, np.zeros((-size) % 8 + 8, dtype=bool)]))[:size // 8 + 1]
+    assert oracle.wide_check_host_table(array, flags, size, got["count"]) == 0
+
+
+def _hash_code(k):
+    M = (1 << 64) - 1
+    k = (k + (~(k << 32) & M)) & M
+    k ^= k >> 22
+    k = (k + (~(k << 13) & M)) & M
+    k ^= k >> 8
+    k = (k + (k << 3)) & M
+    k ^= k >> 15
+    k = (k + (~(k << 27) & M)) & M
+    k ^= k >> 31
+    return k
+
+
+def _hash128(hi, lo):
+    return _hash_code(lo ^ _hash_code(hi)) if hi else _hash_code(lo)
+
+
+@pytest.mark.gpu
+def test_wide_sharded_cfg5_shaped_sample_equals_single_handle_PARITY_UNPINNED(capi, oracle):
+    """cfg5's shape (150-base reads, 0.1 % substitutions, k = 63) at 3 shards x 2 passes against ONE unsharded handle of the
+    same reads (records path) and against the CPU restatement"""
+    n_reads, G, k = 90000, 400000, 63
+    P = oracle.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    bases, offsets = oracle.synth_reads(P, 0, n_reads)
+    want, total = oracle.wide_build(bases, offsets, k, 250)
+    parts = []
+    for i in range(3):
+        lo, hi = i * (n_reads // 3), (i + 1) * (n_reads // 3)
+        parts.append((bases[int(offsets[lo]):int(offsets[hi])], offsets[lo:hi + 1] - offsets[lo]))
+    size = capi.find_next_prime_ref(100_000_000)
+    got = build_wide_sharded(capi, parts, k, size, 2, expected=n_reads * 88 // 3 + 1000)
+    assert (got["total_kmers"], got["count"]) == (total, len(want))
+    assert np.array_equal(got["nodes"], want)
+    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as g:
+        g.push_reads(bases, offsets)
+        st = g.finalize()
+        assert int(st.count) == got["count"] and g.digest() == got["digest"]
+        assert [int(x) for x in g.link_stats(2).depth_stat] == [int(x) for x in got["depth"]]
+
+
+@pytest.mark.gpu
+def test_wide_single_handle_table_beyond_2_32_slots_reads_its_input_in_passes_PARITY_UNPINNED(capi, oracle):
+    """a table of 4.4 G slots (141 GB of 32-byte nodes) has more than 1024 level-1 buckets even at r = 22: two passes over the input, one handle"""
+    n_reads, G, k = 60000, 300000, 63
+    P = oracle.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    bases, offsets = oracle.synth_reads(P, 0, n_reads)
+    want, total = oracle.wide_build(bases, offsets, k, 250)
+    size = capi.find_next_prime_ref(4_400_000_000)
+    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as g:
+        n_passes, _ = g.wide_pass_info()
+        assert n_passes == 2
+        for p in range(n_passes):
+            g.wide_begin_pass(p)
+            g.push_reads(bases, offsets)
+            g.wide_end_pass()
+        st = g.finalize()
+        assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (n_reads, total, len(want))
+        assert np.array_equal(g.wide_export_sorted(), want)
+        assert g.digest() == oracle.wide_digest(want)
+        # forgetting a pass is an error, not a silently incomplete table
+        g.reset()
+        g.push_reads(bases, offsets)
+        with pytest.raises(capi.DbgkError):
+            g.finalize()
