@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--exchange", choices=["records", "nodes"], default="records",
                     help="N > 1: 'records' = slot-range ownership, level-1 buckets exchanged (default); "
                          "'nodes' = local tables, aggregated nodes exchanged by hash owner")
+    ap.add_argument("--passes", type=int, default=0,
+                    help="cfg5, N > 1: passes over the input (0 = as few as the level-1 fan-out needs: 3 at N = 8, where the 12.8 G-slot "
+                         "table has 3052 level-1 buckets and a pass's records, 35 GB sent + 35 GB received, fit beside the 51 GB shard)")
     ap.add_argument("--exchange-chunks", type=int, default=8,
                     help="N > 1, records flow: pieces the level-1 buckets travel in (the build of a piece overlaps "
                          "the transfer of the next); 1 = one all-to-all, then the build")
@@ -277,6 +280,10 @@ def main_kfreq(args, result_out):
 
     for _ in range(args.warmup):
         step()
+        state["verify"] = False
+    if not args.warmup and multi:   # no warm-up step: verify the exchange once, untimed
+        step()
+        state["verify"] = False
     g.sync()
     g.reset_timings()
     fence()
@@ -378,7 +385,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
-    from dbg_assembly_amd.multigpu import HipEngine, WideHipEngine, exchange_and_merge, sharded_finalize
+    from dbg_assembly_amd.multigpu import HipEngine, WideHipEngine, exchange_and_merge, sharded_finalize, wide_sharded_build
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -407,7 +414,10 @@ def main():
     # N > 1: ONE global table of world * slots_per_gpu slots, every rank owns a contiguous slot range
     # (PARTITION engine, slot-range ownership; up to 2^34 slots in total).  --exchange nodes selects
     # the older flow (local tables, aggregated nodes shipped to hash owners).
-    sharded = multi and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
+    # cfg5 (WIDE, k = 63): the same slot-range ownership for 16-byte records; a job whose level-1 buckets (counted over all ranks)
+    # exceed the kernel's fan-out, or whose records would not fit beside the table, reads its input in several passes
+    wide_sharded = multi and args.engine == capi.ENGINE_WIDE and args.exchange == "records"
+    sharded = multi and (args.engine == capi.ENGINE_PARTITION or wide_sharded) and args.exchange == "records"
     # cfg2 (weak scaling): the global table stays below 2^32 slots where that still leaves room (N = 8: 536 M slots per
     # GPU, load 0.4), because level 2 is fastest with <= 1024 final buckets per level-1 bucket; cfg3 IS the big table
     per_gpu_slots = args.table_slots
@@ -418,7 +428,8 @@ def main():
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
                    expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not os.environ.get("DBGK_WIDE_DIRECT")
                    else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
-                   shard_count=world if sharded else 0, shard_index=rank if sharded else 0)
+                   shard_count=world if sharded else 0, shard_index=rank if sharded else 0,
+                   n_passes=args.passes if wide_sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     # WIDE (cfg5) on several GPUs: every rank builds the graph of its reads, the aggregated 32-byte nodes go to their owners
     engine = WideHipEngine(g, device) if args.engine == capi.ENGINE_WIDE else HipEngine(g, device)
@@ -426,8 +437,13 @@ def main():
     debug_mode = int(os.environ.get("DBGK_DEBUG_MODE", "0"))  # kernel timing experiments: results are wrong
     debug_l2 = int(os.environ.get("DBGK_DEBUG_L2", "0")) or int(os.environ.get("DBGK_DEBUG_BUILD", "0"))
 
+    state = {"verify": True}   # the first step run checksums what every rank sent against what its peers received
+
     def step():
         g.reset()
+        if wide_sharded:   # (pushes happen inside: once per pass)
+            return wide_sharded_build(g, device, lambda h: h.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb),
+                                      exchange_chunks=args.exchange_chunks, verify_exchange=state["verify"])
         g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
         if debug_mode:  # level-1 timing experiments leave garbage records: never run the later phases on them
             g.sync()
@@ -440,7 +456,7 @@ def main():
             g.sync()
             return {"stored_kmers": n_reads * kpr, "count": 0}
         if sharded:
-            return sharded_finalize(g, device, exchange_chunks=args.exchange_chunks)
+            return sharded_finalize(g, device, exchange_chunks=args.exchange_chunks, verify_exchange=state["verify"])
         st = g.finalize()
         if multi:
             return exchange_and_merge(engine)
@@ -455,6 +471,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        state["verify"] = False
+    if not args.warmup and multi:   # no warm-up step: verify the exchange once, untimed
+        step()
+        state["verify"] = False
     g.sync()
     g.reset_timings()
     fence()

@@ -408,13 +408,22 @@ static bool plan_wide_partition(dbgk_handle *h, bool *err)
 	if (const char *e = getenv("DBGK_WIDE_R")) r = (uint32_t)std::max(kWRegionBits + 1, std::min(22, atoi(e)));
 	if (!want_shard && want_passes <= 1)
 		while (r < 22u && ((h->size + (1ull << r) - 1) >> r) > 1024ull) r++; // one pass if the fan-out allows it
+	// passes: at least as many as keep the level-1 fan-out (ranks x buckets of a pass) within 1024
+	auto passes_at = [&](uint32_t rr) {
+		const uint64_t nn1 = (h->size + (1ull << rr) - 1) >> rr;
+		const uint32_t BB = (uint32_t)((nn1 + n_ranks - 1) / n_ranks);
+		uint32_t pp = std::max<uint32_t>(1u, want_passes);
+		while ((uint64_t)n_ranks * ((BB + pp - 1) / pp) > 1024ull) pp++;
+		return pp;
+	};
+	// every pass extracts the whole input again: beyond two passes the wider level-1 buckets of r = 22 (half the passes, level 2
+	// fanning out 2048 ways) are the better trade
+	if (!getenv("DBGK_WIDE_R") && r == 21u && passes_at(21u) > 2u && passes_at(22u) < passes_at(21u)) r = 22u;
 	while (r > (uint32_t)kWRegionBits + 1u && qbits + (int)r + 6 > 64) r--;
 	const uint64_t n1 = (h->size + (1ull << r) - 1) >> r;
 	if ((1u << (r - kWRegionBits)) > 2048u || qbits + (int)r + 6 > 64 || n1 >= 65536ull) return refuse("no feasible wide record geometry for this table size");
 	const uint32_t B = (uint32_t)((n1 + n_ranks - 1) / n_ranks);
-	// passes: at least as many as keep the level-1 fan-out (ranks x buckets of a pass) within 1024
-	uint32_t n_passes = std::max<uint32_t>(1u, want_passes);
-	while ((uint64_t)n_ranks * ((B + n_passes - 1) / n_passes) > 1024ull) n_passes++;
+	uint32_t n_passes = passes_at(r);
 	if (n_passes > B) return refuse("shard_count too large for this table size");
 	if (n_passes > 1 && !want_shard && want_passes <= 1 && getenv("DBGK_WIDE_NO_AUTO_PASSES")) return false;
 	WPartGeom &G = h->wgeom;

@@ -146,3 +146,43 @@ def test_bench_multi_gpu_code_path_rehearsal(extra):
     assert out["n_gpus"] == 1 and out["config"]["nodes"] > 1000000 and out["value"] > 0
     for key in ("metric", "unit", "ms_per_step", "roofline", "scaling", "dtype", "data"):
         assert key in out
+
+
+@pytest.mark.parametrize("n_passes", [1, 2])
+def test_wide_sharded_build_single_rank_nccl(n_passes):
+    """`bench.py --config cfg5 --gpus N`: the slot-range flow for 128-bit keys (multigpu.wide_sharded_build: passes over the
+    input, bucket-count all-reduce, all-to-all of the 16-byte record buckets in pieces with the exchange verified, region
+    builds, hand-offs, side-table gather) on one rank over RCCL, against a plain WIDE handle of the same reads; twice on
+    one handle (bench loop)"""
+    import torch
+    import torch.distributed as dist
+    from dbg_assembly_amd import capi
+    from dbg_assembly_amd.multigpu import wide_sharded_build
+
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_reads, G, k = 200000, 1500000, 63
+        P = capi.synth_params(G, 150, sub_rate=0.001, cfg=5)
+        size = capi.find_next_prime_ref(1 << 26)
+        device = torch.device("cuda", 0)
+        with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as ref:
+            d_bases, d_off, nb = ref.synth_reads_device(P, 0, n_reads)
+            ref.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st = ref.finalize()
+            want = (int(st.count), int(st.total_kmers), int(st.total_reads), ref.digest())
+            with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88, shard_count=1, shard_index=0,
+                            n_passes=n_passes) as g:
+                assert g.wide_pass_info()[0] == n_passes
+                for _ in range(2):
+                    g.reset()
+                    out = wide_sharded_build(g, device, lambda h: h.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb), exchange_chunks=4,
+                                             verify_exchange=True)
+                    assert (out["count"], out["total_kmers"], out["total_reads"], g.digest()) == want
+                    assert out["passes"] == n_passes and out["records_global"] <= want[1]
+            d_bases.free()
+            d_off.free()
+    finally:
+        dist.destroy_process_group()

@@ -395,3 +395,238 @@ def test_kfreq_reduce_gloo(oracle, world, chunk):
     assert np.array_equal(got, want)
     if chunk < 4 ** k // world:
         assert all(r[4] > world - 1 for r in results)  # several rounds of chunks
+
+
+# ------------------------------------------------------------------------------------------------
+# the slot-range flow for 128-bit keys (multigpu.wide_sharded_build): passes over the input, 32-byte list entries, the
+# side table of keys with a zero low word gathered onto rank 0 -- with a host-memory stand-in whose arithmetic is the
+# independent checker's (tests/wide_checker.py: strings and Python ints)
+# ------------------------------------------------------------------------------------------------
+NODE32 = np.dtype([("kmer_hi", "<u8"), ("kmer_lo", "<u8"), ("l_link", "<u4"), ("r_link", "<u4"), ("reserved", "<u8")])
+
+
+def _py_hash_code(k):
+    M = (1 << 64) - 1
+    k = (k + (~(k << 32) & M)) & M
+    k ^= k >> 22
+    k = (k + (~(k << 13) & M)) & M
+    k ^= k >> 8
+    k = (k + (k << 3)) & M
+    k ^= k >> 15
+    k = (k + (~(k << 27) & M)) & M
+    k ^= k >> 31
+    return k
+
+
+class FakeWideShardGraph:
+    """capi.Graph look-alike for a sharded WIDE handle on host memory.  'Records' are 32-byte observations {hi, lo, lb, rb};
+    pass p of P keeps own-bucket indices [p * Bp, (p + 1) * Bp) of every rank.  Only what wide_sharded_build uses."""
+    B, P, CAP = 6, 2, 1 << 13
+
+    def __init__(self, W, reads, k, r, world, rank, size):
+        self.W, self.world, self.rank, self.size = W, world, rank, size
+        self.Bp = -(-self.B // self.P)
+        self.span = -(-size // world)
+        self.sub = -(-self.span // self.B)
+        self.obs, self.total_kmers = W.observations(reads, k, r)
+        self.total_reads = len(reads)
+        self.done = 0
+        self.open = False
+        self.agg = {}          # key -> [[4], [4]] raw counts of my slot range
+        self.side = {}         # keys with a zero low word (incl. key 0): raw counts, saturated at export
+        self.pushed = 0
+        self.send = np.zeros((world, self.Bp, self.CAP), NODE32)
+        self.send_cnt = np.zeros((world, self.Bp), np.uint32)
+        self.recv = np.zeros((world, self.Bp, self.CAP), NODE32)
+        self.recv_cnt = np.zeros((world, self.Bp), np.uint32)
+
+    def wide_pass_info(self):
+        return self.P, self.done
+
+    def wide_begin_pass(self, p):
+        assert p == self.done and not self.open
+        self.open, self.pass_, self.calls, self.taken = True, p, [], 0
+        self.send_cnt[:] = 0
+        self.recv_cnt[:] = 0
+
+    def push_all(self):
+        """what push_all(g) of the caller does: every observation of this rank's reads, once per pass"""
+        self.pushed += 1
+        M = (1 << 64)
+        for key, lb, rb in self.obs:
+            hi, lo = key // M, key % M
+            if lo == 0:   # side table / key 0: never a record, counted in pass 0 only
+                if self.pass_ == 0:
+                    c = self.side.setdefault(key, [[0] * 4, [0] * 4])
+                    if lb is not None:
+                        c[0][lb] += 1
+                    if rb is not None:
+                        c[1][rb] += 1
+                continue
+            h = _py_hash_code(lo ^ _py_hash_code(hi)) if hi else _py_hash_code(lo)
+            slot = h % self.size
+            d = slot // self.span
+            j = (slot - d * self.span) // self.sub
+            jj = j - self.pass_ * self.Bp
+            if not 0 <= jj < self.Bp:
+                continue
+            i = int(self.send_cnt[d, jj])
+            self.send[d, jj, i] = (hi, lo, 4 if lb is None else lb, 4 if rb is None else rb, 0)
+            self.send_cnt[d, jj] = i + 1
+
+    def shard_info(self):
+        class I:
+            pass
+        i = I()
+        i.n_ranks, i.rank = self.world, self.rank
+        i.chunk_bytes, i.cnt_chunk_bytes = self.Bp * self.CAP * 32, self.Bp * 4
+        i.buckets_per_rank = self.Bp
+        i.own_buckets = max(0, min(self.Bp, self.B - self.pass_ * self.Bp))
+        i.bucket_bytes, i.cnt_bucket_bytes = self.CAP * 32, 4
+        i.d_send, i.d_recv = self.send.ctypes.data, self.recv.ctypes.data
+        i.d_send_cnt, i.d_recv_cnt = self.send_cnt.ctypes.data, self.recv_cnt.ctypes.data
+        return i
+
+    def sync(self):
+        pass
+
+    def shard_plan(self):
+        self.calls.append("plan")
+
+    def _take(self, j0, j1):
+        for jj in range(j0, j1):
+            for s in range(self.world):
+                for rec in self.recv[s, jj, :int(self.recv_cnt[s, jj])]:
+                    key = (int(rec["kmer_hi"]) << 64) | int(rec["kmer_lo"])
+                    c = self.agg.setdefault(key, [[0] * 4, [0] * 4])
+                    if rec["l_link"] != 4:
+                        c[0][int(rec["l_link"])] += 1
+                    if rec["r_link"] != 4:
+                        c[1][int(rec["r_link"])] += 1
+        self.taken = j1
+
+    def shard_build_range(self, j0, j1):
+        assert self.calls and self.calls[0] == "plan" and j0 == self.taken   # in order, once
+        self.calls.append(("range", j0, j1))
+        self._take(j0, j1)   # what has arrived by now is what gets built: a late transfer would lose records
+
+    def shard_mark_exchanged(self):
+        self.exchanged = True
+
+    def wide_end_pass(self):
+        assert self.open and self.exchanged
+        self._take(self.taken, self.shard_info().own_buckets)
+        self.open, self.exchanged = False, False
+        self.done += 1
+
+    def finalize(self):
+        assert self.done == self.P and not self.open
+
+        class S:
+            pass
+        st = S()
+        st.total_reads, st.total_kmers, st.stored_kmers = self.total_reads, self.total_kmers, len(self.obs)
+        return st
+
+    def shard_overflow(self):
+        return 0, 0
+
+    def shard_outgoing(self):
+        return 0, 0
+
+    def shard_heavy(self):
+        return 0, 0
+
+    def _node(self, key, c):
+        sat = [[min(255, x) for x in side] for side in c]
+        return (key >> 64, key & ((1 << 64) - 1), self.W.link_word(sat[0]), self.W.link_word(sat[1]), 0)
+
+    def shard_side_export(self):
+        keys = [0] + sorted(k for k in self.side if k)
+        self._side_buf = np.zeros(len(keys), NODE32)
+        for i, key in enumerate(keys):
+            self._side_buf[i] = self._node(key, self.side.get(key, [[0] * 4, [0] * 4]))
+        return self._side_buf.ctypes.data, len(keys)
+
+    def wide_merge_nodes(self, ptr, n):
+        got = np.frombuffer((C.c_uint8 * (int(n) * 32)).from_address(int(ptr)), dtype=NODE32)
+        for nd in got:
+            key = (int(nd["kmer_hi"]) << 64) | int(nd["kmer_lo"])
+            assert nd["kmer_lo"] == 0
+            c = self.side.setdefault(key, [[0] * 4, [0] * 4])
+            mine = self._node(key, c)   # saturated first, then added per byte, saturating: exact for any split
+            for side, word, add in ((0, mine[2], int(nd["l_link"])), (1, mine[3], int(nd["r_link"]))):
+                c[side] = [min(255, ((word >> s) & 0xFF) + ((add >> s) & 0xFF)) for s in (24, 16, 8, 0)]
+
+    def shard_side_clear(self):
+        self.side = {}
+
+    def refresh_stats(self):
+        class S:
+            pass
+        s = S()
+        s.count = len(self.agg) + len([k for k in self.side if k]) + (1 if self.rank == 0 else 0)
+        return s
+
+    def result_nodes(self):
+        rows = [self._node(k, c) for k, c in self.agg.items()] + [self._node(k, c) for k, c in self.side.items() if k]
+        if self.rank == 0:
+            rows.append(self._node(0, self.side.get(0, [[0] * 4, [0] * 4])))
+        out = np.zeros(len(rows), NODE32)
+        for i, row in enumerate(rows):
+            out[i] = row
+        return out
+
+
+def _wide_worker(rank, world, port, reads, k, r, size, q, chunks):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import wide_checker as W
+    from dbg_assembly_amd.multigpu import wide_sharded_build
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FakeWideShardGraph(W, reads[rank::world], k, r, world, rank, size)
+    out = wide_sharded_build(g, "cpu", lambda h: h.push_all(), wrap=_wrap_host, exchange_chunks=chunks, verify_exchange=True)
+    out["pushes"] = g.pushed
+    q.put((rank, out, g.result_nodes().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 3)])
+def test_wide_sharded_build_gloo_PARITY_UNPINNED_above_k32(world, chunks):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import wide_checker as W
+    rng = random.Random(63)
+    g = "".join(rng.choice("ACGT") for _ in range(2500))
+    reads = []
+    for _ in range(150):
+        s = rng.randint(0, 2500 - 130)
+        reads.append(g[s:s + rng.randint(60, 130)].encode())
+    reads += [b"A" * 100] * 300 + [b"T" * 70] * 10 + [b"G" + b"A" * 80 + b"C"] * 3 + [b"ACGTTGCA" * 12] * 270   # key 0, zero low words, saturation
+    rng.shuffle(reads)
+    k, r, size = 63, 120, 1000003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(rk, world, port, reads, k, r, size, q, chunks)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nodes, total = W.build(reads, k, r)
+    want = W.as_sorted_nodes(nodes)
+    merged = np.concatenate([np.frombuffer(b, dtype=NODE32) for _, _, b in results])
+    merged = np.sort(merged, order=["kmer_hi", "kmer_lo"])
+    assert np.array_equal(merged, want)   # disjoint slot ranges, the side table once, exact saturating merge
+    assert ((want["kmer_lo"] == 0) & (want["kmer_hi"] != 0)).any()          # keys of the side table took part
+    assert max(int(((want["l_link"] >> s) & 0xFF).max()) for s in (0, 8, 16, 24)) == 255   # and saturating counters
+    for rank, out, _ in results:
+        assert out["count"] == len(want) and out["total_kmers"] == total and out["total_reads"] == len(reads)
+        assert out["passes"] == FakeWideShardGraph.P and out["pushes"] == FakeWideShardGraph.P   # the input is read once per pass

@@ -37,10 +37,10 @@ def _value(word):
     return v
 
 
-def build(reads, k, max_read_len=250):
-    """reads: iterable of bytes / str.  -> (dict key -> [[lA, lC, lG, lT], [rA, rC, rG, rT]] with saturated counters,
-    Kmer_total_num); key 0 is always present"""
-    nodes = {0: [[0, 0, 0, 0], [0, 0, 0, 0]]}
+def observations(reads, k, max_read_len=250):
+    """every window of every read as (canonical key, index of the left neighbour's letter or None, of the right one or None);
+    second result: Kmer_total_num"""
+    out = []
     total = 0
     for read in reads:
         if isinstance(read, (bytes, bytearray, np.ndarray)):
@@ -62,11 +62,21 @@ def build(reads, k, max_read_len=250):
                 key = rev
                 lbase = COMPLEMENT[right] if right is not None else None
                 rbase = COMPLEMENT[left] if left is not None else None
-            node = nodes.setdefault(key, [[0, 0, 0, 0], [0, 0, 0, 0]])
-            if lbase is not None:
-                node[0][LETTER.index(lbase)] = min(255, node[0][LETTER.index(lbase)] + 1)
-            if rbase is not None:
-                node[1][LETTER.index(rbase)] = min(255, node[1][LETTER.index(rbase)] + 1)
+            out.append((key, None if lbase is None else LETTER.index(lbase), None if rbase is None else LETTER.index(rbase)))
+    return out, total
+
+
+def build(reads, k, max_read_len=250):
+    """reads: iterable of bytes / str.  -> (dict key -> [[lA, lC, lG, lT], [rA, rC, rG, rT]] with saturated counters,
+    Kmer_total_num); key 0 is always present"""
+    nodes = {0: [[0, 0, 0, 0], [0, 0, 0, 0]]}
+    obs, total = observations(reads, k, max_read_len)
+    for key, lb, rb in obs:
+        node = nodes.setdefault(key, [[0, 0, 0, 0], [0, 0, 0, 0]])
+        if lb is not None:
+            node[0][lb] = min(255, node[0][lb] + 1)
+        if rb is not None:
+            node[1][rb] = min(255, node[1][rb] + 1)
     return nodes, total
 
 
