@@ -135,6 +135,8 @@ SYMBOLS = [
     ("dbgk_comm_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_comm_link_stats", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_comm_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_comm_wide_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_comm_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_comm_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
     ("dbgk_comm_kfreq_export_bits", _i, [_vp, C.c_uint32, _u64, _u64, _vp]),
     ("dbgk_synth_reads_device", _i, [_vp, C.POINTER(SynthParams), _u64, _u64, _vp, _vp]),
@@ -551,6 +553,21 @@ class Comm:
         array = np.zeros(size, dtype=NODE_DTYPE)
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_comm_export_host_table(self._c, size, array.ctypes.data, flags.ctypes.data), "dbgk_comm_export_host_table")
+        return array, flags
+
+    # ---- a communicator of WIDE handles (engine=ENGINE_WIDE, k <= 63)
+    def wide_export_sorted(self):
+        n = int(self.stats.count)
+        out = np.zeros(n, dtype=NODE32_DTYPE)
+        got = C.c_uint64()
+        _chk(lib().dbgk_comm_wide_export_sorted(self._c, out.ctypes.data, n, C.byref(got)), "dbgk_comm_wide_export_sorted")
+        return out[:got.value]
+
+    def wide_export_host_table(self):
+        size = self.table_slots
+        array = np.zeros(size, dtype=NODE32_DTYPE)
+        flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+        _chk(lib().dbgk_comm_wide_export_host_table(self._c, size, array.ctypes.data, flags.ctypes.data), "dbgk_comm_wide_export_host_table")
         return array, flags
 
     # ---- a communicator of frequency tables (engine=ENGINE_KFREQ)

@@ -28,6 +28,7 @@ struct dbgk_comm {
 	bool finalized = false;
 	// KFREQ communicators: every member counts its reads into a whole table of its own; at finalize member d
 	// becomes the owner of the k-mer values [kf_lo[d], kf_lo[d+1]) and adds the other members' slices to its own
+	bool wide = false;                         // members are sharded WIDE handles (k <= 63, 16-byte records)
 	bool kfreq = false;
 	std::vector<uint64_t> kf_lo;
 	uint64_t kf_distinct = 0;
@@ -79,12 +80,22 @@ extern "C" int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, 
 			c->kfreq = true;
 			one.shard_count = 0;
 			one.shard_index = 0;
+		} else if (cfg->engine == DBGK_ENGINE_WIDE) { // 128-bit keys: slot-range shards of 16-byte records (one pass: the reads stream through once)
+			c->wide = true;
+			one.shard_count = n;
+			one.shard_index = i;
+			one.n_passes = 1;
 		} else {
 			one.engine = DBGK_ENGINE_PARTITION;
 			one.shard_count = n;
 			one.shard_index = i;
 		}
 		int rc = dbgk_create(&one, &c->h[i]);
+		if (rc == DBGK_OK && c->wide && c->h[i]->wgeom.n_passes != 1) {
+			g_last_error = "dbgk_comm (WIDE): this table needs several passes over the input; a communicator streams its reads once -- "
+			               "use the per-handle protocol (dbgk_wide_begin_pass) or fewer level-1 buckets (smaller table / fewer shards)";
+			rc = DBGK_ERR_ARG;
+		}
 		if (rc == DBGK_OK && hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking) != hipSuccess) rc = DBGK_ERR_HIP;
 		if (rc == DBGK_OK && hipEventCreateWithFlags(&c->cnt_ev[i], hipEventDisableTiming) != hipSuccess) rc = DBGK_ERR_HIP;
 		if (rc != DBGK_OK) {
@@ -275,9 +286,177 @@ static int comm_exchange_and_build(dbgk_comm *c)
 	return DBGK_OK;
 }
 
+// The same steps for a communicator of WIDE handles (16-byte records, one pass): fill counts, record buckets in pieces
+// overlapped with level 2 + region build, then -- finalize only, a WIDE store is built once -- the hand-offs with 32-byte
+// entries and the side tables (keys with a zero low word, key-0 links) gathered onto shard 0.
+static int comm_wide_finalize(dbgk_comm *c)
+{
+	const uint32_t n = (uint32_t)c->h.size();
+	int rc;
+	for (dbgk_handle *h : c->h) {
+		rc = dbgk_sync(h);
+		if (rc) return rc;
+	}
+	const WPartGeom &G0 = c->h[0]->wgeom;
+	const uint64_t bucket_bytes = G0.cap1 * 16, chunk_bytes = (uint64_t)G0.Bp * bucket_bytes, cnt_chunk_bytes = (uint64_t)G0.Bp * 4;
+	for (dbgk_handle *h : c->h)
+		if (!h->wpart || h->wgeom.cap1 != G0.cap1 || h->wgeom.Bp != G0.Bp || h->wgeom.size != G0.size || !h->wpass_open) {
+			g_last_error = "dbgk_comm (WIDE): the shards do not share one bucket geometry";
+			return DBGK_ERR_STATE;
+		}
+	if (n > 1) {
+		for (uint32_t d = 0; d < n; d++) { // 1. fill counts
+			dbgk_handle *D = c->h[d];
+			rc = use_device(D);
+			if (rc) return rc;
+			for (uint32_t s = 0; s < n; s++) {
+				dbgk_handle *S = c->h[s];
+				rc = comm_copy(D, reinterpret_cast<char *>(D->winbox_cnt) + s * cnt_chunk_bytes, S,
+				               reinterpret_cast<const char *>(S->wstore.cnt1) + d * cnt_chunk_bytes, cnt_chunk_bytes, c->copy_stream[d]);
+				if (rc) return rc;
+			}
+			HIPCHK(hipEventRecord(c->cnt_ev[d], c->copy_stream[d]));
+		}
+	}
+	// 2. the record buckets, piece by piece; all copies are queued up front
+	const uint32_t pieces = std::max(1u, std::min(c->pieces, G0.Bp));
+	const uint32_t per = (G0.Bp + pieces - 1) / pieces;
+	std::vector<std::pair<uint32_t, uint32_t>> ranges;
+	for (uint32_t j0 = 0; j0 < G0.Bp; j0 += per) ranges.push_back({j0, std::min(j0 + per, G0.Bp)});
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		rc = use_device(D);
+		if (rc) return rc;
+		while (c->ev[d].size() < ranges.size()) {
+			hipEvent_t e;
+			HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			c->ev[d].push_back(e);
+		}
+		for (size_t p = 0; p < ranges.size(); p++) {
+			const uint64_t off = (uint64_t)ranges[p].first * bucket_bytes, len = (uint64_t)(ranges[p].second - ranges[p].first) * bucket_bytes;
+			if (n > 1)
+				for (uint32_t s = 0; s < n; s++) {
+					dbgk_handle *S = c->h[s];
+					rc = comm_copy(D, reinterpret_cast<char *>(D->winbox) + s * chunk_bytes + off, S,
+					               reinterpret_cast<const char *>(S->wstore.l1) + d * chunk_bytes + off, len, c->copy_stream[d]);
+					if (rc) return rc;
+				}
+			HIPCHK(hipEventRecord(c->ev[d][p], c->copy_stream[d]));
+		}
+	}
+	// 3. plan + build, piece by piece as the records arrive
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		rc = use_device(D);
+		if (rc) return rc;
+		if (n > 1) HIPCHK(hipStreamWaitEvent(D->stream, c->cnt_ev[d], 0));
+		rc = wide_plan_pass(D);
+		if (rc) return rc;
+	}
+	for (size_t p = 0; p < ranges.size(); p++)
+		for (uint32_t d = 0; d < n; d++) {
+			dbgk_handle *D = c->h[d];
+			rc = use_device(D);
+			if (rc) return rc;
+			HIPCHK(hipStreamWaitEvent(D->stream, c->ev[d][p], 0));
+			const uint32_t nb = wide_pass_buckets(D);
+			const uint32_t own0 = std::min(ranges[p].first, nb), own1 = std::min(ranges[p].second, nb);
+			if (own1 > own0) {
+				rc = wide_build_range(D, own0, own1);
+				if (rc) return rc;
+			}
+		}
+	for (uint32_t d = 0; d < n; d++) {
+		dbgk_handle *D = c->h[d];
+		D->exchanged = true;
+		rc = dbgk_finalize(D, nullptr); // ends the pass, merges the shard's own spill nodes, reads the counters
+		if (rc) return rc;
+		rc = use_device(D);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(c->copy_stream[d]));
+	}
+	// 4. hand-offs: a list of shard s is merged straight from s's memory when s and d share a device, through a scratch copy otherwise
+	auto offer = [&](dbgk_handle *S, const void *list, uint64_t count, int is_obs, int from_prev, dbgk_handle *D, bool side_nodes) -> int {
+		if (count == 0) return DBGK_OK;
+		int r = use_device(D);
+		if (r) return r;
+		const void *src = list;
+		void *scratch = nullptr;
+		if (S->device != D->device) {
+			if (hipMalloc(&scratch, count * sizeof(dbgk_node32)) != hipSuccess) return DBGK_ERR_NOMEM;
+			r = comm_copy(D, scratch, S, list, count * sizeof(dbgk_node32), D->stream);
+			src = scratch;
+		}
+		if (r == DBGK_OK)
+			r = side_nodes ? dbgk_wide_merge_nodes(D, reinterpret_cast<const dbgk_node32 *>(src), count)
+			               : dbgk_shard_merge(D, reinterpret_cast<const dbgk_node *>(src), count, is_obs, from_prev);
+		if (hipStreamSynchronize(D->stream) != hipSuccess) r = DBGK_ERR_HIP;
+		if (scratch) (void)hipFree(scratch);
+		return r;
+	};
+	for (uint32_t s = 0; s < n; s++) { // overflow observations of shard s: every shard keeps its own
+		dbgk_node *list = nullptr;
+		uint64_t cnt = 0;
+		rc = dbgk_shard_overflow(c->h[s], &list, &cnt);
+		if (rc) return rc;
+		for (uint32_t d = 0; d < n; d++) {
+			rc = offer(c->h[s], list, cnt, 1, 0, c->h[d], false);
+			if (rc) return rc;
+		}
+	}
+	std::fill(c->delivered.begin(), c->delivered.end(), 0);
+	for (uint32_t round = 0; round <= n; round++) { // nodes that ran off the end of shard s continue in shard s+1 (and, rarely, further)
+		bool any = false;
+		for (uint32_t s = 0; s < n; s++) {
+			dbgk_node *list = nullptr;
+			uint64_t v = 0;
+			rc = dbgk_shard_outgoing(c->h[s], &list, &v);
+			if (rc) return rc;
+			if (v > c->delivered[s]) {
+				rc = offer(c->h[s], reinterpret_cast<const dbgk_node32 *>(list) + c->delivered[s], v - c->delivered[s], 0, 1, c->h[(s + 1) % n], false);
+				if (rc) return rc;
+				c->delivered[s] = v;
+				any = true;
+			}
+		}
+		if (!any) break;
+		if (round == n) {
+			g_last_error = "dbgk_comm: handed-over nodes went round all shards without finding a slot (table full)";
+			return DBGK_ERR_TABLE_FULL;
+		}
+	}
+	// 5. the nodes that live outside the table (zero low word, key 0): onto shard 0
+	for (uint32_t s = 1; s < n; s++) {
+		dbgk_node32 *list = nullptr;
+		uint64_t cnt = 0;
+		rc = dbgk_shard_side_export(c->h[s], &list, &cnt);
+		if (rc) return rc;
+		rc = offer(c->h[s], list, cnt, 0, 0, c->h[0], true);
+		if (rc) return rc;
+		rc = dbgk_shard_side_clear(c->h[s]);
+		if (rc) return rc;
+	}
+	for (dbgk_handle *h : c->h) {
+		rc = use_device(h);
+		if (rc) return rc;
+		rc = read_counters(h);
+		if (rc) return rc;
+		if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+		if (h->h_ctr->error & 2u) return DBGK_ERR_CAPACITY;
+	}
+	return DBGK_OK;
+}
+
 extern "C" int dbgk_comm_flush(dbgk_comm *c)
 {
 	if (!c || c->finalized) return DBGK_ERR_STATE;
+	if (c->wide) {
+		bool pending = false;
+		for (dbgk_handle *h : c->h) pending = pending || h->pending_kmers > 0;
+		if (!pending) return DBGK_OK;
+		g_last_error = "dbgk_comm (WIDE): the record stores are built once, at dbgk_comm_finalize (expected_kmers sizes them for the whole input)";
+		return DBGK_ERR_CAPACITY;
+	}
 	if (c->kfreq) { // members are independent until finalize
 		for (dbgk_handle *h : c->h) {
 			const int rc = dbgk_flush(h);
@@ -488,6 +667,13 @@ extern "C" int dbgk_comm_finalize(dbgk_comm *c, dbgk_stats *out)
 		if (out) comm_sum_stats(c, out);
 		return DBGK_OK;
 	}
+	if (c->wide) {
+		int wrc = comm_wide_finalize(c);
+		if (wrc) return wrc;
+		c->finalized = true;
+		if (out) comm_sum_stats(c, out);
+		return DBGK_OK;
+	}
 	int rc = comm_exchange_and_build(c);
 	if (rc) return rc;
 	for (dbgk_handle *h : c->h) {
@@ -558,7 +744,7 @@ extern "C" int dbgk_comm_link_stats(dbgk_comm *c, int32_t cutoff, dbgk_link_stat
 extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
 {
 	if (!c || !array || !nul_flag || host_size < 3) return DBGK_ERR_ARG;
-	if (!c->finalized) return DBGK_ERR_STATE;
+	if (!c->finalized || c->wide || c->kfreq) return DBGK_ERR_STATE; // (WIDE: dbgk_comm_wide_export_*)
 	dbgk_stats tot;
 	comm_sum_stats(c, &tot);
 	if (tot.count > host_size) return DBGK_ERR_TABLE_FULL;
@@ -599,5 +785,62 @@ extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbg
 	array[hc].l_link = tot.polyA_l_link;
 	array[hc].r_link = tot.polyA_r_link;
 	set_flag(hc);
+	return DBGK_OK;
+}
+
+// ---- WIDE communicators: results as 32-byte nodes ----------------------------------------------------------------------
+// all nodes of the job sorted by (kmer_hi, kmer_lo), the key-0 node first; capacity >= stats.count
+extern "C" int dbgk_comm_wide_export_sorted(dbgk_comm *c, dbgk_node32 *out, uint64_t capacity, uint64_t *n_out)
+{
+	if (!c || !out || !n_out) return DBGK_ERR_ARG;
+	if (!c->finalized || !c->wide) return DBGK_ERR_STATE;
+	uint64_t at = 0;
+	for (dbgk_handle *h : c->h) {
+		uint64_t got = 0;
+		int rc = dbgk_wide_export_sorted(h, out + at, capacity - at, &got);
+		if (rc) return rc;
+		at += got;
+	}
+	*n_out = at;
+	std::sort(out, out + at, [](const dbgk_node32 &a, const dbgk_node32 &b) {
+		return a.kmer_hi < b.kmer_hi || (a.kmer_hi == b.kmer_hi && a.kmer_lo < b.kmer_lo);
+	});
+	return DBGK_OK;
+}
+
+// the host table of the whole job (host_size == the global table size): the shards' slices side by side, then the nodes that
+// live outside the table on the devices (zero low word, key 0) put on their probe chains by add_node_to_kmerset's rule
+// (kmerSet.cpp:253-273) -- the contract of dbgk_wide_export_host_table for ONE table over several GPUs
+extern "C" int dbgk_comm_wide_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node32 *array, uint8_t *nul_flag)
+{
+	if (!c || !array || !nul_flag) return DBGK_ERR_ARG;
+	if (!c->finalized || !c->wide) return DBGK_ERR_STATE;
+	if (host_size != c->h[0]->size) return DBGK_ERR_ARG;
+	dbgk_stats tot;
+	comm_sum_stats(c, &tot);
+	if (tot.count > host_size) return DBGK_ERR_TABLE_FULL;
+	memset(nul_flag, 0, host_size / 8 + 1);
+	for (dbgk_handle *h : c->h) {
+		const uint64_t lo = h->wgeom.slot_lo, len = h->tslots;
+		std::vector<uint8_t> fl(len / 8 + 1);
+		int rc = dbgk_wide_export_host_table(h, len, array + lo, fl.data());
+		if (rc) return rc;
+		memcpy(nul_flag + lo / 8, fl.data(), (len + 7) / 8); // slot ranges start at multiples of 2^r: byte-aligned
+	}
+	dbgk_handle *h0 = c->h[0];
+	int rc = use_device(h0);
+	if (rc) return rc;
+	std::vector<WNode> side(kWideSideSlots);
+	HIPCHK(hipMemcpyAsync(side.data(), h0->wside, kWideSideSlots * sizeof(WNode), hipMemcpyDeviceToHost, h0->stream));
+	HIPCHK(hipStreamSynchronize(h0->stream));
+	auto place = [&](dbgk_node32 nd) {
+		uint64_t hc = dbgk_wide::hash128(dbgk_wide::Key128{nd.kmer_hi, nd.kmer_lo}) % host_size;
+		while (nul_flag[hc >> 3] & (uint8_t)(128u >> (hc & 7u))) hc = (hc + 1 == host_size) ? 0 : hc + 1;
+		array[hc] = nd;
+		nul_flag[hc >> 3] |= (uint8_t)(128u >> (hc & 7u));
+	};
+	for (const WNode &sd : side)
+		if (sd.hi1) place(dbgk_node32{sd.hi1 - 1ull, 0ull, (uint32_t)sd.links, (uint32_t)(sd.links >> 32), 0});
+	place(dbgk_node32{0, 0, tot.polyA_l_link, tot.polyA_r_link, 0}); // DBGgraph.cpp:418
 	return DBGK_OK;
 }

@@ -403,6 +403,11 @@ int dbgk_comm_link_stats(dbgk_comm *c, int32_t kmer_freq_cutoff, dbgk_link_stats
 /* the host KmerSet of the whole job (same contract as dbgk_export_host_table): the shards side by side when
  * host_size is the global table size, otherwise every node re-seated on the host                          */
 int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
+/* cfg->engine == DBGK_ENGINE_WIDE (k <= 63, expected_kmers > 0 = what EACH member extracts): n slot-range shards of one table of
+ * 32-byte nodes; the reads stream through once (a geometry that needs several passes is refused: drive the handles yourself with
+ * dbgk_wide_begin_pass), the record stores are built at dbgk_comm_finalize.  Results of the whole job:                          */
+int dbgk_comm_wide_export_sorted(dbgk_comm *c, dbgk_node32 *out, uint64_t capacity, uint64_t *n_out);
+int dbgk_comm_wide_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node32 *array, uint8_t *nul_flag);
 /* cfg->engine == DBGK_ENGINE_KFREQ: a communicator of n whole frequency tables.  Every member counts the reads
  * dealt to it; dbgk_comm_finalize makes member d the owner of an n-th of the k-mer values and adds the other
  * members' slices of that range to its own (peer copies in chunks, overlapped with the saturating add).  The

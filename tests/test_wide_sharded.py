@@ -180,3 +180,30 @@ def test_wide_single_handle_table_beyond_2_32_slots_reads_its_input_in_passes_PA
         g.push_reads(bases, offsets)
         with pytest.raises(capi.DbgkError):
             g.finalize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_shards,pieces", [(63, 2, 1), (33, 3, 4), (31, 2, 8)])
+def test_wide_communicator_in_process_shards_PARITY_UNPINNED_above_k32(capi, oracle, k, n_shards, pieces, monkeypatch):
+    """dbgk_comm_* with DBGK_ENGINE_WIDE: the C++ side of the same flow (N shards in one process, peer copies in pieces
+    overlapped with the builds, hand-offs, side tables gathered onto shard 0) -- against the independent checker, and the
+    host table of the whole job against the consumer-side invariants"""
+    monkeypatch.setenv("DBGK_COMM_PIECES", str(pieces))
+    rng = random.Random(4000 + k + n_shards)
+    reads = _reads(rng, 400)
+    nodes, want_total = W.build(reads, k, 250)
+    want = W.as_sorted_nodes(nodes)
+    size = capi.find_next_prime_ref(1 << 26)
+    with capi.Comm(k=k, table_slots=size, devices=[0] * n_shards, expected_kmers=sum(len(r) for r in reads), engine=capi.ENGINE_WIDE,
+                   max_batch_bases=1 << 16) as c:
+        step = -(-len(reads) // (2 * n_shards))
+        for lo in range(0, len(reads), step):   # batches are dealt round robin
+            c.push_reads(*oracle.pack_reads(reads[lo:lo + step]))
+        st = c.finalize()
+        assert (int(st.total_reads), int(st.total_kmers), int(st.count)) == (len(reads), want_total, len(want))
+        assert np.array_equal(c.wide_export_sorted(), want.astype(capi.NODE32_DTYPE))
+        assert c.digest() == oracle.wide_digest(want)
+        array, flags = c.wide_export_host_table()
+        assert oracle.wide_check_host_table(array, flags, size, st.count) == 0
+        occ = np.unpackbits(flags)[:size].astype(bool)
+        assert np.array_equal(np.sort(array[occ], order=["kmer_hi", "kmer_lo"]), want.astype(capi.NODE32_DTYPE))
