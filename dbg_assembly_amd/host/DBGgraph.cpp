@@ -29,6 +29,7 @@ int Input_file_format = 1;
 string Output_prefix = "output";
 int threadNum = 10;
 KmerSet *kset = NULL;
+KmerSet128 *kset_wide = NULL;
 double initHashSize = 1.0;
 uint64_t maxDoubleHashTimes = 10;
 uint64_t doubleHashTimes = 0;
@@ -64,6 +65,7 @@ struct Session {
 	uint64_t next_progress = 0;
 	int status = DBGK_OK;
 	bool partition = false;                // PARTITION engine (streaming: records are flushed into the table as needed)
+	bool wide = false;                     // -k 33..63: WIDE engine (128-bit keys); the table has the size -i asks for, no enlarge schedule
 	// The reference's table, tracked exactly (DBGgraph.cpp:329-351): after every FULL block of BufferNum
 	// reads `count > max` decides about a doubling, and at the -e cap about abandoning the file.
 	uint64_t ref_size = 0, ref_max = 0;    // size / max of the kset the reference would hold now
@@ -130,6 +132,7 @@ void exact_count(Session &S)
 // reference's own schedule, see end_of_full_block).  No device round trip while the bound says it fits.
 void reserve_device_slots(Session &S)
 {
+	if (S.wide) return; // a WIDE table is sized once (-i); a table too small ends in DBGK_ERR_TABLE_FULL at finalize
 	if ((double)S.count_known + (double)S.bound_since <= 0.80 * (double)S.device_slots) return;
 	exact_count(S);
 	if (S.status != DBGK_OK) return;
@@ -176,6 +179,7 @@ void flush_batch(Session &S)
 void end_of_full_block(Session &S)
 {
 	S.reads_in_block = 0;
+	if (S.wide) return; // the reference's doubling schedule is defined for its 16-byte table only
 	if (S.ref_layout) S.full_block_ends.push_back(S.pos);
 	if (S.count_known + S.bound_since <= S.ref_max) return;
 	flush_batch(S);
@@ -307,6 +311,128 @@ static uint64_t input_size_bound(const vector<string> &files)
 	return total;
 }
 
+// -k 33..63 (this build only: the reference stops at 31, DBG_contig/main.cpp:100; PARITY UNPINNED).  Same host duties -- parse,
+// stream, materialise -- through the WIDE engine: 128-bit keys, 32-byte nodes, the table of the size -i asks for (the reference's
+// doubling schedule is defined for its own table only).  With a known input size (plain files) the occurrences travel as 16-byte
+// records; a table with more level-1 buckets than one pass can fan out to is built in several passes over the input files
+// (dbgk_wide_begin_pass); DBGK_GPUS=N: N slot-range shards of the table in this process (dbgk_comm_*, one pass).
+static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, uint64_t initial_size)
+{
+	S->wide = true;
+	dbgk_config cfg;
+	memset(&cfg, 0, sizeof cfg);
+	cfg.kmer_size = KmerSize;
+	cfg.max_read_len = maxReadLen;
+	cfg.device_id = getenv("DBGK_DEVICE") ? atoi(getenv("DBGK_DEVICE")) : 0;
+	cfg.engine = DBGK_ENGINE_WIDE;
+	cfg.table_slots = initial_size;
+	cfg.max_batch_bases = S->batch_limit + (1u << 16);
+	const uint64_t bound = input_size_bound(reads_files);
+	const bool records = bound > 0 && initial_size >= kPartitionMinSlots && initial_size <= kPartitionMaxSlots && !getenv("DBGK_WIDE_DIRECT");
+	cfg.expected_kmers = records ? bound : 0; // unknown input size (compressed files): fused extract + atomic insert
+	if (records && getenv("DBGK_WIDE_PASSES")) cfg.n_passes = (uint64_t)std::max(1, atoi(getenv("DBGK_WIDE_PASSES"))); // more passes than the geometry needs (small devices, tests)
+	S->device_slots = initial_size;
+	std::vector<int32_t> devices;
+	if (const char *lst = getenv("DBGK_GPU_LIST")) {
+		for (const char *p = lst; *p;) {
+			devices.push_back((int32_t)strtol(p, const_cast<char **>(&p), 10));
+			while (*p == ',' || *p == ' ') p++;
+		}
+	} else if (const char *ng = getenv("DBGK_GPUS")) {
+		for (int i = 0; i < atoi(ng); i++) devices.push_back(i);
+	}
+	int rc;
+	uint32_t n_passes = 1;
+	if (devices.size() > 1 && records) {
+		cfg.expected_kmers = std::max<uint64_t>(bound / devices.size() + (bound >> 4), 1024); // per handle (batches are dealt round robin)
+		rc = dbgk_comm_create(&cfg, devices.data(), (uint32_t)devices.size(), &S->comm);
+		if (rc != DBGK_OK) fail(*S, rc, "dbgk_comm_create");
+		else cerr << "k-mer table of " << S->device_slots << " entries (32 bytes each) over " << devices.size() << " GPU shards" << endl;
+	} else {
+		rc = dbgk_create(&cfg, &S->h);
+		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
+		else if (dbgk_wide_pass_info(S->h, &n_passes, NULL) != DBGK_OK) n_passes = 1;
+	}
+	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
+	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
+	cerr << "The initialization memory used:  " << initHashSize * 32 << " G" << endl;
+	time_end = clock();
+	cerr << "Finished! Run time: " << double(time_end - time_start) / CLOCKS_PER_SEC << endl;
+
+	cerr << "\nparse input reads files: " << endl;
+	for (uint32_t pass = 0; pass < n_passes && S->status == DBGK_OK; pass++) {
+		if (n_passes > 1) {
+			cerr << "\nPass " << pass + 1 << " of " << n_passes << " over the input (the table is completed part by part)" << endl;
+			rc = dbgk_wide_begin_pass(S->h, pass);
+			if (rc != DBGK_OK) fail(*S, rc, "dbgk_wide_begin_pass");
+			Total_reads_num = 0; // every pass reads all files again
+			S->next_progress = 0;
+		}
+		for (size_t i = 0; i < reads_files.size(); i++) {
+			cerr << "\nStart to parse reads file: " << reads_files[i] << endl;
+			if (S->status == DBGK_OK) {
+				const double t0 = now_s(), dev0 = S->t_push + S->t_count;
+				parse_one_reads_file(reads_files[i]);
+				S->t_parse += (now_s() - t0) - (S->t_push + S->t_count - dev0);
+			}
+			dbgk_stats st;
+			if (S->status == DBGK_OK && pass == 0 && (S->comm ? dbgk_comm_refresh_stats(S->comm, &st) : dbgk_refresh_stats(S->h, &st)) == DBGK_OK)
+				Kmer_total_num = st.total_kmers;
+			cerr << "\nTotal number of reads loaded into memory: " << Total_reads_num << endl;
+			cerr << "Total number of kmers loaded into memory: " << Kmer_total_num << endl;
+			time_end = clock();
+			cerr << "Finished! Run time: " << double(time_end - time_start) / CLOCKS_PER_SEC << endl;
+		}
+		if (n_passes > 1 && S->status == DBGK_OK) {
+			rc = dbgk_wide_end_pass(S->h);
+			if (rc != DBGK_OK) fail(*S, rc, "dbgk_wide_end_pass");
+		}
+	}
+	dbgk_stats st;
+	memset(&st, 0, sizeof st);
+	if (S->status == DBGK_OK) {
+		Stopwatch sw(S->t_finalize);
+		rc = S->comm ? dbgk_comm_finalize(S->comm, &st) : dbgk_finalize(S->h, &st);
+		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
+	}
+	const double t_export0 = now_s();
+	KmerSet128 *result = NULL;
+	if (S->status == DBGK_OK) {
+		Kmer_total_num = st.total_kmers;
+		KmerNode32 *array = static_cast<KmerNode32 *>(malloc(initial_size * sizeof(KmerNode32)));
+		uint8_t *nul = static_cast<uint8_t *>(malloc(initial_size / 8 + 1)), *del = static_cast<uint8_t *>(calloc(initial_size / 8 + 1, 1));
+		if (!array || !nul || !del) {
+			free(array), free(nul), free(del);
+			fail(*S, DBGK_ERR_NOMEM, "host table allocation");
+		} else {
+			rc = S->comm ? dbgk_comm_wide_export_host_table(S->comm, initial_size, reinterpret_cast<dbgk_node32 *>(array), nul)
+			             : dbgk_wide_export_host_table(S->h, initial_size, reinterpret_cast<dbgk_node32 *>(array), nul);
+			if (rc != DBGK_OK) {
+				free(array), free(nul), free(del);
+				fail(*S, rc, "dbgk_wide_export_host_table");
+			} else {
+				result = adopt_kmerset128(initial_size, hashLoadFactor, st.count, st.count_conflict, array, nul, del);
+			}
+		}
+	}
+	if (kset_wide) free_hash128(kset_wide);
+	kset_wide = result;
+	// the 64-bit container stays valid and empty (only the key-0 node): code that looks at `kset` keeps working
+	if (kset) free_hash(kset);
+	kset = init_kmerset_parallel(3, hashLoadFactor, std::max(threadNum, 1));
+	KmerNode zero = {0, 0, 0};
+	add_node_to_kmerset(kset, &zero);
+	DbgkLastStatus = S->status;
+	S->t_export = now_s() - t_export0;
+	if (getenv("DBGK_TIMINGS"))
+		cerr << "Host phases (s): create " << S->t_create << " read+parse " << S->t_parse << " push " << S->t_push << " count/flush " << S->t_count
+		     << " finalize " << S->t_finalize << " host table " << S->t_export << endl;
+	cerr << "\nKmerset hash parameters (128-bit keys, 32-byte nodes):" << endl;
+	if (kset_wide)
+		cerr << "array_size: " << kset_wide->size << "\nload_factor: " << kset_wide->load_factor << "\nmax_cutoff: " << kset_wide->max
+		     << "\ncount: " << kset_wide->count << "\ncount_conflict: " << kset_wide->count_conflict << endl;
+}
+
 void build_debruijn_graph(vector<string> &reads_files)
 {
 	time_start = clock();
@@ -331,6 +457,11 @@ void build_debruijn_graph(vector<string> &reads_files)
 	if (const char *mb = getenv("DBGK_BATCH_MB")) S->batch_limit = std::max<uint64_t>(1, strtoull(mb, NULL, 10)) << 20;
 	if (const char *bb = getenv("DBGK_BATCH_BYTES")) S->batch_limit = std::max<uint64_t>(1024, strtoull(bb, NULL, 10)); // tests: many small batches
 	S->bases.reserve(S->batch_limit + (1u << 16));
+	if (KmerSize > 32) return build_debruijn_graph_wide(reads_files, S, initial_size);
+	if (kset_wide) {
+		free_hash128(kset_wide);
+		kset_wide = NULL;
+	}
 
 	S->ref_layout = getenv("DBGK_LAYOUT") && string(getenv("DBGK_LAYOUT")) == "ref";
 	dbgk_config cfg;
@@ -526,6 +657,22 @@ int write_table_image(const string &path)
 
 int write_sorted_dump(const string &path)
 {
+	if (KmerSize > 32) { // 128-bit keys: kmer_hi, kmer_lo, l_link, r_link of every node, sorted by (hi, lo)
+		if (!kset_wide) return DBGK_ERR_STATE;
+		std::vector<KmerNode32> wn;
+		wn.reserve(kset_wide->count);
+		for (uint64_t i = 0; i < kset_wide->size; i++)
+			if (!is_entity_null(kset_wide->nul_flag, i)) wn.push_back(kset_wide->array[i]);
+		std::sort(wn.begin(), wn.end(), [](const KmerNode32 &a, const KmerNode32 &b) { return a.kmer_hi < b.kmer_hi || (a.kmer_hi == b.kmer_hi && a.kmer_lo < b.kmer_lo); });
+		FILE *wf = fopen(path.c_str(), "w");
+		if (!wf) return DBGK_ERR_ARG;
+		fprintf(wf, "#reads %llu kmers %llu count %llu\n", (unsigned long long)Total_reads_num, (unsigned long long)Kmer_total_num,
+		        (unsigned long long)kset_wide->count);
+		for (const KmerNode32 &n : wn)
+			fprintf(wf, "%llu\t%llu\t%08x\t%08x\n", (unsigned long long)n.kmer_hi, (unsigned long long)n.kmer_lo, n.l_link, n.r_link);
+		fclose(wf);
+		return DBGK_OK;
+	}
 	if (!kset) return DBGK_ERR_STATE;
 	std::vector<KmerNode> nodes;
 	nodes.reserve(kset->count);

@@ -29,6 +29,7 @@ extern int Input_file_format;        // -f  1 = one-line FASTQ(.gz), 2 = one-lin
 extern string Output_prefix;         // -o
 extern int threadNum;                // -t  host threads (table zeroing, consumer); the GPU does the hashing
 extern KmerSet *kset;                // THE result
+extern KmerSet128 *kset_wide;        // ... for -k 33..63 (this build only; kset then holds just the key-0 node)
 extern double initHashSize;          // -i  initial table size in units of 1e9 slots (16 GB each)
 extern uint64_t maxDoubleHashTimes;  // -e
 extern uint64_t doubleHashTimes;     // doublings the reference would have performed for this input

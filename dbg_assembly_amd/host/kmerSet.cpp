@@ -198,3 +198,42 @@ void print_kmerset_parameter(KmerSet *set)
 }
 
 uint8_t get_next_kmer_depth(uint32_t link, uint8_t base) { return (uint8_t)(link >> ((3 - base) * 8)); }
+
+// ---- 128-bit keys (k = 33..63; this build only, see kmerSet.h) -------------------------------------------------------------
+uint64_t exist_kmerset128(KmerSet128 *set, uint64_t kmer_hi, uint64_t kmer_lo)
+{
+	uint64_t hc = hash_code128(kmer_hi, kmer_lo) % set->size; // exist_kmerset's walk (kmerSet.cpp:280-302)
+	for (;;) {
+		if (is_entity_null(set->nul_flag, hc)) return set->size;
+		if (set->array[hc].kmer_hi == kmer_hi && set->array[hc].kmer_lo == kmer_lo) return is_entity_delete(set->del_flag, hc) ? set->size : hc;
+		hc = (hc + 1 == set->size) ? 0 : hc + 1;
+	}
+}
+
+void free_hash128(KmerSet128 *set)
+{
+	if (!set) return;
+	free(set->array);
+	free(set->nul_flag);
+	free(set->del_flag);
+	free(set);
+}
+
+KmerSet128 *adopt_kmerset128(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict, KmerNode32 *array, uint8_t *nul_flag,
+                             uint8_t *del_flag)
+{
+	KmerSet128 *set = static_cast<KmerSet128 *>(malloc(sizeof(KmerSet128)));
+	if (!set) return NULL;
+	set->e_size = sizeof(KmerNode32);
+	set->size = size;
+	set->count = count;
+	set->count_conflict = count_conflict;
+	set->load_factor = load_factor <= 0 ? 0.25f : (load_factor >= 1 ? 0.75f : load_factor);
+	set->max = (uint64_t)((float)size * set->load_factor);
+	set->iter_ptr = 0;
+	set->array = array;
+	set->nul_flag = nul_flag;
+	set->del_flag = del_flag;
+	return set;
+}
+

@@ -86,6 +86,40 @@ uint8_t get_next_kmer_depth(uint32_t link, uint8_t base);
 void *thread_memset(void *paras);
 void *memset_parallel(void *pointer, int value, uint64_t memsize, int threadNum);
 
+// ---- k-mers of 33..63 bases (this build only: the reference stops at k = 31, DBG_contig/main.cpp:100) --------------------
+// The same container carried to 128-bit keys: a 32-byte node {kmer_hi, kmer_lo, l_link, r_link, reserved} (layout of
+// dbgk_node32, include/dbgk_wide.h), the same control block, the same flag arrays; a key lives on the linear-probe chain that
+// starts at hash_code128(hi, lo) % size, where hash_code128 is hash_code(lo) for hi == 0 -- the reference's slot for every
+// k <= 32 -- and hash_code(lo ^ hash_code(hi)) otherwise.  PARITY UNPINNED: nothing in the reference defines these.
+typedef struct {
+	uint64_t kmer_hi;          // bases 0 .. k-33 of the k-mer (2 bits each, first base most significant)
+	uint64_t kmer_lo;          // the last 32 bases
+	uint32_t l_link;           // as KmerNode
+	uint32_t r_link;
+	uint64_t reserved;
+} KmerNode32;
+
+typedef struct {
+	uint32_t e_size;           // 32
+	uint64_t size;
+	uint64_t count;
+	uint64_t count_conflict;
+	uint64_t max;
+	float load_factor;
+	uint64_t iter_ptr;
+	KmerNode32 *array;
+	uint8_t *nul_flag;
+	uint8_t *del_flag;
+} KmerSet128;
+
+static_assert(sizeof(KmerNode32) == 32, "KmerNode32 must be 32 bytes");
+
+inline uint64_t hash_code128(uint64_t hi, uint64_t lo) { return hash_code(hi ? (lo ^ hash_code(hi)) : lo); }
+uint64_t exist_kmerset128(KmerSet128 *set, uint64_t kmer_hi, uint64_t kmer_lo);   // slot index, or set->size when absent/deleted (exist_kmerset's rule)
+void free_hash128(KmerSet128 *set);
+KmerSet128 *adopt_kmerset128(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict, KmerNode32 *array, uint8_t *nul_flag,
+                             uint8_t *del_flag);
+
 // wraps already-filled arrays (as produced by dbgk_export_host_table) into a KmerSet control block
 KmerSet *adopt_kmerset(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict,
                        KmerNode *array, uint8_t *nul_flag, uint8_t *del_flag);

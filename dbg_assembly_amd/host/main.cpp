@@ -33,7 +33,7 @@ void build_contig_sequence() __attribute__((weak));  // DBG_contig/contig.h:67, 
 static void print_options(ostream &os, bool with_k_max)
 {
 	// option letters, argument kinds, defaults and order follow the reference (DBG_contig/main.cpp:97-124); the wording is ours
-	os << "   -k <int>    k-mer length" << (with_k_max ? " (at most 31)" : "") << " [" << KmerSize << "]" << endl
+	os << "   -k <int>    k-mer length" << (with_k_max ? " (the contig stage: at most 31; graph stage alone: up to 63, 128-bit keys)" : "") << " [" << KmerSize << "]" << endl
 	   << "   -r <int>    longest read length used; longer reads are cut to this [" << maxReadLen << "]" << endl
 	   << "   -f <int>    input format: 1 = FASTQ, 2 = FASTA, one sequence per line, plain or .gz [" << Input_file_format << "]" << endl
 	   << "   -o <str>    prefix of the output files [" << Output_prefix << "]" << endl
@@ -120,7 +120,11 @@ int main(int argc, char *argv[])
 	if (const char *dump = getenv("DBGK_DUMP")) write_sorted_dump(dump);
 	if (const char *img = getenv("DBGK_DUMP_TABLE")) write_table_image(img);
 
-	if (build_contig_sequence) {
+	if (KmerSize > 32) { // the reference's consumer is written for 64-bit k-mers (uint64_t kmer, DBG_contig/kmerSet.h:71)
+		cerr << "\nStart to calulate kmer links information!" << endl;
+		write_kmer_freq_file(Output_prefix + ".contig.kmer.freq", KmerFreqCutoff);
+		cerr << "\nGraph stage finished: k = " << KmerSize << " graph in kset_wide (32-byte nodes); the contig stage handles k <= 31 only" << endl;
+	} else if (build_contig_sequence) {
 		build_contig_sequence();
 		cerr << "\nRemove tips, merge bubbles, output contig sequence finished !" << endl;
 		cerr << "\nAssembly completely finished!" << endl;

@@ -155,3 +155,49 @@ def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, oracle, store):
     rows = open(str(prefix) + ".contig.kmer.freq").read().splitlines()
     assert rows[0] == KMER_FREQ_HEADER and [int(x.split("\t")[1]) for x in rows[1:]] == gold["depth_stat"][1:]
     os.remove(fa)
+
+
+@pytest.mark.parametrize("k,env", [(63, {}), (33, {"DBGK_WIDE_PASSES": "3"}), (47, {"DBGK_GPU_LIST": "0,0,0"}), (63, {"DBGK_WIDE_DIRECT": "1"})],
+                         ids=["k63", "k33_three_passes", "k47_three_shards", "k63_atomic_kernels"])
+def test_cli_k_above_32_emits_the_128_bit_graph_PARITY_UNPINNED(tmp_path, k, env):
+    """`debruijn_contig -k 33..63` (this build only: the reference stops at 31): files -> WIDE engine -> host KmerSet128 ->
+    sorted node dump + <prefix>.contig.kmer.freq, against the independent checker (tests/wide_checker.py); through 16-byte
+    records in one pass, in three passes over the input files, over three in-process GPU shards, and through the atomic kernels"""
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import wide_checker as W
+    from test_wide_checker import _reads
+    rng = random.Random(1000 + k)
+    reads = [r for r in _reads(rng, 300) if r]   # (an empty line would not be a read of a one-line FASTA file)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as fh:
+        for i, r in enumerate(reads):
+            fh.write(b">r%d\n" % i + r + b"\n")
+    libf = tmp_path / "reads.lib"
+    libf.write_text(str(fa) + "\n")
+    dump, prefix = tmp_path / "dump.txt", tmp_path / "out"
+    run_env = dict(os.environ, DBGK_DUMP=str(dump), DBGK_BATCH_BYTES="20000")
+    run_env.update(env)
+    cmd = [CLI, "-k", str(k), "-r", "120", "-f", "2", "-t", "4", "-i", "0.0672", "-o", str(prefix), str(libf)]
+    r = subprocess.run(cmd, env=run_env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    nodes, total = W.build(reads, k, 120)
+    want = W.as_sorted_nodes(nodes)
+    lines = dump.read_text().splitlines()
+    assert lines[0] == "#reads %d kmers %d count %d" % (len(reads), total, len(want))
+    got = [tuple(int(x, 16) if i >= 2 else int(x) for i, x in enumerate(l.split("\t"))) for l in lines[1:]]
+    assert got == [(int(n["kmer_hi"]), int(n["kmer_lo"]), int(n["l_link"]), int(n["r_link"])) for n in want]
+    assert "Total number of kmers loaded into memory: %d" % total in r.stderr
+    assert re.search(r"^count: %d$" % len(want), r.stderr, re.M)
+    if "DBGK_WIDE_PASSES" in env:
+        assert "Pass 3 of 3 over the input" in r.stderr
+    # <prefix>.contig.kmer.freq: DepthStat[1..255] of all 8 counters of every node
+    depth = [0] * 256
+    for n in want:
+        for w in (int(n["l_link"]), int(n["r_link"])):
+            for s in (24, 16, 8, 0):
+                depth[(w >> s) & 0xFF] += 1
+    rows = (tmp_path / "out.contig.kmer.freq").read_text().splitlines()
+    assert rows[0] == KMER_FREQ_HEADER and len(rows) == 1 + KMER_FREQ_ROWS
+    assert [int(x.split("\t")[1]) for x in rows[1:]] == depth[1:]
