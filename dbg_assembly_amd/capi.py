@@ -90,6 +90,7 @@ SYMBOLS = [
     ("dbgk_store_room", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("dbgk_copy_nodes_peer", _i, [_vp, _vp, _vp, _vp, _u64]),
     ("dbgk_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_export_host_table_links", _i, [_vp, _u64, _vp, _vp, C.c_int32, _vp, _vp, _vp, _u64, C.POINTER(_u64), _vp, _u64, C.POINTER(_u64), _vp]),
     ("dbgk_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_export_first_seen_order", _i, [_vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_digest", _i, [_vp, C.POINTER(_u64)]),
@@ -287,6 +288,23 @@ class Graph:
         flags = np.zeros(size // 8 + 1, dtype=np.uint8)
         _chk(lib().dbgk_export_host_table(self._h, size, array.ctypes.data, flags.ctypes.data), "dbgk_export_host_table")
         return array, flags
+
+    def export_host_table_links(self, cutoff=2, host_size=None):
+        """dbgk_export_host_table + the consumer's whole first pass (calculate_kmer_links, contig.cpp:107-181) for that table:
+        -> (array, nul_flag, klink u16[size], del_flag, tip slots, branch slots, LinkStats)"""
+        size = self.table_slots if host_size is None else host_size
+        array = np.zeros(size, dtype=NODE_DTYPE)
+        flags = np.zeros(size // 8 + 1, dtype=np.uint8)
+        klink = np.zeros(size, dtype=np.uint16)
+        dele = np.zeros(size // 8 + 1, dtype=np.uint8)
+        cap = int(self.stats.count)
+        tips, branches = np.zeros(max(cap, 1), dtype=np.uint64), np.zeros(max(cap, 1), dtype=np.uint64)
+        nt, nb = C.c_uint64(), C.c_uint64()
+        st = LinkStats()
+        _chk(lib().dbgk_export_host_table_links(self._h, size, array.ctypes.data, flags.ctypes.data, cutoff, klink.ctypes.data, dele.ctypes.data,
+                                                tips.ctypes.data, cap, C.byref(nt), branches.ctypes.data, cap, C.byref(nb), C.byref(st)),
+             "dbgk_export_host_table_links")
+        return array, flags, klink, dele, tips[:nt.value], branches[:nb.value], st
 
     def export_first_seen_order(self):
         n = self.stats.count - 1

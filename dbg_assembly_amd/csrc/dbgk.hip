@@ -2005,7 +2005,121 @@ __global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restri
 	}
 }
 
+// what the link pass of an export returns (all optional)
+struct LinkOutputs {
+	int32_t cutoff = 0;
+	uint16_t *klink = nullptr;
+	uint8_t *del_flag = nullptr;
+	uint64_t *tips = nullptr, *branches = nullptr;
+	uint64_t tip_cap = 0, branch_cap = 0;
+	uint64_t *n_tips = nullptr, *n_branches = nullptr;
+	dbgk_link_stats *stats = nullptr;
+};
+
+static int export_host_table_impl(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, const LinkOutputs *LO);
+
 extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag)
+{
+	return export_host_table_impl(h, host_size, array, nul_flag, nullptr);
+}
+
+extern "C" int dbgk_export_host_table_links(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, int32_t kmer_freq_cutoff,
+                                            uint16_t *klink, uint8_t *del_flag, uint64_t *tip_nodes, uint64_t tip_capacity, uint64_t *n_tips,
+                                            uint64_t *branch_nodes, uint64_t branch_capacity, uint64_t *n_branches, dbgk_link_stats *stats)
+{
+	if (!klink || !del_flag || !n_tips || !n_branches) return DBGK_ERR_ARG;
+	if (h && h->sharded) return DBGK_ERR_STATE; // slot numbers are those of ONE table: export the shards, assemble, then scan (or use one handle)
+	LinkOutputs LO;
+	LO.cutoff = kmer_freq_cutoff;
+	LO.klink = klink;
+	LO.del_flag = del_flag;
+	LO.tips = tip_nodes;
+	LO.branches = branch_nodes;
+	LO.tip_cap = tip_nodes ? tip_capacity : 0;
+	LO.branch_cap = branch_nodes ? branch_capacity : 0;
+	LO.n_tips = n_tips;
+	LO.n_branches = n_branches;
+	LO.stats = stats;
+	return export_host_table_impl(h, host_size, array, nul_flag, &LO);
+}
+
+// the link pass on the host-layout image T (key-0 node placed, ctr->polyA_slot set)
+static int run_link_pass(dbgk_handle *h, const TableRef &T, const LinkOutputs &LO)
+{
+	const uint64_t n_blocks = (T.size + kLinkChunk - 1) / kLinkChunk;
+	uint16_t *d_klink = nullptr;
+	uint8_t *d_del = nullptr;
+	unsigned long long *d_stats = nullptr, *d_base = nullptr, *d_tips = nullptr, *d_branches = nullptr;
+	uint32_t *d_counts = nullptr;
+	auto cleanup = [&]() {
+		for (void *p : {(void *)d_klink, (void *)d_del, (void *)d_stats, (void *)d_base, (void *)d_tips, (void *)d_branches, (void *)d_counts})
+			if (p) (void)hipFree(p);
+	};
+	if (hipMalloc(&d_klink, T.size * 2) != hipSuccess || hipMalloc(&d_del, T.size / 8 + 1) != hipSuccess || hipMalloc(&d_stats, 261 * 8) != hipSuccess ||
+	    hipMalloc(&d_counts, n_blocks * 8) != hipSuccess || hipMalloc(&d_base, n_blocks * 16) != hipSuccess) {
+		cleanup();
+		return DBGK_ERR_NOMEM;
+	}
+	hipError_t e = hipMemsetAsync(d_stats, 0, 261 * 8, h->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_del, 0, T.size / 8 + 1, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_kmer_links<0>, dim3((unsigned)n_blocks), dim3(kBlock), 0, h->stream, T.nodes, T.size, h->d_ctr, (int)LO.cutoff, d_klink, d_del, d_stats,
+		                   d_counts, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+		e = hipGetLastError();
+	}
+	std::vector<uint32_t> counts(n_blocks * 2);
+	std::vector<unsigned long long> base(n_blocks * 2);
+	unsigned long long res[261];
+	if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_counts, n_blocks * 8, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(res, d_stats, sizeof res, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(LO.klink, d_klink, T.size * 2, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(LO.del_flag, d_del, T.size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) {
+		cleanup();
+		return hip_fail(e, "export_host_table_links", __LINE__);
+	}
+	unsigned long long nt = 0, nb = 0;
+	for (uint64_t b = 0; b < n_blocks; b++) {
+		base[2 * b] = nt;
+		base[2 * b + 1] = nb;
+		nt += counts[2 * b];
+		nb += counts[2 * b + 1];
+	}
+	*LO.n_tips = nt;
+	*LO.n_branches = nb;
+	if (LO.stats) {
+		for (int i = 0; i < 256; i++) LO.stats->depth_stat[i] = (int64_t)res[i];
+		LO.stats->total_nodes = (int64_t)res[256];
+		LO.stats->deleted_lowfreq = (int64_t)res[257];
+		LO.stats->linear_nodes = (int64_t)res[258];
+		LO.stats->tip_nodes = (int64_t)res[259];
+		LO.stats->branch_nodes = (int64_t)res[260];
+	}
+	int rc = DBGK_OK;
+	if ((LO.tips || LO.branches) && (nt || nb)) {
+		if ((LO.tips && nt > LO.tip_cap) || (LO.branches && nb > LO.branch_cap)) {
+			rc = DBGK_ERR_CAPACITY; // *n_tips / *n_branches say what is needed
+		} else if (hipMalloc(&d_tips, (nt ? nt : 1) * 8) != hipSuccess || hipMalloc(&d_branches, (nb ? nb : 1) * 8) != hipSuccess) {
+			rc = DBGK_ERR_NOMEM;
+		} else {
+			e = hipMemcpyAsync(d_base, base.data(), n_blocks * 16, hipMemcpyHostToDevice, h->stream);
+			if (e == hipSuccess) {
+				hipLaunchKernelGGL(k_kmer_links<1>, dim3((unsigned)n_blocks), dim3(kBlock), 0, h->stream, T.nodes, T.size, h->d_ctr, (int)LO.cutoff, d_klink, d_del,
+				                   d_stats, d_counts, d_base, d_tips, d_branches);
+				e = hipGetLastError();
+			}
+			if (e == hipSuccess && LO.tips && nt) e = hipMemcpyAsync(LO.tips, d_tips, nt * 8, hipMemcpyDeviceToHost, h->stream);
+			if (e == hipSuccess && LO.branches && nb) e = hipMemcpyAsync(LO.branches, d_branches, nb * 8, hipMemcpyDeviceToHost, h->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+			if (e != hipSuccess) rc = hip_fail(e, "export_host_table_links(lists)", __LINE__);
+		}
+	}
+	cleanup();
+	return rc;
+}
+
+static int export_host_table_impl(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, const LinkOutputs *LO)
 {
 	if (h && h->seed) return DBGK_ERR_STATE; // SEEDIDX handles: use dbgk_seed_export_*
 	if (h && h->wide) return DBGK_ERR_STATE;  // WIDE handles: dbgk_wide_export_*
@@ -2050,6 +2164,8 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(array, T.nodes, host_size * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	int link_rc = DBGK_OK;
+	if (e == hipSuccess && LO) link_rc = run_link_pass(h, T, *LO); // on the very image that is being copied out
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_unplace_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
 		e = hipGetLastError();
@@ -2058,7 +2174,8 @@ extern "C" int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_n
 	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	cleanup();
 	if (e != hipSuccess) return hip_fail(e, "export_host_table", __LINE__);
-	return (h->h_ctr->error & 1u) ? DBGK_ERR_TABLE_FULL : DBGK_OK;
+	if (h->h_ctr->error & 1u) return DBGK_ERR_TABLE_FULL;
+	return link_rc;
 }
 
 extern "C" int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out)

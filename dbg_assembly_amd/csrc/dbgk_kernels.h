@@ -944,6 +944,118 @@ __global__ __launch_bounds__(kBlock) void k_link_stats(const Node *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The WHOLE first pass of the consumer, calculate_kmer_links (DBG_contig/contig.cpp:107-181), on the host-layout image of
+// the table (the one dbgk_export_host_table is about to copy out): per slot the 2-byte KmerLink record (contig.h:31-42:
+// l_link_num:2 | l_link_base:2 | r_link_num:2 | r_link_base:2 in the first byte, linear in bit 0 of the second), the
+// del_flag bit of nodes without any link above the cutoff (MSB first like nul_flag, set_entity_delete kmerSet.h:161-164),
+// DepthStat / class counts, and tip_nodes / branch_nodes as ASCENDING slot lists (the order of the reference's slot loop,
+// :119).  One block owns kLinkChunk consecutive slots; PASS 0 counts its tips / branches, the host prefix-sums the block
+// counts, PASS 1 writes the lists in order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLinkChunk = 4096; // slots per block: 16 sweeps of 256 threads
+
+__device__ __forceinline__ uint32_t kmer_link_record(uint64_t links, int cutoff)
+{
+	// contig.cpp:129-163: a side's link number = counters above the cutoff (at most 3: a 2-bit field), its base = the FIRST
+	// base with the largest such counter (strict <), 0 when there is none
+	uint32_t rec = 0;
+#pragma unroll
+	for (int side = 0; side < 2; side++) {
+		const uint32_t w = side ? (uint32_t)(links >> 32) : (uint32_t)links;
+		int num = 0, best = 0, base = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int d = (int)((w >> (24 - 8 * j)) & 0xFFu); // get_next_kmer_depth (kmerSet.cpp:341-344): A in bits 31..24
+			if (d > cutoff) {
+				if (num < 3) num++;
+				if (best < d) { best = d; base = j; }
+			}
+		}
+		rec |= ((uint32_t)num | ((uint32_t)base << 2)) << (4 * side);
+	}
+	if ((rec & 3u) == 1u && ((rec >> 4) & 3u) == 1u) rec |= 1u << 8; // linear: exactly one link on each side (:170-173)
+	return rec;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void k_kmer_links(const Node *__restrict__ nodes, uint64_t size, const Counters *__restrict__ ctr, int cutoff,
+                                                       uint16_t *__restrict__ klink, uint8_t *__restrict__ del_flag, unsigned long long *__restrict__ stats,
+                                                       uint32_t *__restrict__ block_counts, const unsigned long long *__restrict__ block_base,
+                                                       unsigned long long *__restrict__ tips, unsigned long long *__restrict__ branches)
+{
+	__shared__ unsigned int hist[256];
+	__shared__ unsigned long long red[kBlock / 64];
+	__shared__ unsigned int wave_cnt[2][kBlock / 64];
+	__shared__ unsigned long long run[2];
+	const uint64_t polyA_slot = ctr->polyA_slot; // where the key-0 node was placed for this export
+	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	if (PASS == 0) hist[t] = 0; // kBlock == 256
+	if (t == 0) {
+		run[0] = PASS ? block_base[2 * blockIdx.x] : 0ull;
+		run[1] = PASS ? block_base[2 * blockIdx.x + 1] : 0ull;
+	}
+	__syncthreads();
+	unsigned long long cls[5] = {0, 0, 0, 0, 0};
+	const uint64_t first = (uint64_t)blockIdx.x * kLinkChunk;
+	for (int sweep = 0; sweep < kLinkChunk / kBlock; sweep++) {
+		const uint64_t i = first + (uint64_t)sweep * kBlock + t;
+		bool occ = false;
+		uint32_t rec = 0;
+		if (i < size) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(&nodes[i]);
+			const uint64_t key = ((uint64_t)v.y << 32) | v.x, links = ((uint64_t)v.w << 32) | v.z;
+			occ = key != 0ull || i == polyA_slot;
+			if (occ) {
+				rec = kmer_link_record(links, cutoff);
+				if (PASS == 0) link_classes(links, cutoff, hist, cls);
+			}
+		}
+		const uint32_t ln = rec & 3u, rn = (rec >> 4) & 3u;
+		const bool del = occ && ln == 0u && rn == 0u, tip = occ && ln + rn == 1u, branch = occ && (ln > 1u || rn > 1u);
+		if (PASS == 0) {
+			if (i < size) klink[i] = (uint16_t)rec;
+			// del_flag byte of 8 consecutive slots, bit of slot i = 128 >> (i % 8): lanes 8b .. 8b+7 of the wave's ballot
+			const unsigned long long m = __ballot(del);
+			if ((lane & 7u) == 0u && i < size) {
+				const uint32_t bits = (uint32_t)(m >> lane) & 0xFFu;
+				del_flag[i >> 3] = (uint8_t)(__brev(bits) >> 24);
+			}
+		}
+		// ordered positions: threads in slot order inside a sweep, sweeps in order
+		const unsigned long long mt = __ballot(tip), mb = __ballot(branch);
+		const unsigned long long below = (1ull << lane) - 1ull;
+		if (lane == 0u) {
+			wave_cnt[0][wave] = (unsigned int)__popcll(mt);
+			wave_cnt[1][wave] = (unsigned int)__popcll(mb);
+		}
+		__syncthreads();
+		if (PASS == 1) {
+			unsigned long long bt = run[0], bb = run[1];
+			for (uint32_t w = 0; w < wave; w++) { bt += wave_cnt[0][w]; bb += wave_cnt[1][w]; }
+			if (tip) tips[bt + (unsigned long long)__popcll(mt & below)] = i;
+			if (branch) branches[bb + (unsigned long long)__popcll(mb & below)] = i;
+		}
+		__syncthreads();
+		if (t == 0) {
+			for (uint32_t w = 0; w < kBlock / 64; w++) { run[0] += wave_cnt[0][w]; run[1] += wave_cnt[1][w]; }
+		}
+		__syncthreads();
+	}
+	if (PASS == 0) {
+		if (t == 0) {
+			block_counts[2 * blockIdx.x] = (uint32_t)run[0];
+			block_counts[2 * blockIdx.x + 1] = (uint32_t)run[1];
+		}
+		if (hist[t]) atomicAdd(&stats[t], (unsigned long long)hist[t]);
+#pragma unroll
+		for (int c = 0; c < 5; c++) {
+			const unsigned long long s = block_sum(cls[c], red);
+			if (t == 0 && s) atomicAdd(&stats[256 + c], s);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-GPU: nodes grouped by owner = (hash_code(key) >> 32) % n_parts; key 0 -> part 0
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxParts = 64;

@@ -49,6 +49,10 @@ clock_t time_start;
 clock_t time_end;
 
 int DbgkLastStatus = 0;
+uint16_t *DbgkKmerLinks = NULL;
+vector<uint64_t> DbgkTipNodes;
+vector<uint64_t> DbgkBranchNodes;
+extern int KmerFreqCutoff __attribute__((weak)); // -D of the contig stage (defined by main.cpp / contig.cpp when linked in)
 
 namespace {
 
@@ -583,8 +587,25 @@ void build_debruijn_graph(vector<string> &reads_files)
 				free(array), free(nul), free(del);
 				fail(*S, DBGK_ERR_NOMEM, "host table allocation");
 			} else {
-				rc = S->comm ? dbgk_comm_export_host_table(S->comm, use_size, reinterpret_cast<dbgk_node *>(array), nul)
-				             : dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
+				const bool links = getenv("DBGK_LINKS") && atoi(getenv("DBGK_LINKS")) != 0 && !S->comm;
+				if (links) { // the consumer's first pass on the device, for exactly this table
+					free(DbgkKmerLinks);
+					DbgkKmerLinks = static_cast<uint16_t *>(malloc(use_size * sizeof(uint16_t)));
+					DbgkTipNodes.assign(st.count ? st.count : 1, 0);
+					DbgkBranchNodes.assign(st.count ? st.count : 1, 0);
+					uint64_t nt = 0, nb = 0;
+					const int cutoff = &KmerFreqCutoff ? KmerFreqCutoff : 2;
+					rc = DbgkKmerLinks ? dbgk_export_host_table_links(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul, cutoff, DbgkKmerLinks, del,
+					                                                  DbgkTipNodes.data(), DbgkTipNodes.size(), &nt, DbgkBranchNodes.data(),
+					                                                  DbgkBranchNodes.size(), &nb, NULL)
+					                   : DBGK_ERR_NOMEM;
+					DbgkTipNodes.resize(rc == DBGK_OK ? nt : 0);
+					DbgkBranchNodes.resize(rc == DBGK_OK ? nb : 0);
+					if (rc == DBGK_OK) cerr << "First pass of the contig stage done on the GPU: " << nt << " tip nodes, " << nb << " branching nodes" << endl;
+				} else {
+					rc = S->comm ? dbgk_comm_export_host_table(S->comm, use_size, reinterpret_cast<dbgk_node *>(array), nul)
+					             : dbgk_export_host_table(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul);
+				}
 				if (rc != DBGK_OK) {
 					free(array), free(nul), free(del);
 					fail(*S, rc, "dbgk_export_host_table");
@@ -638,6 +659,22 @@ int write_kmer_freq_file(const string &path, int kmer_freq_cutoff)
 	cerr << "Used branching kmer nodes:  " << ls.branch_nodes << "\t" << (double)ls.branch_nodes / ls.total_nodes << endl;
 	out << "Kmer_depth\tAppear_times\n";
 	for (int i = 1; i <= 255; i++) out << i << "\t" << ls.depth_stat[i] << endl;
+	return DBGK_OK;
+}
+
+int write_links_dump(const string &path)
+{
+	// what DBGK_LINKS=1 left behind: `K slot record(hex) deleted` for every occupied slot, then `T slot` / `B slot` lines
+	if (!kset || !DbgkKmerLinks) return DBGK_ERR_STATE;
+	FILE *fp = fopen(path.c_str(), "w");
+	if (!fp) return DBGK_ERR_ARG;
+	fprintf(fp, "#size %llu tips %llu branches %llu\n", (unsigned long long)kset->size, (unsigned long long)DbgkTipNodes.size(),
+	        (unsigned long long)DbgkBranchNodes.size());
+	for (uint64_t i = 0; i < kset->size; i++)
+		if (!is_entity_null(kset->nul_flag, i)) fprintf(fp, "K\t%llu\t%04x\t%d\n", (unsigned long long)i, DbgkKmerLinks[i], is_entity_delete(kset->del_flag, i));
+	for (uint64_t v : DbgkTipNodes) fprintf(fp, "T\t%llu\n", (unsigned long long)v);
+	for (uint64_t v : DbgkBranchNodes) fprintf(fp, "B\t%llu\n", (unsigned long long)v);
+	fclose(fp);
 	return DBGK_OK;
 }
 

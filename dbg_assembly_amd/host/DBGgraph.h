@@ -69,5 +69,14 @@ int write_kmer_freq_file(const string &path, int kmer_freq_cutoff);
 int write_sorted_dump(const string &path);
 // raw image (size, count, node array, nul_flag) of the current kset
 int write_table_image(const string &path);
+// DBGK_LINKS=1 in the environment: build_debruijn_graph() also runs the consumer's whole first pass, calculate_kmer_links
+// (DBG_contig/contig.cpp:107-181), on the device for the table it hands over (dbgk_export_host_table_links): kset->del_flag
+// holds the low-frequency nodes' delete bits, and below are the per-slot 2-byte KmerLink records (contig.h:31-42; kset->size
+// of them, malloc()ed, NULL when not computed) and the tip / branching slots in ascending slot order -- what the serial scan
+// of contig.cpp:119-181 would produce with -D KmerFreqCutoff, ready to be adopted by the contig stage
+int write_links_dump(const string &path);   // text dump of the three artefacts below (tests)
+extern uint16_t *DbgkKmerLinks;
+extern vector<uint64_t> DbgkTipNodes;
+extern vector<uint64_t> DbgkBranchNodes;
 
 #endif

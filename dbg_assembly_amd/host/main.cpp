@@ -68,6 +68,8 @@ static void usage()
 	     << "                DBGK_ENGINE=1|2   1 = global-atomic insert, 2 = partitioned records + LDS-built table regions (default)" << endl
 	     << "                DBGK_STORE_KMERS=<n>  k-mer occurrences the partitioned engine holds before merging them into the table" << endl
 	     << "                DBGK_LAYOUT=ref   lay the hash table out slot for slot like `debruijn_contig -t 1` of the reference" << endl
+	     << "                DBGK_LINKS=1      also run the contig stage's first pass (link records, delete flags, tip / branch lists) on the GPU" << endl
+	     << "                DBGK_GPUS=<n> | DBGK_GPU_LIST=a,b,..   one table over several GPUs;  DBGK_WIDE_PASSES=<n>  (-k > 32) passes over the input" << endl
 	     << "\nExample: \ndebruijn_contig  -k 31 -r 250  -t 10  -i 0.1  -M 125 -o Ecoli reads_files.lib   2> reads_files.debruijn_contig.log \n" << endl;
 	exit(0);
 }
@@ -119,6 +121,7 @@ int main(int argc, char *argv[])
 	}
 	if (const char *dump = getenv("DBGK_DUMP")) write_sorted_dump(dump);
 	if (const char *img = getenv("DBGK_DUMP_TABLE")) write_table_image(img);
+	if (const char *lk = getenv("DBGK_DUMP_LINKS")) write_links_dump(lk);
 
 	if (KmerSize > 32) { // the reference's consumer is written for 64-bit k-mers (uint64_t kmer, DBG_contig/kmerSet.h:71)
 		cerr << "\nStart to calulate kmer links information!" << endl;

@@ -209,6 +209,24 @@ int dbgk_store_room(dbgk_handle *h, uint64_t *pending_kmers, uint64_t *capacity_
  * enlarge_kmerset_parallel, kmerSet.cpp:132-189).                                                */
 int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
 
+/* dbgk_export_host_table + the WHOLE first pass of the consumer, calculate_kmer_links (DBG_contig/contig.cpp:107-181), computed
+ * on the device for exactly the table that is handed over, so that the consumer can skip its serial scan of it:
+ *   klink[host_size]      the 2-byte KmerLink record of every slot (contig.h:31-42): byte 0 = l_link_num | l_link_base << 2 |
+ *                         r_link_num << 4 | r_link_base << 6, byte 1 bit 0 = linear; 0 for empty slots (the consumer zeroes klink,
+ *                         contig.cpp:60).  link number = counters > kmer_freq_cutoff, at most 3; base = first base with the
+ *                         largest such counter (contig.cpp:129-163)
+ *   del_flag[host_size/8+1]  bit set (128 >> (i % 8) of byte i / 8, kmerSet.h:161-164) for nodes with no link above the cutoff
+ *                         (contig.cpp:165-168); all other bits 0
+ *   tip_nodes / branch_nodes  slots with l_link_num + r_link_num == 1 / with a side of more than one link, in ASCENDING slot
+ *                         order -- the order of the reference's loop (contig.cpp:119,173-178); either may be NULL (counts only);
+ *                         *n_tips / *n_branches always return the counts; DBGK_ERR_CAPACITY when a list does not fit
+ *   stats                 DepthStat[256] and the five class counts (optional)
+ * Unsharded handles.  PARITY UNPINNED: contig.cpp needs Boost headers, absent here, so this is checked against this build's
+ * restatement of those lines (tests), not against the compiled reference.                                                       */
+int dbgk_export_host_table_links(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, int32_t kmer_freq_cutoff,
+                                 uint16_t *klink, uint8_t *del_flag, uint64_t *tip_nodes, uint64_t tip_capacity, uint64_t *n_tips,
+                                 uint64_t *branch_nodes, uint64_t branch_capacity, uint64_t *n_branches, dbgk_link_stats *stats);
+
 /* canonical dump: all nodes sorted by kmer (the parity artefact of SURVEY.md section 8(a)).
  * `capacity` = number of nodes `out` can hold (>= stats.count).                                  */
 int dbgk_export_sorted(dbgk_handle *h, dbgk_node *out, uint64_t capacity, uint64_t *n_out);

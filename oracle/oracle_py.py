@@ -207,6 +207,34 @@ def link_stats(nodes, cutoff=2):
     return st
 
 
+def kmer_links(array, nul_flag, cutoff=2):
+    """TEST INFRASTRUCTURE: restatement of calculate_kmer_links (DBG_contig/contig.cpp:107-181) over a host table: per slot the
+    2-byte KmerLink record (contig.h:31-42, as a uint16: l_link_num | l_link_base << 2 | r_link_num << 4 | r_link_base << 6 |
+    linear << 8), the del_flag bitmap (MSB first), tip_nodes and branch_nodes in slot order.  PARITY UNPINNED: contig.cpp cannot
+    be compiled here (Boost headers absent), this follows its text line by line."""
+    array = np.ascontiguousarray(array, dtype=NODE_DTYPE)
+    size = len(array)
+    occ = np.unpackbits(np.ascontiguousarray(nul_flag, dtype=np.uint8))[:size].astype(bool)   # ! is_entity_null (:121)
+    rec = np.zeros(size, dtype=np.uint16)
+    nums = []
+    for side, word in enumerate((array["l_link"].astype(np.int64), array["r_link"].astype(np.int64))):
+        depth = np.stack([(word >> (24 - 8 * j)) & 0xFF for j in range(4)], axis=1)               # get_next_kmer_depth (:129,:147)
+        above = depth > cutoff                                                                     # :132,:150
+        num = np.minimum(above.sum(axis=1), 3)                                                     # :133-135 (2-bit field, stops at 3)
+        masked = np.where(above, depth, 0)
+        base = np.where(above.any(axis=1), masked.argmax(axis=1), 0)                               # :136-139 strict <: the first maximum
+        rec |= ((num | (base << 2)) << (4 * side)).astype(np.uint16)
+        nums.append(num)
+    ln, rn = nums
+    rec |= (((ln == 1) & (rn == 1)).astype(np.uint16) << 8)                                        # :170-173
+    rec[~occ] = 0
+    dele = occ & (ln == 0) & (rn == 0)                                                             # :165-168
+    del_flag = np.packbits(np.concatenate([dele, np.zeros((-size) % 8 + 8, dtype=bool)]))[:size // 8 + 1]
+    tips = np.nonzero(occ & (ln + rn == 1))[0].astype(np.uint64)                                   # :174-176
+    branches = np.nonzero(occ & ((ln > 1) | (rn > 1)))[0].astype(np.uint64)                        # :177-179
+    return rec, del_flag, tips, branches
+
+
 def read_sequences(path, fmt):
     b, o = C.c_void_p(), C.c_void_p()
     n = lib().orc_read_sequences(os.fsencode(path), fmt, C.byref(b), C.byref(o))

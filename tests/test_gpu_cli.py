@@ -201,3 +201,31 @@ def test_cli_k_above_32_emits_the_128_bit_graph_PARITY_UNPINNED(tmp_path, k, env
     rows = (tmp_path / "out.contig.kmer.freq").read_text().splitlines()
     assert rows[0] == KMER_FREQ_HEADER and len(rows) == 1 + KMER_FREQ_ROWS
     assert [int(x.split("\t")[1]) for x in rows[1:]] == depth[1:]
+
+
+@pytest.mark.parametrize("name,cutoff", [("mixed150_k31", 2), ("saturate_k31", 5), ("fastq_gz_k31", 0)])
+def test_cli_first_pass_of_the_contig_stage_on_the_gpu_PARITY_UNPINNED(tmp_path, oracle, name, cutoff):
+    """DBGK_LINKS=1: build_debruijn_graph() hands over, with the table, what calculate_kmer_links (contig.cpp:107-181) would
+    compute from it -- KmerLink records, del_flag, tip / branch lists in slot order (dbgk_export_host_table_links) -- checked
+    against the restatement of those lines applied to the table image the CLI wrote (parity unpinned: contig.cpp needs Boost)"""
+    import numpy as np
+    case = [c for c in golden_cases() if c["name"] == name][0]
+    p = case["params"]
+    libf = tmp_path / "reads.lib"
+    libf.write_text("\n".join(case_files(case)) + "\n")
+    img, lk, prefix = tmp_path / "table.img", tmp_path / "links.txt", tmp_path / "out"
+    env = dict(os.environ, DBGK_LINKS="1", DBGK_DUMP_TABLE=str(img), DBGK_DUMP_LINKS=str(lk))
+    cmd = [CLI, "-k", str(p["k"]), "-r", str(p["max_read_len"]), "-f", str(p["fmt"]), "-t", "4", "-i", repr(p["init_hash_size"]),
+           "-l", repr(p["load_factor"]), "-e", str(p["max_double"]), "-b", str(p["buffer_num"]), "-D", str(cutoff), "-o", str(prefix), str(libf)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "First pass of the contig stage done on the GPU" in r.stderr
+    size, count, array, flags = oracle.read_table_image(str(img))
+    assert count == case["ref"]["count"]
+    rec, dele, tips, branches = oracle.kmer_links(array, flags, cutoff)
+    lines = lk.read_text().splitlines()
+    assert lines[0] == "#size %d tips %d branches %d" % (size, len(tips), len(branches))
+    occ = np.flatnonzero(np.unpackbits(flags)[:size])
+    dbits = np.unpackbits(dele)[:size]
+    want = ["K\t%d\t%04x\t%d" % (i, rec[i], dbits[i]) for i in occ] + ["T\t%d" % t for t in tips] + ["B\t%d" % b for b in branches]
+    assert lines[1:] == want

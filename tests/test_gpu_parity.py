@@ -744,3 +744,37 @@ def test_comm_in_process_shards_equal_oracle(capi, oracle, n_shards, store, piec
             assert oracle.check_host_table(array, flags, host_size, st.count) == 0
             occ = np.unpackbits(flags)[:host_size].astype(bool)
             assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in golden_cases() if c["name"] in ("mixed150_k31", "saturate_k31", "polyA_k31", "even_k16", "synth_20k_k31")],
+                         ids=lambda c: c["name"])
+@pytest.mark.parametrize("engine,cutoff", [(2, 2), (1, 0), (2, 7)])
+def test_export_with_the_consumers_first_pass_on_the_device_PARITY_UNPINNED(capi, oracle, case, engine, cutoff):
+    """dbgk_export_host_table_links: the table AND what calculate_kmer_links (contig.cpp:107-181) makes of it -- KmerLink record
+    per slot, del_flag bitmap, tip / branch slot lists in ascending order, DepthStat -- against the restatement of those lines
+    applied to the exported table itself, slot for slot (parity unpinned: contig.cpp needs Boost, absent here)"""
+    p = case["params"]
+    files = case_reads(case, oracle)
+    host_size = capi.find_next_prime_ref(max(3 * case["ref"]["count"], 1000))   # != the device table: the export re-seats the nodes
+    with capi.Graph(k=p["k"], table_slots=capi.find_next_prime_ref(70_000_000 if engine == 2 else 2 * case["ref"]["count"] + 1000),
+                    max_read_len=p["max_read_len"], engine=engine, expected_kmers=case["ref"]["kmers"] + 1000 if engine == 2 else 0) as g:
+        for bases, offsets in files:
+            g.push_reads(bases, offsets)
+        st = g.finalize()
+        array, flags, klink, dele, tips, branches, ls = g.export_host_table_links(cutoff, host_size)
+        assert oracle.check_host_table(array, flags, host_size, st.count) == 0
+        plain, plain_flags = g.export_host_table(host_size)   # (re-seated anew by atomics: a valid layout of its own, same nodes)
+        assert oracle.check_host_table(plain, plain_flags, host_size, st.count) == 0
+        assert np.array_equal(np.sort(plain[plain["kmer"] != 0], order="kmer"), np.sort(array[array["kmer"] != 0], order="kmer"))
+    want_rec, want_del, want_tips, want_branches = oracle.kmer_links(array, flags, cutoff)
+    assert np.array_equal(klink, want_rec)
+    assert np.array_equal(dele, want_del)
+    assert np.array_equal(tips, want_tips) and np.array_equal(branches, want_branches)
+    assert np.all(np.diff(tips.astype(np.int64)) > 0) and np.all(np.diff(branches.astype(np.int64)) > 0)
+    occ = np.unpackbits(flags)[:host_size].astype(bool)
+    ref = oracle.link_stats(array[occ], cutoff)
+    assert list(ls.depth_stat) == list(ref.depth_stat)
+    assert (ls.total_nodes, ls.deleted_lowfreq, ls.linear_nodes, ls.tip_nodes, ls.branch_nodes) == \
+           (ref.total_nodes, ref.deleted_lowfreq, ref.linear_nodes, len(tips), len(branches))
+    assert ls.tip_nodes == ref.tip_nodes and ls.branch_nodes == ref.branch_nodes

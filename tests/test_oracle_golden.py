@@ -98,3 +98,25 @@ def test_link_stats_histogram(oracle):
     assert st.total_nodes == res.count
     assert sum(st.depth_stat) == 8 * res.count
     assert st.depth_stat[255] > 0  # saturated counters present
+
+
+def test_kmer_links_restatement_known_answers(oracle):
+    """calculate_kmer_links (contig.cpp:107-181) restated in oracle_py.kmer_links, worked by hand from the reference's text:
+    link number = counters > cutoff (at most 3), base = the first base with the largest such counter, linear = one link on each
+    side, deleted = none at all; tips have exactly one link in total, branches a side with more than one"""
+    nodes = np.zeros(8, dtype=oracle.NODE_DTYPE)
+    flags = np.zeros(2, dtype=np.uint8)
+    #            slot 0: A=5 C=3 G=9 T=0 | T=3      slot 1: empty      slot 2: linear (C=7 | G=4)   slot 3: nothing above 2
+    nodes[0] = (11, 0x05030900, 0x00000003)
+    nodes[2] = (12, 0x00070000, 0x00000400)
+    nodes[3] = (13, 0x02020202, 0x01000002)
+    nodes[4] = (14, 0x09090000, 0x00000000)   # two equal maxima: the FIRST base wins (strict <); a tip? no: l_num = 2 -> branch
+    nodes[5] = (15, 0x00000000, 0xFF000000)   # one link in total: tip
+    nodes[6] = (16, 0x03030303, 0x03030303)   # four above the cutoff: the 2-bit field stops at 3
+    for i in (0, 2, 3, 4, 5, 6):
+        flags[i >> 3] |= 128 >> (i & 7)
+    rec, dele, tips, branches = oracle.kmer_links(nodes, flags, 2)
+    f = lambda ln, lb, rn, rb, lin=0: ln | lb << 2 | rn << 4 | rb << 6 | lin << 8
+    assert list(rec) == [f(3, 2, 1, 3), 0, f(1, 1, 1, 2, 1), f(0, 0, 0, 0), f(2, 0, 0, 0), f(0, 0, 1, 0), f(3, 0, 3, 0), 0]
+    assert list(dele) == [128 >> 3, 0]
+    assert list(tips) == [5] and list(branches) == [0, 4, 6]
