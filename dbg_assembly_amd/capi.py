@@ -136,6 +136,7 @@ SYMBOLS = [
     ("dbgk_comm_digest", _i, [_vp, C.POINTER(_u64)]),
     ("dbgk_comm_link_stats", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_comm_export_host_table", _i, [_vp, _u64, _vp, _vp]),
+    ("dbgk_comm_resize", _i, [_vp, _u64]),
     ("dbgk_comm_wide_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_comm_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_comm_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -544,6 +545,10 @@ class Comm:
 
     def flush(self):
         _chk(lib().dbgk_comm_flush(self._c), "dbgk_comm_flush")
+
+    def resize(self, new_slots):
+        _chk(lib().dbgk_comm_resize(self._c, new_slots), "dbgk_comm_resize")
+        self.table_slots = new_slots
 
     def refresh_stats(self):
         st = Stats()

@@ -26,6 +26,11 @@ struct dbgk_comm {
 	uint32_t next_push = 0;
 	uint32_t pieces = 8;
 	bool finalized = false;
+	bool host_staging = false;                 // some pair of member GPUs are no peers (or DBGK_COMM_HOST_STAGING=1): copies between
+	                                           // different devices go through a pinned host buffer instead of hipMemcpyPeerAsync
+	void *stage = nullptr;                     // pinned, kStageBytes
+	dbgk_config cfg;                           // what the members were created from (dbgk_comm_resize)
+	std::vector<int32_t> devices;
 	// KFREQ communicators: every member counts its reads into a whole table of its own; at finalize member d
 	// becomes the owner of the k-mer values [kf_lo[d], kf_lo[d+1]) and adds the other members' slices to its own
 	bool wide = false;                         // members are sharded WIDE handles (k <= 63, 16-byte records)
@@ -34,13 +39,37 @@ struct dbgk_comm {
 	uint64_t kf_distinct = 0;
 };
 
+constexpr size_t kCommStageBytes = 64ull << 20;
+static thread_local dbgk_comm *g_comm_ctx = nullptr; // the communicator whose copies are being queued (host staging needs its buffer)
+
 static int comm_copy(dbgk_handle *dst, void *d_dst, dbgk_handle *src, const void *d_src, size_t bytes, hipStream_t stream)
 {
 	if (bytes == 0) return DBGK_OK;
-	if (dst->device == src->device) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, stream));
-	else HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, stream));
+	if (dst->device == src->device && !(g_comm_ctx && g_comm_ctx->host_staging && getenv("DBGK_COMM_HOST_STAGING"))) {
+		HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, stream));
+		return DBGK_OK;
+	}
+	if (!g_comm_ctx || !g_comm_ctx->host_staging) {
+		HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, stream));
+		return DBGK_OK;
+	}
+	// no peer access: through pinned host memory, piece by piece, synchronously (slow but correct; ordered behind what `stream` holds)
+	HIPCHK(hipStreamSynchronize(stream));
+	for (size_t off = 0; off < bytes; off += kCommStageBytes) {
+		const size_t len = std::min(kCommStageBytes, bytes - off);
+		HIPCHK(hipSetDevice(src->device));
+		HIPCHK(hipMemcpy(g_comm_ctx->stage, static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost));
+		HIPCHK(hipSetDevice(dst->device));
+		HIPCHK(hipMemcpy(static_cast<char *>(d_dst) + off, g_comm_ctx->stage, len, hipMemcpyHostToDevice));
+	}
 	return DBGK_OK;
 }
+
+struct CommScope { // every entry point that copies sets the context for comm_copy
+	dbgk_comm *prev;
+	explicit CommScope(dbgk_comm *c) : prev(g_comm_ctx) { g_comm_ctx = c; }
+	~CommScope() { g_comm_ctx = prev; }
+};
 
 extern "C" int dbgk_comm_destroy(dbgk_comm *c)
 {
@@ -57,6 +86,7 @@ extern "C" int dbgk_comm_destroy(dbgk_comm *c)
 		if (i < c->cnt_ev.size() && c->cnt_ev[i]) (void)hipEventDestroy(c->cnt_ev[i]);
 		free_handle(c->h[i]);
 	}
+	if (c->stage) (void)hipHostFree(c->stage);
 	delete c;
 	return DBGK_OK;
 }
@@ -73,6 +103,9 @@ extern "C" int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, 
 	c->cnt_ev.assign(n, nullptr);
 	c->delivered.assign(n, 0);
 	if (const char *e = getenv("DBGK_COMM_PIECES")) c->pieces = (uint32_t)std::max(1, atoi(e));
+	c->cfg = *cfg;
+	c->devices.assign(devices, devices + n);
+	c->host_staging = getenv("DBGK_COMM_HOST_STAGING") != nullptr; // tests / diagnosis: never use device-to-device copies between members
 	for (uint32_t i = 0; i < n; i++) {
 		dbgk_config one = *cfg;
 		one.device_id = devices[i];
@@ -108,14 +141,14 @@ extern "C" int dbgk_comm_create(const dbgk_config *cfg, const int32_t *devices, 
 			if (devices[i] != devices[j]) {
 				(void)hipSetDevice(devices[i]);
 				const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-					(void)hipGetLastError();
-					g_last_error = "hipDeviceEnablePeerAccess failed: the GPUs of a communicator must be peers";
-					dbgk_comm_destroy(c);
-					return DBGK_ERR_HIP;
-				}
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) c->host_staging = true; // not peers: copies go through pinned host memory
 				(void)hipGetLastError();
 			}
+	if (c->host_staging && hipHostMalloc(&c->stage, kCommStageBytes, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		dbgk_comm_destroy(c);
+		return DBGK_ERR_NOMEM;
+	}
 	*out = c;
 	return DBGK_OK;
 }
@@ -126,6 +159,7 @@ extern "C" dbgk_handle *dbgk_comm_handle(dbgk_comm *c, uint32_t i) { return (c &
 // steps 1-4 of the header comment on every shard
 static int comm_exchange_and_build(dbgk_comm *c)
 {
+	CommScope scope(c);
 	const uint32_t n = (uint32_t)c->h.size();
 	int rc;
 	for (dbgk_handle *h : c->h) { // every rank's level-1 store is complete
@@ -212,6 +246,22 @@ static int comm_exchange_and_build(dbgk_comm *c)
 		HIPCHK(hipStreamSynchronize(c->h[d]->stream));
 		HIPCHK(hipStreamSynchronize(c->copy_stream[d]));
 	}
+	{ // what every shard received must be what the others extracted for it: the fill counts, summed over the whole job on both sides
+		unsigned long long sent = 0, received = 0;
+		std::vector<uint32_t> buf((size_t)n * G0.B * G0.n_sub);
+		for (uint32_t d = 0; d < n; d++) {
+			rc = use_device(c->h[d]);
+			if (rc) return rc;
+			HIPCHK(hipMemcpy(buf.data(), c->h[d]->store.cnt1, buf.size() * 4, hipMemcpyDeviceToHost));
+			for (uint32_t v : buf) sent += v;
+			HIPCHK(hipMemcpy(buf.data(), c->h[d]->inbox_cnt, buf.size() * 4, hipMemcpyDeviceToHost));
+			for (uint32_t v : buf) received += v;
+		}
+		if (sent != received) {
+			g_last_error = "dbgk_comm: records sent (" + std::to_string(sent) + ") != records received (" + std::to_string(received) + "): a copy between shards went wrong";
+			return DBGK_ERR_STATE;
+		}
+	}
 	// 4. hand-offs.  A list of rank s is merged straight from s's memory when s and d share a device, through a
 	// scratch copy otherwise.
 	auto offer = [&](dbgk_handle *S, const Node *list, uint64_t count, int is_triple, int from_prev, dbgk_handle *D) -> int {
@@ -291,6 +341,7 @@ static int comm_exchange_and_build(dbgk_comm *c)
 // entries and the side tables (keys with a zero low word, key-0 links) gathered onto shard 0.
 static int comm_wide_finalize(dbgk_comm *c)
 {
+	CommScope scope(c);
 	const uint32_t n = (uint32_t)c->h.size();
 	int rc;
 	for (dbgk_handle *h : c->h) {
@@ -483,6 +534,131 @@ extern "C" int dbgk_comm_flush(dbgk_comm *c)
 	return DBGK_OK;
 }
 
+// enlarge_kmerset_parallel (kmerSet.cpp:132-189) for a table that lives on several GPUs: new shards of a table of new_slots
+// slots are created, every node of every old shard is re-seated into the new shard that owns its new home slot (each new shard
+// scans the old shards and keeps its own keys: k_merge_sharded), nodes that run off the end of a shard are handed on, the totals
+// and the key-0 links carry over, the old shards are freed.  The record stores must be empty: pending records are flushed first.
+extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
+{
+	if (!c || new_slots < 3) return DBGK_ERR_ARG;
+	if (c->finalized || c->kfreq || c->wide) return DBGK_ERR_STATE;
+	int rc = dbgk_comm_flush(c);
+	if (rc) return rc;
+	if (new_slots == c->h[0]->size) return DBGK_OK;
+	CommScope scope(c);
+	const uint32_t n = (uint32_t)c->h.size();
+	std::vector<dbgk_handle *> fresh(n, nullptr);
+	auto drop_fresh = [&]() {
+		for (dbgk_handle *f : fresh)
+			if (f) free_handle(f);
+	};
+	for (uint32_t i = 0; i < n && rc == DBGK_OK; i++) {
+		dbgk_config one = c->cfg;
+		one.device_id = c->devices[i];
+		one.engine = DBGK_ENGINE_PARTITION;
+		one.shard_count = n;
+		one.shard_index = i;
+		one.table_slots = new_slots;
+		rc = dbgk_create(&one, &fresh[i]);
+		if (rc == DBGK_OK) rc = use_device(fresh[i]);
+		if (rc == DBGK_OK) rc = zero_table_now(fresh[i]); // nodes arrive through the atomic path
+		if (rc == DBGK_OK) fresh[i]->incr = true;        // later region builds load them back
+	}
+	if (rc) {
+		drop_fresh();
+		return rc;
+	}
+	const uint64_t chunk_nodes = 16ull << 20; // 256 MiB of nodes at a time when source and destination sit on different GPUs
+	for (uint32_t d = 0; d < n && rc == DBGK_OK; d++) {
+		dbgk_handle *D = fresh[d];
+		Node *scratch = nullptr;
+		for (uint32_t s = 0; s < n && rc == DBGK_OK; s++) {
+			dbgk_handle *S = c->h[s];
+			for (uint64_t off = 0; off < S->tslots && rc == DBGK_OK; off += chunk_nodes) {
+				const uint64_t cnt = std::min(chunk_nodes, S->tslots - off);
+				const Node *src = S->table + off;
+				rc = use_device(D);
+				if (rc) break;
+				if (S->device != D->device || c->host_staging) {
+					if (!scratch && hipMalloc(&scratch, chunk_nodes * sizeof(Node)) != hipSuccess) { rc = DBGK_ERR_NOMEM; break; }
+					rc = comm_copy(D, scratch, S, src, cnt * sizeof(Node), D->stream);
+					src = scratch;
+					if (rc) break;
+				}
+				hipLaunchKernelGGL(k_merge_sharded, dim3(grid_for(D, cnt)), dim3(kBlock), 0, D->stream, src, (const unsigned long long *)nullptr, cnt, cnt, 0, 0, D->geom,
+				                   D->store, D->table, D->d_ctr);
+				if (hipGetLastError() != hipSuccess || hipStreamSynchronize(D->stream) != hipSuccess) rc = DBGK_ERR_HIP;
+			}
+		}
+		if (scratch) (void)hipFree(scratch);
+	}
+	// nodes that ran off the end of a new shard continue in the next one
+	std::vector<uint64_t> delivered(n, 0);
+	for (uint32_t round = 0; round <= n && rc == DBGK_OK; round++) {
+		bool any = false;
+		for (uint32_t s = 0; s < n && rc == DBGK_OK; s++) {
+			dbgk_handle *S = fresh[s], *D = fresh[(s + 1) % n];
+			unsigned long long v = 0;
+			rc = use_device(S);
+			if (rc) break;
+			if (hipMemcpy(&v, S->store.outgoing_n, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
+			if (v > S->store.outgoing_cap) { rc = DBGK_ERR_CAPACITY; break; }
+			if (v <= delivered[s]) continue;
+			const uint64_t cnt = v - delivered[s];
+			const Node *src = S->store.outgoing + delivered[s];
+			Node *scratch = nullptr;
+			rc = use_device(D);
+			if (rc) break;
+			if (S->device != D->device || c->host_staging) {
+				if (hipMalloc(&scratch, cnt * sizeof(Node)) != hipSuccess) { rc = DBGK_ERR_NOMEM; break; }
+				rc = comm_copy(D, scratch, S, src, cnt * sizeof(Node), D->stream);
+				src = scratch;
+			}
+			if (rc == DBGK_OK) {
+				hipLaunchKernelGGL(k_merge_sharded, dim3(grid_for(D, cnt)), dim3(kBlock), 0, D->stream, src, (const unsigned long long *)nullptr, cnt, cnt, 0, 1, D->geom,
+				                   D->store, D->table, D->d_ctr);
+				if (hipGetLastError() != hipSuccess || hipStreamSynchronize(D->stream) != hipSuccess) rc = DBGK_ERR_HIP;
+			}
+			if (scratch) (void)hipFree(scratch);
+			delivered[s] = v;
+			any = true;
+		}
+		if (!any) break;
+		if (round == n) rc = DBGK_ERR_TABLE_FULL;
+	}
+	// totals and key-0 links carry over shard by shard (they belong to the reads a shard extracted, not to its slot range)
+	for (uint32_t i = 0; i < n && rc == DBGK_OK; i++) {
+		dbgk_handle *O = c->h[i], *F = fresh[i];
+		Counters co, cf;
+		rc = use_device(O);
+		if (rc) break;
+		if (hipMemcpy(&co, O->d_ctr, sizeof co, hipMemcpyDeviceToHost) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
+		rc = use_device(F);
+		if (rc) break;
+		if (hipMemcpy(&cf, F->d_ctr, sizeof cf, hipMemcpyDeviceToHost) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
+		if (cf.error & 1u) { rc = DBGK_ERR_TABLE_FULL; break; }
+		if (cf.error & 2u) { rc = DBGK_ERR_CAPACITY; break; }
+		cf.total_reads = co.total_reads;
+		cf.total_kmers = co.total_kmers;
+		cf.stored_kmers = co.stored_kmers;
+		cf.polyA_links = co.polyA_links;
+		cf.n_conflict += co.n_conflict;
+		if (hipMemcpy(F->d_ctr, &cf, sizeof cf, hipMemcpyHostToDevice) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
+		if (hipMemsetAsync(F->store.outgoing_n, 0, 8, F->stream) != hipSuccess || hipStreamSynchronize(F->stream) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
+		F->total_reads = O->total_reads;
+	}
+	if (rc) {
+		drop_fresh();
+		return rc;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		free_handle(c->h[i]);
+		c->h[i] = fresh[i];
+	}
+	c->cfg.table_slots = new_slots;
+	return DBGK_OK;
+}
+
 extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
 	if (!c || !offsets) return DBGK_ERR_ARG;
@@ -511,6 +687,7 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 // own GPU: the peer copy of chunk j+1 (copy stream) runs while chunk j is added (the handle's stream).
 static int comm_kfreq_finalize(dbgk_comm *c)
 {
+	CommScope scope(c);
 	const uint32_t n = (uint32_t)c->h.size();
 	for (dbgk_handle *h : c->h) {
 		const int rc = dbgk_finalize(h, nullptr);

@@ -1563,8 +1563,8 @@ __global__ __launch_bounds__(kBlock) void k_merge_sharded(const Node *__restrict
 		const uint64_t key = in[i].kmer;
 		uint64_t add = in[i].links;
 		if (is_triple) add = links_observe(0ull, (uint32_t)add & 0xFFu, (uint32_t)(add >> 8) & 0xFFu);
-		if (key == 0ull) { // key-0 node of another shard: folded into this handle's side node
-			links_cas_merge(&ctr->polyA_links, 0ull, add);
+		if (key == 0ull) { // key-0 node of another shard: folded into this handle's side node (an all-zero entry -- an empty slot of a whole table given as the list -- adds nothing)
+			if (add) links_cas_merge(&ctr->polyA_links, 0ull, add);
 			continue;
 		}
 		const uint64_t home = fast_mod(hash_code(key), G.magic);

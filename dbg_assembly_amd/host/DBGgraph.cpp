@@ -142,12 +142,8 @@ void reserve_device_slots(Session &S)
 	if (S.status != DBGK_OK) return;
 	const double need = (double)S.count_known + (double)S.bound_since;
 	if (need <= 0.80 * (double)S.device_slots) return;
-	if (S.comm) { // the global table of a communicator is sized once, from the input size
-		cerr << "\nAlert message: the device table of " << S.device_slots << " entries is too small for this input; use a larger -i" << endl;
-		return fail(S, DBGK_ERR_TABLE_FULL, "multi-GPU table");
-	}
 	const uint64_t target = find_next_prime((uint64_t)(need / 0.55) + 16);
-	int rc = dbgk_resize_table(S.h, target);
+	int rc = S.comm ? dbgk_comm_resize(S.comm, std::min(target, kPartitionMaxSlots)) : dbgk_resize_table(S.h, target);
 	if (rc != DBGK_OK) return fail(S, rc, "dbgk_resize_table");
 	S.device_slots = target;
 	cerr << "Enlarge device hash array size to be: " << target << endl;

@@ -413,6 +413,10 @@ dbgk_handle *dbgk_comm_handle(dbgk_comm *c, uint32_t i);
 int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 /* records -> table on every shard now (dbgk_flush for a communicator); a push does it when a store is full */
 int dbgk_comm_flush(dbgk_comm *c);
+/* enlarge_kmerset_parallel (kmerSet.cpp:132-189) for the table of a communicator: flushes, creates shards of a table of new_slots
+ * slots, re-seats every node into the shard that owns its new home slot, frees the old shards.  The node multiset and the totals
+ * are unchanged; handles obtained from dbgk_comm_handle before the call are gone.  Graph communicators only.                  */
+int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots);
 /* totals of the whole job (count includes the one key-0 node); exact after a flush                       */
 int dbgk_comm_refresh_stats(dbgk_comm *c, dbgk_stats *out);
 int dbgk_comm_finalize(dbgk_comm *c, dbgk_stats *out);

@@ -778,3 +778,39 @@ def test_export_with_the_consumers_first_pass_on_the_device_PARITY_UNPINNED(capi
     assert (ls.total_nodes, ls.deleted_lowfreq, ls.linear_nodes, ls.tip_nodes, ls.branch_nodes) == \
            (ref.total_nodes, ref.deleted_lowfreq, ref.linear_nodes, len(tips), len(branches))
     assert ls.tip_nodes == ref.tip_nodes and ls.branch_nodes == ref.branch_nodes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards,staging", [(2, False), (3, True)])
+def test_comm_resize_across_shards_and_host_staged_copies(capi, oracle, n_shards, staging, monkeypatch):
+    """dbgk_comm_resize: the table of a communicator enlarged mid-stream (enlarge_kmerset_parallel, kmerSet.cpp:132-189, for a
+    table that lives on several GPUs): every node re-seated into the shard that owns its new home slot, totals and key-0 links
+    carried over, the rest of the input joining afterwards.  With DBGK_COMM_HOST_STAGING every copy between members goes through
+    pinned host memory -- the path taken when two GPUs refuse peer access."""
+    if staging:
+        monkeypatch.setenv("DBGK_COMM_HOST_STAGING", "1")
+    rng = random.Random(90 + n_shards)
+    reads = rand_reads(rng, 4000, G=25000) + [b"A" * 150] * 100 + [b"T" * 90] * 40
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    bigger = capi.find_next_prime_ref(2 * PART_SLOTS + 12345)
+    with capi.Comm(k=31, table_slots=size, devices=[0] * n_shards, expected_kmers=200000, max_batch_bases=1 << 16) as c:
+        n = len(reads)
+        cuts = list(range(0, n, n // 6)) + [n]
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            lo, hi = int(offsets[a]), int(offsets[b])
+            c.push_reads(bases[lo:hi], offsets[a:b + 1] - offsets[a])
+            if i == 2:
+                part = oracle.build_graph(files_mem=[(bases[:hi], offsets[:b + 1])], k=31, init_hash_size=0.001)
+                c.resize(bigger)
+                st_mid = c.refresh_stats()
+                assert (st_mid.count, st_mid.total_kmers, st_mid.table_slots) == (part.count, part.total_kmers, bigger)
+        st = c.finalize()
+        assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+        assert c.digest() == oracle.nodes_digest(ref.nodes)
+        array, flags = c.export_host_table(bigger)
+        assert oracle.check_host_table(array, flags, bigger, st.count) == 0
+        occ = np.unpackbits(flags)[:bigger].astype(bool)
+        assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)
