@@ -82,6 +82,8 @@ SYMBOLS = [
     ("dbgk_destroy", _i, [_vp]),
     ("dbgk_reset", _i, [_vp]),
     ("dbgk_push_reads", _i, [_vp, _vp, _vp, _u64]),
+    ("dbgk_push_acquire", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
+    ("dbgk_push_commit", _i, [_vp, _u64]),
     ("dbgk_push_reads_device", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_sync", _i, [_vp]),
@@ -245,6 +247,26 @@ class Graph:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _chk(lib().dbgk_push_reads(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "dbgk_push_reads")
+
+    def push_reads_zero_copy(self, bases, offsets):
+        """the batch written straight into the handle's pinned staging buffers (dbgk_push_acquire / dbgk_push_commit), in pieces
+        that fit them"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n, r0 = len(offsets) - 1, 0
+        while r0 < n:
+            pb, po, cb, cr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+            _chk(lib().dbgk_push_acquire(self._h, C.byref(pb), C.byref(po), C.byref(cb), C.byref(cr)), "dbgk_push_acquire")
+            base0 = int(offsets[r0])
+            r1 = int(np.searchsorted(offsets, base0 + cb.value, side="right")) - 1
+            r1 = min(max(r1, r0 + 1), r0 + cr.value, n)
+            nb = int(offsets[r1]) - base0
+            assert nb <= cb.value, "a read larger than the staging buffer"
+            C.memmove(pb.value, bases.ctypes.data + base0, nb)
+            rel = (offsets[r0:r1 + 1] - offsets[r0]).astype(np.uint64)
+            C.memmove(po.value, rel.ctypes.data, rel.nbytes)
+            _chk(lib().dbgk_push_commit(self._h, r1 - r0), "dbgk_push_commit")
+            r0 = r1
 
     def push_reads_device(self, d_bases, d_offsets, n_reads, n_bases):
         _chk(lib().dbgk_push_reads_device(self._h, d_bases, d_offsets, n_reads, n_bases), "dbgk_push_reads_device")

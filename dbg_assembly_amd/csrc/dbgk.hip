@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -174,6 +175,10 @@ struct dbgk_handle {
 	uint64_t *inbox = nullptr;    // [n_ranks][B][cap1]
 	uint32_t *inbox_cnt = nullptr;
 
+	// large device-to-host copies (the host KmerSet): slices through pinned buffers, host threads moving them on
+	std::vector<void *> d2h_stage;
+	std::vector<hipEvent_t> d2h_ev;
+
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
 	uint64_t insert_launches = 0;
@@ -313,6 +318,10 @@ static void free_handle(dbgk_handle *h)
 	(void)hipSetDevice(h->device);
 	if (h->stream2) (void)hipStreamSynchronize(h->stream2); // region builds of an unfinished ranged finalize
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	for (void *p : h->d2h_stage)
+		if (p) (void)hipHostFree(p);
+	for (hipEvent_t e : h->d2h_ev)
+		if (e) (void)hipEventDestroy(e);
 	for (auto &s : h->slots) {
 		if (s.h_bases) (void)hipHostFree(s.h_bases);
 		if (s.h_offsets) (void)hipHostFree(s.h_offsets);
@@ -1540,6 +1549,70 @@ static int ensure_slot(dbgk_handle *h, StageSlot &s)
 	return DBGK_OK;
 }
 
+// Zero-copy hand-over of a batch: the caller writes the sequences and offsets straight into the handle's pinned staging
+// buffers (dbgk_push_acquire) and commits them (dbgk_push_commit) -- what dbgk_push_reads does minus its copy of the batch.
+extern "C" int dbgk_push_acquire(dbgk_handle *h, char **bases, uint64_t **offsets, uint64_t *cap_bases, uint64_t *cap_reads)
+{
+	if (!h || !bases || !offsets) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	int rc = use_device(h);
+	if (rc) return rc;
+	StageSlot &s = h->slots[h->next_slot];
+	rc = ensure_slot(h, s);
+	if (rc) return rc;
+	if (s.busy) {
+		HIPCHK(hipEventSynchronize(s.done));
+		s.busy = false;
+	}
+	*bases = s.h_bases;
+	*offsets = s.h_offsets;
+	if (cap_bases) *cap_bases = h->cap_bases;
+	if (cap_reads) *cap_reads = h->cap_reads;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads)
+{
+	if (!h) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	if (n_reads == 0) return DBGK_OK;
+	if (n_reads > h->cap_reads) return DBGK_ERR_ARG;
+	if (h->seed && h->total_reads + n_reads > 0xFFFFFFFFull) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	StageSlot &s = h->slots[h->next_slot];
+	if (!s.h_offsets || s.busy) return DBGK_ERR_STATE; // dbgk_push_acquire first
+	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
+	if (s.h_offsets[0] != 0) return DBGK_ERR_ARG;
+	uint64_t batch_windows = 0, len_max = 0;
+	int has_long = 0;
+	int64_t uniform_len = (int64_t)(s.h_offsets[1] - s.h_offsets[0]);
+	for (uint64_t i = 1; i <= n_reads; i++) {
+		if (s.h_offsets[i] < s.h_offsets[i - 1] || s.h_offsets[i] > h->cap_bases) return DBGK_ERR_ARG;
+		const uint64_t len = s.h_offsets[i] - s.h_offsets[i - 1], rl = len > max_len ? max_len : len;
+		if (rl >= K) batch_windows += rl - K + 1;
+		if (len > max_len) has_long = 1;
+		if ((int64_t)len != uniform_len) uniform_len = 0;
+		len_max = std::max(len_max, len);
+		if (h->seed && len >= (1ull << 30)) return DBGK_ERR_ARG;
+	}
+	const uint64_t nb = s.h_offsets[n_reads];
+	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
+	if (streaming && h->pending_kmers > 0 && h->pending_kmers + batch_windows > h->store_capacity) { // the store is full: records -> table first
+		rc = flush_records(h);
+		if (rc) return rc;
+	}
+	if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
+	HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream));
+	rc = launch_batch(h, s.d_bases, s.d_offsets, n_reads, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
+	if (rc) return rc;
+	h->pending_kmers += batch_windows;
+	HIPCHK(hipEventRecord(s.done, h->stream));
+	s.busy = true;
+	h->next_slot ^= 1;
+	return DBGK_OK;
+}
+
 extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
 	if (!h || !offsets || (n_reads && !bases && offsets[n_reads] != offsets[0])) return DBGK_ERR_ARG;
@@ -2005,6 +2078,73 @@ __global__ __launch_bounds__(kBlock) void k_build_flags_ctr(const Node *__restri
 	}
 }
 
+// A large device-to-host copy into ORDINARY (pageable, malloc()ed) host memory -- the host KmerSet must be free()-able by the
+// consumer.  hipMemcpy into pageable memory stages through the runtime's own bounce buffer on one thread (~20 GB/s); here the
+// device fills pinned slices at the link's rate and several host threads move them on (their first touch also spreads the
+// page faults of the fresh allocation).  Everything queued on the handle's stream before the call is complete on return.
+static int d2h_pipelined(dbgk_handle *h, void *dst, const void *d_src, size_t bytes)
+{
+	constexpr size_t kSlice = 32ull << 20;
+	constexpr int kBuffers = 8;
+	static const int n_threads = getenv("DBGK_EXPORT_THREADS") ? std::max(1, atoi(getenv("DBGK_EXPORT_THREADS"))) : 6;
+	if (bytes < 8 * kSlice || getenv("DBGK_EXPORT_PLAIN")) {
+		HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		return DBGK_OK;
+	}
+	while (h->d2h_stage.size() < (size_t)kBuffers) {
+		void *p = nullptr;
+		hipEvent_t e = nullptr;
+		if (hipHostMalloc(&p, kSlice, hipHostMallocDefault) != hipSuccess) return DBGK_ERR_NOMEM;
+		h->d2h_stage.push_back(p);
+		HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		h->d2h_ev.push_back(e);
+	}
+	const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+	std::vector<std::atomic<int>> issued(n_slices), done(n_slices);
+	for (size_t i = 0; i < n_slices; i++) { issued[i].store(0); done[i].store(0); }
+	std::atomic<int> failed{0};
+	std::vector<std::thread> workers;
+	for (int w = 0; w < n_threads; w++)
+		workers.emplace_back([&, w]() {
+			if (hipSetDevice(h->device) != hipSuccess) { failed.store(1); return; }
+			for (size_t i = (size_t)w; i < n_slices; i += (size_t)n_threads) {
+				while (!issued[i].load(std::memory_order_acquire)) {
+					if (failed.load()) return;
+					std::this_thread::yield();
+				}
+				const int b = (int)(i % kBuffers);
+				if (hipEventSynchronize(h->d2h_ev[b]) != hipSuccess) { failed.store(1); return; }
+				const size_t off = i * kSlice, len = std::min(kSlice, bytes - off);
+				memcpy(static_cast<char *>(dst) + off, h->d2h_stage[b], len);
+				done[i].store(1, std::memory_order_release);
+			}
+		});
+	int rc = DBGK_OK;
+	for (size_t i = 0; i < n_slices && rc == DBGK_OK; i++) {
+		if (i >= (size_t)kBuffers)
+			while (!done[i - kBuffers].load(std::memory_order_acquire)) { // its buffer is free again
+				if (failed.load()) { rc = DBGK_ERR_HIP; break; }
+				std::this_thread::yield();
+			}
+		if (rc) break;
+		const int b = (int)(i % kBuffers);
+		const size_t off = i * kSlice, len = std::min(kSlice, bytes - off);
+		if (hipMemcpyAsync(h->d2h_stage[b], static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+		    hipEventRecord(h->d2h_ev[b], h->stream) != hipSuccess) {
+			rc = DBGK_ERR_HIP;
+			break;
+		}
+		issued[i].store(1, std::memory_order_release);
+	}
+	if (rc) failed.store(1);
+	for (auto &t : workers) t.join();
+	if (failed.load() && rc == DBGK_OK) rc = DBGK_ERR_HIP;
+	if (rc) return hip_fail(hipGetLastError(), "d2h_pipelined", __LINE__);
+	HIPCHK(hipStreamSynchronize(h->stream));
+	return DBGK_OK;
+}
+
 // what the link pass of an export returns (all optional)
 struct LinkOutputs {
 	int32_t cutoff = 0;
@@ -2162,10 +2302,11 @@ static int export_host_table_impl(dbgk_handle *h, uint64_t host_size, dbgk_node 
 	hipLaunchKernelGGL(k_build_flags_ctr, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, T.nodes, T.size,
 	                   h->d_ctr, d_flags);
 	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) e = hipMemcpyAsync(array, T.nodes, host_size * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
-	int link_rc = DBGK_OK;
-	if (e == hipSuccess && LO) link_rc = run_link_pass(h, T, *LO); // on the very image that is being copied out
+	int copy_rc = DBGK_OK;
+	if (e == hipSuccess) copy_rc = d2h_pipelined(h, array, T.nodes, host_size * sizeof(Node));
+	if (e == hipSuccess && copy_rc == DBGK_OK) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	int link_rc = copy_rc;
+	if (e == hipSuccess && LO && copy_rc == DBGK_OK) link_rc = run_link_pass(h, T, *LO); // on the very image that is being copied out
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_unplace_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
 		e = hipGetLastError();

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "dbgk.h"
 #include "reads_io.h"
@@ -59,11 +60,69 @@ namespace {
 const uint64_t kPartitionMinSlots = 67108879;   // smallest table the PARTITION engine takes (2^26 slots), a prime above it
 const uint64_t kPartitionMaxSlots = (1ull << 34) - (1ull << 24); // the engine's geometry: < 2^34 slots
 
+// bytes of the pending batch: grows without zero-filling (std::vector::resize would clear every batch's 256 MB first).  In
+// EXTERNAL mode it is the handle's pinned staging buffer itself (dbgk_push_acquire): the batch is parsed straight into the memory
+// the H2D copy reads from; if a batch outgrows that buffer it moves to the heap and is handed over with dbgk_push_reads.
+struct ByteBuffer {
+	char *p = nullptr;
+	size_t n = 0, cap = 0;
+	bool external = false;
+	~ByteBuffer() { if (!external) free(p); }
+	char *data() { return p; }
+	size_t size() const { return n; }
+	void clear() { n = 0; }
+	void set_external(char *mem, size_t bytes)
+	{
+		if (!external) free(p);
+		p = mem;
+		cap = bytes;
+		n = 0;
+		external = true;
+	}
+	void detach() // give the external memory back (committed)
+	{
+		if (external) { p = nullptr; cap = 0; n = 0; external = false; }
+	}
+	void reserve(size_t want)
+	{
+		if (want <= cap) return;
+		size_t c = cap ? cap : (1u << 16);
+		while (c < want) c += c / 2 + (1u << 16);
+		char *q = external ? static_cast<char *>(malloc(c)) : static_cast<char *>(realloc(p, c));
+		if (!q) abort();
+		if (external) { // outgrown the staging buffer: continue on the heap
+			memcpy(q, p, n);
+			external = false;
+		}
+		p = q;
+		cap = c;
+	}
+	void append(const char *src, size_t len)
+	{
+		reserve(n + len);
+		memcpy(p + n, src, len);
+		n += len;
+	}
+	void grow_uninitialized(size_t len)
+	{
+		reserve(n + len);
+		n += len;
+	}
+};
+
 struct Session {
 	dbgk_handle *h = nullptr;              // one GPU
 	dbgk_comm *comm = nullptr;             // DBGK_GPUS=N / DBGK_GPU_LIST: N sharded handles of one table (always PARTITION)
-	std::vector<char> bases;          // sequences of the pending batch, back to back
+	ByteBuffer bases;                 // sequences of the pending batch, back to back
 	std::vector<uint64_t> offsets;    // offsets.size() == reads in batch + 1
+	// plain files are mapped and parsed with several threads (reads_io.h): their reads are first only NOTED (pointer into the
+	// mapping, length; offsets grows) and copied into `bases` by the same threads when the batch is handed over
+	std::vector<std::pair<const char *, uint32_t>> noted;
+	uint64_t noted_bytes = 0;
+	int parse_threads = 4;
+	bool zero_copy = false;           // one GPU: batches are assembled in the handle's pinned staging buffers (dbgk_push_acquire / _commit)
+	uint64_t *staged_offsets = nullptr;
+	uint64_t staged_cap_reads = 0;
 	uint64_t batch_limit = 128ull << 20;
 	uint64_t device_slots = 0;
 	uint64_t next_progress = 0;
@@ -149,21 +208,66 @@ void reserve_device_slots(Session &S)
 	cerr << "Enlarge device hash array size to be: " << target << endl;
 }
 
+// zero-copy batches: the staging buffers of the handle's next slot become the batch buffer
+void acquire_staging(Session &S)
+{
+	if (!S.zero_copy || S.bases.external || S.bases.size() || S.status != DBGK_OK) return;
+	char *mem = nullptr;
+	uint64_t cap_bases = 0;
+	Stopwatch sw(S.t_push);
+	const int rc = dbgk_push_acquire(S.h, &mem, &S.staged_offsets, &cap_bases, &S.staged_cap_reads);
+	if (rc != DBGK_OK) {
+		S.zero_copy = false; // hand batches over by copy from here on
+		return;
+	}
+	S.bases.set_external(mem, cap_bases);
+}
+
+// the reads noted since the last hand-over: their bytes into `bases`, several threads
+void materialize_noted(Session &S)
+{
+	if (S.noted.empty()) return;
+	acquire_staging(S);
+	const size_t first = S.offsets.size() - 1 - S.noted.size();
+	S.bases.grow_uninitialized(S.noted_bytes);
+	const int T = std::max(1, std::min(S.parse_threads, (int)(S.noted.size() / 4096 + 1)));
+	const size_t per = (S.noted.size() + (size_t)T - 1) / (size_t)T;
+	auto copy = [&](int t) {
+		const size_t a = std::min(S.noted.size(), per * (size_t)t), b = std::min(S.noted.size(), a + per);
+		for (size_t i = a; i < b; i++) memcpy(S.bases.data() + S.offsets[first + i], S.noted[i].first, S.noted[i].second);
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < T; t++) th.emplace_back(copy, t);
+	copy(0);
+	for (auto &x : th) x.join();
+	S.noted.clear();
+	S.noted_bytes = 0;
+}
+
 void flush_batch(Session &S)
 {
+	materialize_noted(S);
 	const uint64_t n_reads = S.offsets.size() - 1;
 	if (n_reads == 0 || S.status != DBGK_OK) {
 		S.bases.clear();
 		S.offsets.assign(1, 0);
 		return;
 	}
+	if (S.bases.external && n_reads > S.staged_cap_reads) S.bases.reserve(S.bases.cap + 1); // (more reads than offsets fit: hand over by copy)
 	reserve_device_slots(S);
 	if (S.status == DBGK_OK) {
 		Stopwatch sw(S.t_push);
-		int rc = S.comm ? dbgk_comm_push_reads(S.comm, S.bases.data(), S.offsets.data(), n_reads)
-		                : dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
+		int rc;
+		if (S.bases.external && n_reads <= S.staged_cap_reads) { // the batch sits in the staging buffer already
+			memcpy(S.staged_offsets, S.offsets.data(), (n_reads + 1) * sizeof(uint64_t));
+			rc = dbgk_push_commit(S.h, n_reads);
+		} else {
+			rc = S.comm ? dbgk_comm_push_reads(S.comm, S.bases.data(), S.offsets.data(), n_reads)
+			            : dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
+		}
 		if (rc != DBGK_OK) fail(S, rc, "dbgk_push_reads");
 	}
+	S.bases.detach(); // (a staging buffer goes back to the handle; the next batch takes the other one)
 	Total_reads_num += n_reads;
 	if (Total_reads_num >= S.next_progress) {
 		cerr << "Load reads block " << Total_reads_num << endl;
@@ -203,12 +307,27 @@ void end_of_full_block(Session &S)
 
 inline void add_read(Session &S, const char *seq, size_t len)
 {
-	S.bases.insert(S.bases.end(), seq, seq + len);
+	acquire_staging(S);
+	if (S.bases.external && S.bases.size() + len > S.bases.cap && S.bases.size()) flush_batch(S), acquire_staging(S);
+	S.bases.append(seq, len);
 	S.offsets.push_back(S.bases.size());
 	S.bound_since += windows_of(len);
 	S.pos += len;
 	if (++S.reads_in_block == (uint64_t)std::max(BufferNum, 1)) end_of_full_block(S);
 	else if (S.bases.size() >= S.batch_limit) flush_batch(S);
+}
+
+// the same bookkeeping for a read of a mapped file: its bytes are copied when the batch is handed over
+inline void note_read(Session &S, const char *seq, size_t len)
+{
+	if (S.zero_copy && S.offsets.back() + len > S.batch_limit + (1u << 16) && S.offsets.size() > 1) flush_batch(S); // keep the batch inside the staging buffer
+	S.noted.push_back({seq, (uint32_t)len});
+	S.noted_bytes += len;
+	S.offsets.push_back(S.offsets.back() + len);
+	S.bound_since += windows_of(len);
+	S.pos += len;
+	if (++S.reads_in_block == (uint64_t)std::max(BufferNum, 1)) end_of_full_block(S);
+	else if (S.offsets.back() >= S.batch_limit) flush_batch(S);
 }
 
 }  // namespace
@@ -232,11 +351,23 @@ void parse_one_reads_file(string &reads_file)
 	Session &S = *g_session;
 	S.stop_file = false;
 	S.reads_in_block = 0;
-	if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); }, &S.stop_file)) {
-		cerr << "fail to open reads file " << reads_file << endl;
-		return;
+	ChunkedReadsFile chunked;
+	static const bool sequential = getenv("DBGK_PARSE_SEQUENTIAL") != nullptr;
+	if (const char *pt = getenv("DBGK_PARSE_THREADS")) S.parse_threads = std::max(1, atoi(pt));
+	if (!sequential && chunked.open(reads_file)) { // a plain file: windows read, lines found and bytes copied by several threads
+		const bool ok = chunked.for_each_read(Input_file_format, S.parse_threads, [&](const char *seq, size_t len) {
+			if (len >> 32) { S.stop_file = true; return; } // (a 4 GiB line is no read)
+			note_read(S, seq, len);
+		}, [&]() { materialize_noted(S); }, &S.stop_file);
+		if (!ok) cerr << "fail to read reads file " << reads_file << endl;
+		flush_batch(S);
+	} else {
+		if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); }, &S.stop_file)) {
+			cerr << "fail to open reads file " << reads_file << endl;
+			return;
+		}
+		flush_batch(S);
 	}
-	flush_batch(S);
 	S.reads_in_block = 0; // a file's last, short block is never followed by an enlarge check (DBGgraph.cpp:329-331)
 	if (!S.stop_file) cerr << "this block has reach the end of file " << endl;
 }
@@ -291,6 +422,8 @@ static void release_session()
 	delete g_session;
 	g_session = nullptr;
 }
+
+void dbgk_host_release_session() { release_session(); }
 
 // plain (not gzip'ed) input: the sum of the file sizes bounds the number of k-mer windows; 0 = unknown
 static uint64_t input_size_bound(const vector<string> &files)
@@ -352,6 +485,7 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 		rc = dbgk_create(&cfg, &S->h);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
 		else if (dbgk_wide_pass_info(S->h, &n_passes, NULL) != DBGK_OK) n_passes = 1;
+		S->zero_copy = rc == DBGK_OK && !getenv("DBGK_NO_ZERO_COPY");
 	}
 	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
@@ -399,8 +533,8 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 	KmerSet128 *result = NULL;
 	if (S->status == DBGK_OK) {
 		Kmer_total_num = st.total_kmers;
-		KmerNode32 *array = static_cast<KmerNode32 *>(malloc(initial_size * sizeof(KmerNode32)));
-		uint8_t *nul = static_cast<uint8_t *>(malloc(initial_size / 8 + 1)), *del = static_cast<uint8_t *>(calloc(initial_size / 8 + 1, 1));
+		KmerNode32 *array = static_cast<KmerNode32 *>(kmerset_alloc(initial_size * sizeof(KmerNode32), false));
+		uint8_t *nul = static_cast<uint8_t *>(kmerset_alloc(initial_size / 8 + 1, false)), *del = static_cast<uint8_t *>(kmerset_alloc(initial_size / 8 + 1, true));
 		if (!array || !nul || !del) {
 			free(array), free(nul), free(del);
 			fail(*S, DBGK_ERR_NOMEM, "host table allocation");
@@ -515,6 +649,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 	} else {
 		rc = dbgk_create(&cfg, &S->h);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
+		S->zero_copy = rc == DBGK_OK && !getenv("DBGK_NO_ZERO_COPY"); // batches are parsed straight into the pinned staging buffers
 	}
 
 	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
@@ -576,9 +711,9 @@ void build_debruijn_graph(vector<string> &reads_files)
 			     << " entries the -i/-e settings allow" << endl;
 			fail(*S, DBGK_ERR_TABLE_FULL, "host table");
 		} else {
-			array = static_cast<KmerNode *>(malloc(use_size * sizeof(KmerNode)));
-			nul = static_cast<uint8_t *>(malloc(use_size / 8 + 1));
-			del = static_cast<uint8_t *>(calloc(use_size / 8 + 1, 1));
+			array = static_cast<KmerNode *>(kmerset_alloc(use_size * sizeof(KmerNode), false));
+			nul = static_cast<uint8_t *>(kmerset_alloc(use_size / 8 + 1, false));
+			del = static_cast<uint8_t *>(kmerset_alloc(use_size / 8 + 1, true));
 			if (!array || !nul || !del) {
 				free(array), free(nul), free(del);
 				fail(*S, DBGK_ERR_NOMEM, "host table allocation");

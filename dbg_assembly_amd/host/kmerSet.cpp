@@ -2,6 +2,8 @@
 // Semantics follow /root/reference/DBG_contig/kmerSet.cpp; line references are to that file.
 #include "kmerSet.h"
 
+#include <sys/mman.h>
+
 #include <thread>
 #include <vector>
 
@@ -70,6 +72,16 @@ void *memset_parallel(void *pointer, int value, uint64_t memsize, int threadNum)
 	return pointer;
 }
 
+void *kmerset_alloc(size_t bytes, bool zero)
+{
+	if (bytes < (4u << 20)) return zero ? calloc(bytes ? bytes : 1, 1) : malloc(bytes ? bytes : 1);
+	void *p = NULL;
+	if (posix_memalign(&p, 2u << 20, bytes) != 0) return NULL;
+	(void)madvise(p, bytes, MADV_HUGEPAGE); // (a hint: without transparent huge pages this is an ordinary aligned allocation)
+	if (zero) memset_parallel(p, 0, bytes, 8);
+	return p;
+}
+
 KmerSet *adopt_kmerset(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict,
                        KmerNode *array, uint8_t *nul_flag, uint8_t *del_flag)
 {
@@ -91,9 +103,9 @@ KmerSet *adopt_kmerset(uint64_t size, float load_factor, uint64_t count, uint64_
 KmerSet *init_kmerset_parallel(uint64_t init_size, float load_factor, int threadNum)
 {
 	const uint64_t size = init_size < 3 ? 3 : find_next_prime(init_size);  // :103-104
-	KmerNode *array = static_cast<KmerNode *>(malloc(size * sizeof(KmerNode)));
-	uint8_t *nul = static_cast<uint8_t *>(calloc(size / 8 + 1, 1));
-	uint8_t *del = static_cast<uint8_t *>(calloc(size / 8 + 1, 1));
+	KmerNode *array = static_cast<KmerNode *>(kmerset_alloc(size * sizeof(KmerNode), false));
+	uint8_t *nul = static_cast<uint8_t *>(kmerset_alloc(size / 8 + 1, true));
+	uint8_t *del = static_cast<uint8_t *>(kmerset_alloc(size / 8 + 1, true));
 	if (!array || !nul || !del) {
 		free(array), free(nul), free(del);
 		return NULL;

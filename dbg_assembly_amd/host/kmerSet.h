@@ -120,6 +120,12 @@ void free_hash128(KmerSet128 *set);
 KmerSet128 *adopt_kmerset128(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict, KmerNode32 *array, uint8_t *nul_flag,
                              uint8_t *del_flag);
 
+// malloc() for the big arrays of a set (free()- and realloc()-compatible, as free_hash / enlarge_kmerset_parallel need): from 4 MiB
+// on, 2 MiB-aligned and advised for transparent huge pages -- a 9.6 GB table then takes 4 600 page faults to fill instead of
+// 2.3 million and the process exits without unmapping it page by page (0.08 s against 0.74 s to touch it with 8 threads, 0.9 s
+// less at exit: profiles/r03_hip_startup.txt).  zero = calloc semantics.
+void *kmerset_alloc(size_t bytes, bool zero);
+
 // wraps already-filled arrays (as produced by dbgk_export_host_table) into a KmerSet control block
 KmerSet *adopt_kmerset(uint64_t size, float load_factor, uint64_t count, uint64_t count_conflict,
                        KmerNode *array, uint8_t *nul_flag, uint8_t *del_flag);

@@ -9,7 +9,10 @@
 // writes the artefacts that stage defines: <prefix>.contig.kmer.freq (first pass of
 // calculate_kmer_links) and, if DBGK_DUMP is set, the canonical node dump.
 #include <unistd.h>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "DBGgraph.h"
 
@@ -74,8 +77,23 @@ static void usage()
 	exit(0);
 }
 
+static double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Leave without tearing down: the results are on disk, and returning from main() would spend a good part of a second unmapping
+// the 16 bytes x table-size host array page by page and unloading the HIP runtime with all its device allocations.
+// DBGK_SLOW_EXIT=1 returns normally (leak checkers).
+static void leave(int code)
+{
+	cout.flush();
+	cerr.flush();
+	fflush(NULL);
+	if (getenv("DBGK_SLOW_EXIT")) exit(code);
+	_exit(code);
+}
+
 int main(int argc, char *argv[])
 {
+	const double t_main = wall_now();
 	int c;
 	while ((c = getopt(argc, argv, "k:r:f:o:t:i:l:e:b:D:T:I:P:W:C:G:B:U:L:E:M:h")) != -1) {
 		switch (c) {
@@ -113,11 +131,13 @@ int main(int argc, char *argv[])
 	vector<string> reads_files;
 	reading_file_list(reads_lib_file, reads_files);
 
+	const double t_build0 = wall_now();
 	build_debruijn_graph(reads_files);
+	const double t_build1 = wall_now();
 	cerr << "\nLoad reads, chop kmer, build kmer graph finished !" << endl;
 	if (DbgkLastStatus != 0) {
 		cerr << "graph construction failed with status " << DbgkLastStatus << endl;
-		return 1;
+		leave(1);
 	}
 	if (const char *dump = getenv("DBGK_DUMP")) write_sorted_dump(dump);
 	if (const char *img = getenv("DBGK_DUMP_TABLE")) write_table_image(img);
@@ -136,5 +156,30 @@ int main(int argc, char *argv[])
 		write_kmer_freq_file(Output_prefix + ".contig.kmer.freq", KmerFreqCutoff);
 		cerr << "\nGraph stage finished (contig stage not linked in, see INTEGRATION.md)" << endl;
 	}
+	if (getenv("DBGK_TIMINGS"))
+		cerr << "Wall phases (s): start-up " << t_build0 - t_main << " build_debruijn_graph " << t_build1 - t_build0 << " after " << wall_now() - t_build1 << endl;
+	if (getenv("DBGK_TIMINGS")) { // how much of the process sits in transparent huge pages
+		if (FILE *fp = fopen("/proc/self/smaps_rollup", "r")) {
+			char line[256];
+			while (fgets(line, sizeof line, fp))
+				if (!strncmp(line, "Rss:", 4) || !strncmp(line, "AnonHugePages:", 14)) cerr << line;
+			fclose(fp);
+		}
+	}
+	if (getenv("DBGK_TIMINGS") && getenv("DBGK_SLOW_EXIT")) { // what the teardown that leave() skips would cost
+		const double t0 = wall_now();
+		free_hash(kset);
+		kset = NULL;
+		const double t1 = wall_now();
+		vector<string> none;
+		extern void dbgk_host_release_session();
+		dbgk_host_release_session();
+		cerr << "Teardown (s): free host KmerSet " << t1 - t0 << " destroy GPU handle " << wall_now() - t1 << endl;
+	}
+	if (getenv("DBGK_EXIT_DESTROY")) { // experiment: give the device memory back before leaving
+		extern void dbgk_host_release_session();
+		dbgk_host_release_session();
+	}
+	leave(0);
 	return 0;
 }

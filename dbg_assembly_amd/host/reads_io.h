@@ -8,9 +8,15 @@
 #ifndef DBGK_HOST_READS_IO_H_
 #define DBGK_HOST_READS_IO_H_
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+#include <cstdint>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 // calls cb(sequence pointer, length) for every record; false if the file cannot be opened.  When `stop`
@@ -59,5 +65,145 @@ bool for_each_read_in_file(const std::string &path, int format, Callback cb, con
 	gzclose(fp);
 	return true;
 }
+
+// ---- plain (not compressed) files with several threads ---------------------------------------------------------------------
+// The file is read in windows of 256 MiB into one reusable buffer (2 MiB-aligned, huge pages advised): (1) n_threads threads
+// pread() their byte ranges of the window and note the newline positions in them, each with the first character of the line that
+// follows; (2) the calling thread runs the SAME record state machine as above over those notes -- whatever a line begins with is
+// judged in file order, so the result is that of the sequential reader for any input (FASTQ quality lines that start with '@'
+// included) -- and calls cb(pointer into the window, length) for every record; (3) end_of_window() is called before the buffer is
+// reused: the caller copies the sequence bytes it was shown (again with several threads).  A line that straddles two windows is
+// carried over to the front of the buffer.
+class ChunkedReadsFile {
+public:
+	~ChunkedReadsFile() { close(); }
+	// false: cannot be opened, or the file is gzip'ed (use for_each_read_in_file)
+	bool open(const std::string &path)
+	{
+		close();
+		fd_ = ::open(path.c_str(), O_RDONLY);
+		if (fd_ < 0) return false;
+		struct stat st;
+		if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return close(), false;
+		size_ = (size_t)st.st_size;
+		unsigned char magic[2] = {0, 0};
+		if (size_ >= 2 && pread(fd_, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return close(), false;
+		return true;
+	}
+	void close()
+	{
+		if (fd_ >= 0) ::close(fd_);
+		free(buf_);
+		buf_ = NULL;
+		cap_ = 0;
+		fd_ = -1;
+		size_ = 0;
+	}
+	size_t size() const { return size_; }
+
+	template <class Callback, class EndOfWindow>
+	bool for_each_read(int format, int n_threads, Callback cb, EndOfWindow end_of_window, const bool *stop = nullptr)
+	{
+		const char marker = (format == 1) ? '@' : '>';
+#ifdef DBGK_READS_WINDOW
+		const size_t WINDOW = DBGK_READS_WINDOW; // (tests: windows of a few hundred bytes)
+#else
+		const size_t WINDOW = (size_t)256 << 20;
+#endif
+		if (n_threads < 1) n_threads = 1;
+		std::vector<std::vector<uint64_t>> nl((size_t)n_threads); // newline position | first character of the next line << 56
+		std::vector<size_t> slice_end((size_t)n_threads);
+		int state = 0;          // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
+		size_t have = 0;        // bytes of an unfinished line carried over to the front of the buffer
+		size_t file_off = 0;
+		bool ok = true;
+		while (file_off < size_ && !(stop && *stop)) {
+			const size_t take = std::min(WINDOW, size_ - file_off);
+			if (!reserve(have + take)) return false;
+			const size_t per = (take + (size_t)n_threads - 1) / (size_t)n_threads;
+			std::vector<char> failed((size_t)n_threads, 0);
+			auto work = [&](int t) {
+				std::vector<uint64_t> &out = nl[(size_t)t];
+				out.clear();
+				const size_t a = std::min(take, per * (size_t)t), b = std::min(take, a + per);
+				slice_end[(size_t)t] = have + b;
+				for (size_t done = a; done < b;) { // pread may return less than asked
+					const ssize_t got = pread(fd_, buf_ + have + done, b - done, (off_t)(file_off + done));
+					if (got <= 0) { failed[(size_t)t] = 1; return; }
+					done += (size_t)got;
+				}
+				out.reserve((b - a) / 64 + 16);
+				for (const char *p = buf_ + have + a, *e = buf_ + have + b; p < e;) {
+					const char *q = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)));
+					if (!q) break;
+					const unsigned char next = q + 1 < e ? (unsigned char)q[1] : 0; // (at the slice's end: looked up below, the neighbour is still reading)
+					out.push_back((uint64_t)(q - buf_) | ((uint64_t)next << 56));
+					p = q + 1;
+				}
+			};
+			std::vector<std::thread> th;
+			for (int t = 1; t < n_threads; t++) th.emplace_back(work, t);
+			work(0);
+			for (auto &x : th) x.join();
+			for (char f : failed) ok = ok && !f;
+			if (!ok) return false;
+			const size_t end = have + take;
+			size_t line_start = 0;
+			char first = buf_[0]; // end >= 1 here
+			for (int t = 0; t < n_threads && !(stop && *stop); t++)
+				for (uint64_t word : nl[(size_t)t]) {
+					if (stop && *stop) break;
+					const size_t pos = (size_t)(word & ((1ull << 56) - 1));
+					const size_t len = pos - line_start;
+					switch (state) { // the record rules of for_each_read_in_file
+						case 0: if (len && first == marker) state = 1; break;
+						case 1: cb(buf_ + line_start, len); state = (format == 1) ? 2 : 0; break;
+						case 2: state = 3; break;
+						default: state = 0; break;
+					}
+					line_start = pos + 1;
+					first = pos + 1 == slice_end[(size_t)t] ? (pos + 1 < end ? buf_[pos + 1] : 0) : (char)(word >> 56);
+				}
+			file_off += take;
+			if (stop && *stop) break;
+			if (file_off >= size_ && line_start < end) { // the file's last line has no newline
+				const size_t len = end - line_start;
+				switch (state) {
+					case 0: if (len && buf_[line_start] == marker) state = 1; break;
+					case 1: cb(buf_ + line_start, len); state = (format == 1) ? 2 : 0; break;
+					case 2: state = 3; break;
+					default: state = 0; break;
+				}
+				line_start = end;
+			}
+			end_of_window(); // the records shown so far are copied now: the buffer is about to be reused
+			have = end - line_start;
+			if (have) memmove(buf_, buf_ + line_start, have);
+		}
+		if (!(stop && *stop) && state == 1) { // a header on the very last line
+			cb("", 0);
+			end_of_window();
+		}
+		return true;
+	}
+
+private:
+	bool reserve(size_t want)
+	{
+		if (want <= cap_) return true;
+		const size_t c = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+		void *p = NULL;
+		if (posix_memalign(&p, (size_t)2 << 20, c) != 0) return false;
+		(void)madvise(p, c, MADV_HUGEPAGE);
+		if (buf_) memcpy(p, buf_, cap_);
+		free(buf_);
+		buf_ = static_cast<char *>(p);
+		cap_ = c;
+		return true;
+	}
+	char *buf_ = NULL;
+	size_t cap_ = 0, size_ = 0;
+	int fd_ = -1;
+};
 
 #endif

@@ -168,6 +168,13 @@ int dbgk_reset(dbgk_handle *h);
  * queued (asynchronous w.r.t. the device).                                                       */
 int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
+/* the same without the copy: dbgk_push_acquire returns the handle's next pinned staging buffers -- room for cap_bases sequence
+ * bytes and cap_reads + 1 offsets (offsets[0] = 0); it waits until the batch that used them last has left for the device -- the
+ * caller fills them (a parser writes its reads there directly) and dbgk_push_commit(n_reads) queues the batch.  One acquire
+ * per commit; dbgk_push_reads may be mixed in between batches.                                                        */
+int dbgk_push_acquire(dbgk_handle *h, char **bases, uint64_t **offsets, uint64_t *cap_bases, uint64_t *cap_reads);
+int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads);
+
 /* same, for reads already resident in device memory of the handle's GPU (both pointers 16-byte
  * aligned, readable through the end of the last read).  Nothing is copied; the buffers must stay
  * valid until the next dbgk_sync/dbgk_finalize.                                                  */
