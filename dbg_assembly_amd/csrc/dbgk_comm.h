@@ -674,11 +674,50 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 		const uint64_t len = offsets[i + 1] - offsets[i], rl = len > max_len ? max_len : len;
 		if (rl >= K) windows += rl - K + 1;
 	}
+	const uint32_t n = (uint32_t)c->h.size();
+	// A large batch is cut into one piece per member and the pieces are handed over by as many host threads at once (each member
+	// has its own pinned staging buffers, stream and PCIe link): one thread copying batch after batch tops out near 30 GB/s whatever
+	// the number of GPUs.  Small batches go to one member, round robin.
+	static const bool serial = getenv("DBGK_COMM_SERIAL_PUSH") != nullptr;
+	const uint64_t bytes = offsets[n_reads] - offsets[0];
+	if (!serial && n > 1 && n_reads >= 4ull * n && bytes >= (8ull << 20)) {
+		uint64_t worst = 0;
+		for (dbgk_handle *m : c->h) worst = std::max(worst, m->pending_kmers);
+		if (worst > 0 && worst + windows / n + (windows >> 4) > h->store_capacity) { // some store would run full: everybody exchanges and builds
+			int rc = dbgk_comm_flush(c);
+			if (rc) return rc;
+		}
+		std::vector<uint64_t> cut(n + 1, n_reads); // cut[i]: first read of member i's piece (equal byte shares)
+		cut[0] = 0;
+		for (uint32_t i = 1; i < n; i++) {
+			const uint64_t want = offsets[0] + bytes * i / n;
+			cut[i] = (uint64_t)(std::lower_bound(offsets, offsets + n_reads + 1, want) - offsets);
+			cut[i] = std::max(cut[i - 1], std::min(cut[i], n_reads));
+		}
+		std::vector<int> rcs(n, DBGK_OK);
+		std::vector<std::string> errs(n);
+		auto push_piece = [&](uint32_t i) {
+			dbgk_handle *m = c->h[(c->next_push + i) % n];
+			if (cut[i + 1] > cut[i]) rcs[i] = dbgk_push_reads(m, bases, offsets + cut[i], cut[i + 1] - cut[i]);
+			if (rcs[i]) errs[i] = g_last_error; // (the message is per thread)
+		};
+		std::vector<std::thread> th;
+		for (uint32_t i = 1; i < n; i++) th.emplace_back(push_piece, i);
+		push_piece(0);
+		for (auto &t : th) t.join();
+		c->next_push = (c->next_push + 1) % n;
+		for (uint32_t i = 0; i < n; i++)
+			if (rcs[i]) {
+				g_last_error = errs[i];
+				return rcs[i];
+			}
+		return DBGK_OK;
+	}
 	if (h->pending_kmers > 0 && h->pending_kmers + windows > h->store_capacity) { // this rank's store is full: everybody exchanges and builds
 		int rc = dbgk_comm_flush(c);
 		if (rc) return rc;
 	}
-	c->next_push = (c->next_push + 1) % (uint32_t)c->h.size();
+	c->next_push = (c->next_push + 1) % n;
 	return dbgk_push_reads(h, bases, offsets, n_reads);
 }
 
