@@ -60,3 +60,21 @@ def test_kmerset_maintenance_equals_oracle(driver_output, oracle):
     assert rows["layout"] == [str(chk)]  # slot-for-slot the layout the reference's enlarge produces
     assert rows["revcomp"] == ["TACGTT", "C", "1"]
     L.orc_kmerset_free(s)
+
+
+def test_bench_starts_its_own_ranks_and_relays_their_status():
+    """`python bench.py --gpus N` with no torch.distributed environment starts N ranks itself (a torch.distributed.run child).
+    Here, without a GPU, every rank stops with "needs an MI355X": the launcher must pass that failure on and print no result."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is visible: the ranks would run")
+    assert "starting 2 ranks" in r.stderr
+    assert r.returncode != 0 and r.stdout.strip() == ""

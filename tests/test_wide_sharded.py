@@ -207,3 +207,79 @@ def test_wide_communicator_in_process_shards_PARITY_UNPINNED_above_k32(capi, ora
         assert oracle.wide_check_host_table(array, flags, size, st.count) == 0
         occ = np.unpackbits(flags)[:size].astype(bool)
         assert np.array_equal(np.sort(array[occ], order=["kmer_hi", "kmer_lo"]), want.astype(capi.NODE32_DTYPE))
+
+
+def _np_hash_code(k):
+    k = k.astype(np.uint64).copy()
+    with np.errstate(over="ignore"):
+        k += ~(k << np.uint64(32))
+        k ^= k >> np.uint64(22)
+        k += ~(k << np.uint64(13))
+        k ^= k >> np.uint64(8)
+        k += k << np.uint64(3)
+        k ^= k >> np.uint64(15)
+        k += ~(k << np.uint64(27))
+        k ^= k >> np.uint64(31)
+    return k
+
+
+@pytest.mark.gpu
+def test_wide_cfg5_eight_gpu_geometry_first_and_last_shard_PARITY_UNPINNED(capi, oracle):
+    """BASELINE cfg5 as stated -- k = 63 on 8 GPUs, ONE table of 12.8 G slots of 32 bytes (410 GB: 51 GB per GPU) -- has 3052
+    level-1 buckets at r = 22, 382 per rank, and is built in 3 passes over the input.  One GPU holds two of those shards: the
+    FIRST and the LAST (the table's end, the wrap-around to slot 0) are built here from a sample of the cfg5 reads exactly as
+    ranks 0 and 7 would -- same geometry, same kernels (64-bit hash / size division, slot numbers beyond 2^32), the records of
+    the six absent ranks dropped -- and must hold exactly the nodes of a single-handle build whose home slot lies in their ranges."""
+    n_reads, G, k, world = 200000, 1000000, 63, 8
+    size = capi.find_next_prime_ref(8 * 1_600_000_000)
+    P = capi.synth_params(G, 150, sub_rate=0.001, cfg=5)
+    with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(1 << 27), engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as ref:
+        d_bases, d_off, nb = ref.synth_reads_device(P, 0, n_reads)
+        bases, offsets = d_bases.to_host(np.uint8, nb).copy(), d_off.to_host(np.uint64).copy()
+        d_bases.free()
+        d_off.free()
+        ref.push_reads(bases, offsets)
+        st = ref.finalize()
+        whole = ref.wide_export_sorted()
+    hi, lo = whole["kmer_hi"], whole["kmer_lo"]
+    h = _np_hash_code(np.where(hi != 0, lo ^ _np_hash_code(hi), lo))
+    home = (h % np.uint64(size)).astype(np.uint64)
+    shards = {}
+    for rank in (0, world - 1):
+        g = capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88, shard_count=world, shard_index=rank,
+                       max_batch_bases=64 << 20)
+        shards[rank] = g
+    try:
+        n_passes, _ = shards[0].wide_pass_info()
+        assert n_passes == 3
+        c0 = shards[0]
+        for p in range(n_passes):
+            for g in shards.values():
+                g.wide_begin_pass(p)
+                g.push_reads(bases, offsets)   # both ranks extract the same sample: every record arrives twice ...
+                g.sync()
+            infos = {r: g.shard_info() for r, g in shards.items()}
+            assert infos[0].buckets_per_rank == 128 and infos[0].n_ranks == world
+            for d, gd in shards.items():     # ... so only rank 0's records are delivered (chunk d of its send buffer -> slot 0 of d's inbox)
+                c0.memcpy_d2d(infos[d].d_recv_cnt, infos[0].d_send_cnt + d * infos[0].cnt_chunk_bytes, infos[0].cnt_chunk_bytes)
+                c0.memcpy_d2d(infos[d].d_recv, infos[0].d_send + d * infos[0].chunk_bytes, infos[0].chunk_bytes)
+                for s in range(1, world):      # the other seven sources sent nothing
+                    zero = np.zeros(infos[d].cnt_chunk_bytes // 4, dtype=np.uint32)
+                    capi.lib().dbgk_memcpy_h2d(gd._h, infos[d].d_recv_cnt + s * infos[d].cnt_chunk_bytes, zero.ctypes.data, zero.nbytes)
+            c0.sync()
+            for g in shards.values():
+                g.shard_mark_exchanged()
+                g.wide_end_pass()
+        for rank, g in shards.items():
+            stg = g.finalize()
+            info = g.shard_info()
+            assert g.shard_outgoing()[1] == 0 and g.shard_overflow()[1] == 0
+            mine = (home >= np.uint64(info.slot_lo)) & (home < np.uint64(info.slot_hi)) & (whole["kmer_lo"] != 0)
+            got = g.wide_export_sorted()
+            got = got[got["kmer_lo"] != 0]   # (side-table keys and the key-0 node live outside the slot ranges)
+            assert info.slot_hi > info.slot_lo and (rank == 0 or info.slot_lo >= 1 << 33)
+            assert np.array_equal(got, whole[mine]), "shard %d of the 8-GPU geometry" % rank
+            assert int(stg.total_kmers) == int(st.total_kmers)
+    finally:
+        for g in shards.values():
+            g.close()
