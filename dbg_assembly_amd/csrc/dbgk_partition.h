@@ -1275,33 +1275,35 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 				n_conf_r += probing[u] ? 1u : 0u;
 				any = any || probing[u];
 			}
-			// the records whose home slot holds another key walk on one after the other: plain reads, a claim only where a slot is
-			// seen empty (an LDS instruction costs the same whatever its lane count -- profiles/ubench/lds_rate.hip: 2.6 ns per
-			// 64-bit read, 8 ns per 64-bit compare-swap and CU -- so the four-wide claims above are not repeated here)
-#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 1
-			any = false; // timing experiment: no miss loops (results are wrong)
-#endif
+			// the records whose home slot holds another key walk on: plain reads, a claim only where a slot is seen empty.  An LDS
+			// instruction costs the same whatever its lane count (profiles/ubench/lds_rate.hip: 2.6 ns per 64-bit read, 8 ns per
+			// 64-bit compare-swap and CU), so the walks of a thread's four records are NOT four loops (each as long as its slowest
+			// lane) but ONE: every lane steps the first of its records that is still walking -- a fifth of the records walk at all,
+			// most lanes have none or one, and the loop ends after as many steps as the busiest lane needs in total.
 			if (any) {
-#pragma unroll
-				for (int u = 0; u < kBatch; u++) {
-					const unsigned long long id = (recs[u] >> 6) + 1ull;
-					bool on = probing[u];
-					uint32_t at = idx[u];
-					while (on) { // ONE exit, no breaks
-						unsigned long long cur = L.ident[at];
-						if (cur == 0ull) {
-							const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
-							cur = prev == 0ull ? id : prev;
-							n_new_r += (prev == 0ull && at < region_len) ? 1u : 0u;
-						}
-						const bool hit = cur == id;
-						at += hit ? 0u : 1u;
-						n_conf_r += hit ? 0u : 1u;
-						const bool lost = at >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full:
-						ovf = ovf || lost;                                                  // the exact pass sends it to the overflow list
-						on = !hit && !lost;
+				uint32_t pend = (probing[0] ? 1u : 0u) | (probing[1] ? 2u : 0u) | (probing[2] ? 4u : 0u) | (probing[3] ? 8u : 0u);
+				while (pend) { // ONE exit, no breaks
+					const uint32_t u = (uint32_t)__builtin_ctz(pend);
+					const uint64_t rc = u == 0u ? recs[0] : (u == 1u ? recs[1] : (u == 2u ? recs[2] : recs[3]));
+					uint32_t at = u == 0u ? idx[0] : (u == 1u ? idx[1] : (u == 2u ? idx[2] : idx[3]));
+					const unsigned long long id = (rc >> 6) + 1ull;
+					unsigned long long cur = L.ident[at];
+					if (cur == 0ull) {
+						const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
+						cur = prev == 0ull ? id : prev;
+						n_new_r += (prev == 0ull && at < region_len) ? 1u : 0u;
 					}
-					idx[u] = at < (uint32_t)(kRegionSlots + kSpillSlots) ? at : 0u;
+					const bool hit = cur == id;
+					at += hit ? 0u : 1u;
+					n_conf_r += hit ? 0u : 1u;
+					const bool lost = at >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full:
+					ovf = ovf || lost;                                                  // the exact pass sends it to the overflow list
+					at = lost ? 0u : at;
+					idx[0] = u == 0u ? at : idx[0];
+					idx[1] = u == 1u ? at : idx[1];
+					idx[2] = u == 2u ? at : idx[2];
+					idx[3] = u == 3u ? at : idx[3];
+					pend &= (hit || lost) ? ~(1u << u) : ~0u;
 				}
 			}
 			// +1 on the observed neighbour bytes, both dwords with one add; the returned word tells whether a byte was already 255

@@ -9,6 +9,10 @@
 // instantiated at k <= 31 this restatement must equal the pinned oracle (oracle/dbg_oracle.c) on every golden
 // fixture, node for node (tests/test_wide.py).
 //
+// Because the rule definitions are SHARED with the kernels, a mistake in that header would pass every comparison between the two:
+// tests/wide_checker.py restates the rules a third time in pure Python (strings and ints, nothing shared) and pins THIS file at
+// k in {33, 47, 62, 63} and the real reference's dumps at k <= 32 (tests/test_wide_checker.py).
+//
 // Only tests/ may call this.
 #include <algorithm>
 #include <cstdint>
