@@ -291,10 +291,6 @@ def main_kfreq(args, result_out):
 
     for _ in range(args.warmup):
         step()
-        state["verify"] = False
-    if not args.warmup and multi:   # no warm-up step: verify the exchange once, untimed
-        step()
-        state["verify"] = False
     g.sync()
     g.reset_timings()
     fence()
