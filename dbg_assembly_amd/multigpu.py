@@ -251,8 +251,10 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
     per = int(info.cnt_chunk_bytes) // 4   # fill counters per rank chunk (buckets x sub-stores)
     mine = recv_cnt.view(torch.int32).to(torch.int64).view(world, per).sum(dim=0)
     want = bucket_counts.view(world, per)[rank]
-    if not bool(torch.equal(mine, want)):
-        raise RuntimeError("rank %d: the exchanged bucket fill counts disagree with the all-reduced totals" % rank)
+    flag = torch.tensor([0 if bool(torch.equal(mine, want)) else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        raise RuntimeError("rank %d: the exchanged bucket fill counts disagree with the all-reduced totals (here or on another rank)" % rank)
     n_chunks = max(1, min(int(exchange_chunks), B))
     if n_chunks <= 1:
         _exchange_range(send, recv, info, 0, B, world, rank, group)
@@ -288,10 +290,12 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
         got = torch.stack([recv[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
         theirs = torch.empty_like(sent)
         dist.all_to_all_single(theirs, sent, group=group)   # theirs[p] = checksum of what rank p sent to me
-        if not bool(torch.equal(theirs, got)):
-            bad = [p for p in range(world) if int(theirs[p]) != int(got[p])]
+        bad = [p for p in range(world) if int(theirs[p]) != int(got[p])]
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)   # every rank stops, not only the one that saw it (no rank is left waiting)
+        if int(flag.item()):
             raise RuntimeError("rank %d: the level-1 record buckets received from rank(s) %r differ from what was sent "
-                               "(a truncated or corrupted transfer)" % (rank, bad))
+                               "(a truncated or corrupted transfer%s)" % (rank, bad, "" if bad else " seen by another rank"))
     g.shard_mark_exchanged()
     return records_global
 

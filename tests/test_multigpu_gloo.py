@@ -293,7 +293,7 @@ def _shard_worker(rank, world, port, reads, k, size, q, chunks):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = FakeShardGraph(O, reads[rank::world], k, world, rank, size)
-    out = sharded_finalize(g, "cpu", wrap=_wrap_host, exchange_chunks=chunks)
+    out = sharded_finalize(g, "cpu", wrap=_wrap_host, exchange_chunks=chunks, verify_exchange=True)
     out["ranged_calls"] = len(g.calls)
     q.put((rank, out, g.result_nodes().tobytes()))
     dist.barrier()
@@ -630,3 +630,50 @@ def test_wide_sharded_build_gloo_PARITY_UNPINNED_above_k32(world, chunks):
     for rank, out, _ in results:
         assert out["count"] == len(want) and out["total_kmers"] == total and out["total_reads"] == len(reads)
         assert out["passes"] == FakeWideShardGraph.P and out["pushes"] == FakeWideShardGraph.P   # the input is read once per pass
+
+
+def _corrupt_worker(rank, world, port, reads, k, size, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as O
+    import dbg_assembly_amd.multigpu as M
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FakeShardGraph(O, reads[rank::world], k, world, rank, size)
+    real = M._exchange_range
+
+    def truncated(send, recv, info, j0, j1, world_, rank_, group):   # rank 1 "receives" only part of what rank 0 sent it
+        real(send, recv, info, j0, j1, world_, rank_, group)
+        if rank_ == 1:
+            lo = 0 * info.chunk_bytes + j0 * info.bucket_bytes
+            recv[lo + 16:lo + 64] = 0
+    M._exchange_range = truncated
+    try:
+        M.sharded_finalize(g, "cpu", wrap=_wrap_host, exchange_chunks=1, verify_exchange=True)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_truncated_exchange_fails_loudly_on_every_rank():
+    """multi-GPU hardening: what a rank received is checksummed against what its peers sent; a transfer that lost bytes stops ALL
+    ranks with an error instead of building a wrong table (or leaving the other ranks waiting)"""
+    rng = random.Random(11)
+    g = "".join(rng.choice("ACGT") for _ in range(3000))
+    reads = [g[s:s + 100].encode() for s in (rng.randint(0, 2900) for _ in range(400))]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_corrupt_worker, args=(r, world, port, reads, 21, 100003, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "differ from what was sent" in results[1] and "[0]" in results[1]
+    assert "differ from what was sent" in results[0] and "seen by another rank" in results[0]
