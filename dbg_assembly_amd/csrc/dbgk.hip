@@ -1517,10 +1517,10 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 
 // pageable host buffer -> pinned staging buffer.  One memcpy thread moves ~12 GB/s, less than a third of
 // what the H2D copy behind it can take, so large batches are cut over a few threads (DBGK_COPY_THREADS,
-// default 4; the offset bookkeeping of the batch runs on the calling thread meanwhile).
+// default 8; the offset bookkeeping of the batch runs on the calling thread meanwhile).
 static void staged_copy(char *dst, const char *src, size_t n, std::vector<std::thread> &workers)
 {
-	static const int want = getenv("DBGK_COPY_THREADS") ? atoi(getenv("DBGK_COPY_THREADS")) : 4;
+	static const int want = getenv("DBGK_COPY_THREADS") ? atoi(getenv("DBGK_COPY_THREADS")) : 8;
 	const size_t min_piece = 8u << 20;
 	size_t pieces = want > 1 ? std::min<size_t>((size_t)want, n / min_piece) : 1;
 	if (pieces <= 1) {
