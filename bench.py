@@ -84,6 +84,14 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (process group, slot-range shard, exchange in pieces) with the ranks "
                          "there are, even one: rehearsal of the multi-GPU flow on a one-GPU box")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1 transport: nccl = RCCL over xGMI (the product path); gloo = the same flow with every collective staged "
+                         "through host memory (multigpu.py 'transport') -- with --one-gpu the rehearsal of N ranks on a one-GPU box")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device); correctness rehearsal, "
+                         "the throughput printed is meaningless")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: skip the check after the timed loop (rank 0 rebuilds the WHOLE job with the atomic engine and compares)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +108,8 @@ def parse_args():
         args.engine = 5   # capi.ENGINE_WIDE
     if args.config == "cfg4":
         args.engine = 3   # capi.ENGINE_KFREQ
+    if args.one_gpu and args.backend != "gloo":
+        ap.error("--one-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     return args
 
 
@@ -207,6 +217,50 @@ def golden_cfg2(args, world, n_reads, genome_len):
     return gold
 
 
+def verify_whole_job(args, torch, capi, g, res, P, world, rank, dev_index, device, n_reads, size, sharded):
+    """N > 1, after the timed loop: what the ranks hold TOGETHER against a rebuild of the WHOLE job on rank 0 by a different
+    code path -- the atomic engine (DIRECT; k > 32: the WIDE engine without records): global atomics on one table, no records,
+    no partition, no exchange; itself pinned to the oracle / the reference's dumps in tests/.  Compared: node count, k-mer
+    total, the order-independent node digest (a sum over nodes, so the ranks' digests add up) and DepthStat (contig.cpp:119-181).
+    A mismatch ends the run with an error; a rebuild that cannot run (memory) is reported as such."""
+    wide = args.engine == capi.ENGINE_WIDE
+    ls = g.link_stats(2)
+    depth = [int(x) for x in ls.depth_stat]
+    got = sum_u64_over_ranks([g.digest()] + depth, torch, device)
+    if not sharded:
+        # hash-ownership flow: every rank's table carries a key-0 node and only rank 0's is real -- the placeholders are empty
+        # nodes (eight zero counters each in DepthStat; their digest term is not known here, so the digest is left out)
+        got[1] -= 8 * (world - 1)
+    if rank != 0:
+        return None
+    v_size = size if sharded else capi.find_next_prime_ref(size * world)
+    node_bytes = 32 if wide else 16
+    free = torch.cuda.mem_get_info()[0]
+    need = v_size * node_bytes + n_reads * 200 + (6 << 30)
+    if free < need:
+        return "not run: %.1f GB free on rank 0, the rebuild of the whole job needs %.1f" % (free / 1e9, need / 1e9)
+    with capi.Graph(k=args.kmer, table_slots=v_size, max_read_len=250, device=dev_index,
+                    engine=capi.ENGINE_WIDE if wide else capi.ENGINE_DIRECT, expected_kmers=0) as v:
+        for r in range(world):
+            rb, ro, rnb = v.synth_reads_device(P, r * n_reads, n_reads)
+            v.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
+            v.sync()
+            rb.free()
+            ro.free()
+        st = v.finalize()
+        want = [v.digest()] + [int(x) for x in v.link_stats(2).depth_stat]
+        want_scalars = (int(st.count), int(st.total_kmers), int(st.total_reads))
+    got_scalars = (int(res["count"]), int(res["total_kmers"]), int(res["total_reads"]))
+    same = got_scalars == want_scalars and got[1:] == want[1:] and (got[0] == want[0] or not sharded)
+    if not same:
+        sys.exit("bench.py: the graph the %d ranks hold together differs from the whole job rebuilt on rank 0 with the atomic engine "
+                 "(count / k-mers / reads %r, expected %r; digest %x, expected %x; DepthStat %s)"
+                 % (world, got_scalars, want_scalars, got[0], want[0], "equal" if got[1:] == want[1:] else "differs"))
+    return ("node count, k-mer total, %sDepthStat of the last timed step, added over the %d ranks == the WHOLE job (%d reads) rebuilt on "
+            "rank 0 with the atomic engine (global atomics on one table: no records, no exchange)"
+            % ("node digest and " if sharded else "", world, n_reads * world))
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks ourselves --
     a fresh `python -m torch.distributed.run` child (one process per GPU over RCCL), its stdout (rank 0's one JSON
@@ -223,6 +277,36 @@ def launch_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
+
+
+def start_ranks(args, torch, dist, world, local_rank, single=False):
+    """device of this rank + the process group (RCCL, or gloo for the host-staged rehearsal)"""
+    dev_index = 0 if args.one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1 or single:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = dict(rank=0, world_size=1) if world == 1 else {}
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, **kw)
+        else:
+            dist.init_process_group("gloo", **kw)
+    return dev_index, device
+
+
+def sum_u64_over_ranks(values, torch, device):
+    """all-reduce of unsigned 64-bit sums (mod 2^64): as two 32-bit halves each, so that nothing overflows on the way"""
+    from dbg_assembly_amd.multigpu import all_reduce
+    import torch.distributed as dist
+    halves = []
+    for v in values:
+        v = int(v) & ((1 << 64) - 1)
+        halves += [v & 0xFFFFFFFF, v >> 32]
+    t = torch.tensor(halves, dtype=torch.int64, device=device)
+    all_reduce(t, op=dist.ReduceOp.SUM)
+    h = [int(x) for x in t.cpu().numpy()]
+    return [(h[2 * i] + (h[2 * i + 1] << 32)) & ((1 << 64) - 1) for i in range(len(values))]
 
 
 def cpu_baseline_kfreq(args, genome_len):
@@ -256,22 +340,19 @@ def main_kfreq(args, result_out):
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
-    from dbg_assembly_amd.multigpu import kfreq_reduce, wrap_device_memory
+    from dbg_assembly_amd.multigpu import all_reduce, kfreq_reduce, kfreq_slice_bounds, wrap_device_memory
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     multi = world > 1
-    if multi:
-        dist.init_process_group("nccl", device_id=device)
+    dev_index, device = start_ranks(args, torch, dist, world, local_rank)
     n_reads, k = args.reads_per_gpu, args.kmer
     kpr = 150 - k + 1
     genome_len = args.genome_per_gpu * world
     P = capi.synth_params(genome_len, 150, cfg=CONFIGS["cfg4"]["synth_cfg"])
-    g = capi.Graph(k=k, table_slots=0, max_read_len=250, device=local_rank, engine=capi.ENGINE_KFREQ, expected_kmers=n_reads * kpr)
+    g = capi.Graph(k=k, table_slots=0, max_read_len=250, device=dev_index, engine=capi.ENGINE_KFREQ, expected_kmers=n_reads * kpr)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)
 
     def step():
@@ -301,7 +382,7 @@ def main_kfreq(args, result_out):
     dt = time.perf_counter() - t0
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = g.timings()
     ms_per_step = dt / args.steps * 1e3
@@ -315,7 +396,7 @@ def main_kfreq(args, result_out):
         mine = wrap_device_memory(ptr, n_counts, device).view(torch.int64)
         sum_a = int(mine.sum().item()) & ((1 << 64) - 1)
         xor_a = int(torch.bitwise_xor(mine[0::2], mine[1::2]).sum().item()) & ((1 << 64) - 1)
-        with capi.Graph(k=k, table_slots=0, max_read_len=250, device=local_rank, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
+        with capi.Graph(k=k, table_slots=0, max_read_len=250, device=dev_index, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
             g2.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
             st2 = g2.finalize()
             ptr2, _ = g2.kfreq_device_counts()
@@ -327,6 +408,39 @@ def main_kfreq(args, result_out):
         verified = ("the 4^%d-byte table of the last timed step == the table the atomic kernel builds from the same reads (byte for byte), "
                     "%d distinct canonical k-mers; both paths are pinned to the oracle in tests/test_kfreq.py" % (k, distinct))
         del mine, other, xor_a
+    elif not args.no_verify:
+        # N > 1: after the reduce-scatter rank d owns the counters of the k-mer values [bounds[d], bounds[d+1]) of the WHOLE job.
+        # Two 64-bit sums over the 8-byte words of every owned range (plain, and of a mixed word), added over the ranks, against
+        # the same sums over the table rank 0 builds from ALL ranks' reads with the atomic kernel (no records, no exchange)
+        def sums(words):
+            mixed = (words * -7046029254386353131) ^ (words >> 29)
+            return [int(words.sum().item()), int(mixed.sum().item())]
+        ptr, n_counts = g.kfreq_device_counts()
+        bounds = kfreq_slice_bounds(n_counts, world)
+        table = wrap_device_memory(ptr, n_counts, device)
+        got = sum_u64_over_ranks(sums(table[bounds[rank]:bounds[rank + 1]].view(torch.int64)), torch, device)
+        if rank == 0:
+            free = torch.cuda.mem_get_info()[0]
+            if free < n_counts + (4 << 30):
+                verified = "not run: %.1f GB free on rank 0, the whole-job table needs %.1f" % (free / 1e9, n_counts / 1e9)
+            else:
+                with capi.Graph(k=k, table_slots=0, max_read_len=250, device=dev_index, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
+                    for r in range(world):
+                        rb, ro, rnb = g2.synth_reads_device(P, r * n_reads, n_reads)
+                        g2.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
+                        g2.sync()
+                        rb.free()
+                        ro.free()
+                    st2 = g2.finalize()
+                    ptr2, _ = g2.kfreq_device_counts()
+                    want = [v & ((1 << 64) - 1) for v in sums(wrap_device_memory(ptr2, n_counts, device).view(torch.int64))]
+                    whole_distinct = int(st2.count)
+                if got != want:
+                    sys.exit("bench.py cfg4: the reduce-scattered tables of the %d ranks differ from the table of the whole job "
+                             "(checksums %r, expected %r)" % (world, got, want))
+                verified = ("two 64-bit checksums over the counters every rank owns after the reduce-scatter, added over the %d ranks == the same "
+                            "checksums of the table the atomic kernel builds on rank 0 from ALL ranks' reads (%d distinct canonical k-mers)"
+                            % (world, whole_distinct))
     if rank == 0:
         b_alg = 150.0 / kpr + 2.0   # bases + one counter byte read + one written
         achieved = kmers_step * b_alg / (ms_per_step * 1e-3) / 1e9
@@ -392,7 +506,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dbg_assembly_amd import capi
-    from dbg_assembly_amd.multigpu import HipEngine, WideHipEngine, exchange_and_merge, sharded_finalize, wide_sharded_build
+    from dbg_assembly_amd.multigpu import HipEngine, WideHipEngine, all_reduce, exchange_and_merge, sharded_finalize, wide_sharded_build
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -403,16 +517,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_sharded
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if world == 1:
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-        else:
-            dist.init_process_group("nccl", device_id=device)
+    dev_index, device = start_ranks(args, torch, dist, world, local_rank, single=args.force_sharded)
 
     n_reads = args.reads_per_gpu
     genome_len = args.genome_per_gpu * world
@@ -432,7 +538,7 @@ def main():
         per_gpu_slots = min(per_gpu_slots, (2 ** 32 - 2 ** 22) // world)
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
-    g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=local_rank, engine=args.engine,
+    g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=dev_index, engine=args.engine,
                    expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not os.environ.get("DBGK_WIDE_DIRECT")
                    else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0,
@@ -493,7 +599,7 @@ def main():
     dt = time.perf_counter() - t0
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = g.timings()
 
@@ -512,6 +618,8 @@ def main():
                      "(count/kmers/digest %r, expected %r)" % (got[:3], want[:3]))
         verified = ("count, k-mer total, node digest and DepthStat of the last timed step == tests/golden/cfg2_full.json (full size; CPU oracle"
                     + (", confirmed by the real reference" if gold.get("confirmed_by") else "") + ")")
+    if multi and not args.no_verify and not (debug_mode or debug_l2):
+        verified = verify_whole_job(args, torch, capi, g, res, P, world, rank, dev_index, device, n_reads, size, sharded)
     value_incl_h2d = None
     if world == 1 and not multi and not args.no_h2d and args.config != "cfg5" and not (debug_mode or debug_l2):
         import numpy as np

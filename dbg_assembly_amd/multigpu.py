@@ -85,12 +85,79 @@ class WideHipEngine(HipEngine):
 MAX_MESSAGE_BYTES = 512 << 20
 
 
+# ---- transport ------------------------------------------------------------------------------------------------
+# The product transport is RCCL (backend "nccl"): every collective below runs on device memory over xGMI.  A process
+# group WITHOUT a device transport (gloo) can still drive real handles: device tensors are then staged through host
+# copies around each collective.  That is how several ranks are rehearsed on ONE GPU (bench.py --backend gloo
+# --one-gpu, tests/test_gpu_multigpu.py: RCCL refuses two ranks on one device) and what a node whose RCCL cannot do
+# peer transfers falls back to.  Only the transport changes: every kernel of the flow still runs on the GPU.
+def _host_staged(t, group):
+    return bool(t.is_cuda) and dist.get_backend(group) != "nccl"
+
+
+def all_reduce(t, op, group=None):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def all_to_all_single(out, inp, group=None):
+    if _host_staged(out, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h, inp.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def all_gather(outs, t, group=None):
+    if _host_staged(t, group):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+def broadcast(buf, src, group=None):
+    if _host_staged(buf, group):
+        h = buf.cpu()
+        dist.broadcast(h, src=src, group=group)
+        buf.copy_(h)
+    else:
+        dist.broadcast(buf, src=src, group=group)
+
+
+def _run_p2p(sends, recvs, group):
+    """sends / recvs: lists of (tensor view, peer).  One batch of point-to-point transfers, complete on return (NCCL: the
+    current stream is ordered behind it)."""
+    if not sends and not recvs:
+        return
+    staged = _host_staged((sends or recvs)[0][0], group)
+    ops, landing = [], []
+    for t, peer in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group))
+    for t, peer in recvs:
+        h = torch.empty(t.shape, dtype=t.dtype) if staged else t
+        landing.append((t, h))
+        ops.append(dist.P2POp(dist.irecv, h, peer, group))
+    for work in dist.batch_isend_irecv(ops):
+        work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+    if staged:
+        for t, h in landing:
+            t.copy_(h)
+
+
 def exchange_slices(pairs, rank, group=None):
     """pairs: list of (send_view, recv_view, peer) of uint8 tensors, equal sizes on both ends of a pair.
     Moves send_view of every pair to the peer's recv_view."""
     longest = max([int(sv.numel()) for sv, _, _ in pairs] + [0])
     for off in range(0, longest, MAX_MESSAGE_BYTES):
-        ops = []
+        sends, recvs = [], []
         for sv, rv, peer in pairs:
             n = int(sv.numel())
             if off >= n:
@@ -99,18 +166,16 @@ def exchange_slices(pairs, rank, group=None):
             if peer == rank:
                 rv[off:hi].copy_(sv[off:hi])
             else:
-                ops.append(dist.P2POp(dist.isend, sv[off:hi], peer, group))
-                ops.append(dist.P2POp(dist.irecv, rv[off:hi], peer, group))
-        if ops:
-            for work in dist.batch_isend_irecv(ops):
-                work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+                sends.append((sv[off:hi], peer))
+                recvs.append((rv[off:hi], peer))
+        _run_p2p(sends, recvs, group)
 
 
 def _exchange_uneven(pairs, rank, group=None):
     """like exchange_slices, but the two directions of a pair have their own lengths"""
     longest = max([max(int(sv.numel()), int(rv.numel())) for sv, rv, _ in pairs] + [0])
     for off in range(0, longest, MAX_MESSAGE_BYTES):
-        ops = []
+        sends, recvs = [], []
         for sv, rv, peer in pairs:
             sn, rn = int(sv.numel()), int(rv.numel())
             if peer == rank:
@@ -119,12 +184,10 @@ def _exchange_uneven(pairs, rank, group=None):
                     rv[off:hi].copy_(sv[off:hi])
                 continue
             if off < sn:
-                ops.append(dist.P2POp(dist.isend, sv[off:min(sn, off + MAX_MESSAGE_BYTES)], peer, group))
+                sends.append((sv[off:min(sn, off + MAX_MESSAGE_BYTES)], peer))
             if off < rn:
-                ops.append(dist.P2POp(dist.irecv, rv[off:min(rn, off + MAX_MESSAGE_BYTES)], peer, group))
-        if ops:
-            for work in dist.batch_isend_irecv(ops):
-                work.wait()
+                recvs.append((rv[off:min(rn, off + MAX_MESSAGE_BYTES)], peer))
+        _run_p2p(sends, recvs, group)
 
 
 def exchange_and_merge(engine, group=None):
@@ -142,7 +205,7 @@ def exchange_and_merge(engine, group=None):
     dev = getattr(engine, "device", "cpu")
     mat = torch.zeros((world, world), dtype=torch.int64, device=dev)
     mat[rank] = torch.as_tensor(counts, dtype=torch.int64, device=dev)
-    dist.all_reduce(mat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(mat, op=dist.ReduceOp.SUM, group=group)
     mat_h = mat.cpu().numpy()
     send_counts = mat_h[rank]           # what I send to each owner
     recv_counts = mat_h[:, rank]        # what each rank sends to me
@@ -172,7 +235,7 @@ def exchange_and_merge(engine, group=None):
     # 3. scalar totals.  Every rank's owned count includes one key-0 node (rank 0 owns the real
     # one); the global graph has exactly one, so subtract the world-1 placeholders.
     tot = torch.tensor([local_reads, local_kmers, local_stored, int(owned.count)], dtype=torch.int64, device=dev)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]),
             "count": int(tot[3]) - (world - 1), "owned_count": int(owned.count),
@@ -240,11 +303,11 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
 
     # 1. per-bucket k-mer counts of the whole job
     bucket_counts = send_cnt.view(torch.int32).to(torch.int64)
-    dist.all_reduce(bucket_counts, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(bucket_counts, op=dist.ReduceOp.SUM, group=group)
     records_global = int(bucket_counts.sum().item())
 
     # 2. the exchange
-    dist.all_to_all_single(recv_cnt, send_cnt, group=group)
+    all_to_all_single(recv_cnt, send_cnt, group=group)
     # every own bucket must have received exactly what the all-reduce says the job holds for it (counts are capped by the
     # bucket capacity on both sides alike): a wrong fill count would silently drop or invent records
     B = int(info.buckets_per_rank)
@@ -252,7 +315,7 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
     mine = recv_cnt.view(torch.int32).to(torch.int64).view(world, per).sum(dim=0)
     want = bucket_counts.view(world, per)[rank]
     flag = torch.tensor([0 if bool(torch.equal(mine, want)) else 1], dtype=torch.int64, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     if int(flag.item()):
         raise RuntimeError("rank %d: the exchanged bucket fill counts disagree with the all-reduced totals (here or on another rank)" % rank)
     n_chunks = max(1, min(int(exchange_chunks), B))
@@ -289,10 +352,10 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
         sent = torch.stack([send[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
         got = torch.stack([recv[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
         theirs = torch.empty_like(sent)
-        dist.all_to_all_single(theirs, sent, group=group)   # theirs[p] = checksum of what rank p sent to me
+        all_to_all_single(theirs, sent, group=group)   # theirs[p] = checksum of what rank p sent to me
         bad = [p for p in range(world) if int(theirs[p]) != int(got[p])]
         flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)   # every rank stops, not only the one that saw it (no rank is left waiting)
+        all_reduce(flag, op=dist.ReduceOp.MAX, group=group)   # every rank stops, not only the one that saw it (no rank is left waiting)
         if int(flag.item()):
             raise RuntimeError("rank %d: the level-1 record buckets received from rank(s) %r differ from what was sent "
                                "(a truncated or corrupted transfer%s)" % (rank, bad, "" if bad else " seen by another rank"))
@@ -305,7 +368,7 @@ def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
     world = dist.get_world_size(group)
     sizes = torch.tensor([n], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
+    all_gather(all_sizes, sizes, group=group)
     all_sizes = torch.stack(all_sizes).cpu().numpy()[:, 0]
     longest = int(all_sizes.max())
     if not longest:
@@ -314,7 +377,7 @@ def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
     if n:
         mine[:n * node_bytes] = wrap(ptr, n * node_bytes, device)
     lists = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(lists, mine, group=group)
+    all_gather(lists, mine, group=group)
     if on_gpu:
         torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
     return all_sizes, lists
@@ -338,13 +401,13 @@ def _hand_offs(g, device, group, wrap, node_bytes):
     p_hh, n_hh = g.shard_heavy()
     sizes = torch.tensor([n_hh], dtype=torch.int64, device=device)
     hh_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(hh_sizes, sizes, group=group)
+    all_gather(hh_sizes, sizes, group=group)
     hh_sizes = torch.stack(hh_sizes).cpu().numpy()[:, 0]
     for src in range(world):
         if hh_sizes[src]:
             nbytes = int(hh_sizes[src]) * node_bytes
             buf = wrap(p_hh, nbytes, device).clone() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
-            dist.broadcast(buf, src=src, group=group)
+            broadcast(buf, src=src, group=group)
             if on_gpu:
                 torch.cuda.synchronize()
             g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))
@@ -384,7 +447,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8, verify
     # 5. key-0 node onto rank 0, totals
     links = torch.tensor([int(st.polyA_l_link), int(st.polyA_r_link)], dtype=torch.int64, device=device)
     all_links = [torch.zeros_like(links) for _ in range(world)]
-    dist.all_gather(all_links, links, group=group)
+    all_gather(all_links, links, group=group)
     if rank == 0:
         for src in range(1, world):
             l, r = (int(x) for x in all_links[src].cpu().numpy())
@@ -392,7 +455,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8, verify
                 g.add_polyA(l, r)
     owned = g.refresh_stats()
     tot = torch.tensor([local[0], local[1], local[2], int(owned.count)], dtype=torch.int64, device=device)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global,
@@ -434,7 +497,7 @@ def wide_sharded_build(g, device, push_all, group=None, wrap=None, exchange_chun
         g.shard_side_clear()
     owned = g.refresh_stats()
     tot = torch.tensor([local[0], local[1], local[2], int(owned.count)], dtype=torch.int64, device=device)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global, "passes": n_passes,

@@ -186,3 +186,38 @@ def test_wide_sharded_build_single_rank_nccl(n_passes):
             d_off.free()
     finally:
         dist.destroy_process_group()
+
+
+SMALL = ["--reads-per-gpu", "200000", "--genome-per-gpu", "1500000", "--table-slots", "40000000", "--steps", "2", "--warmup", "1",
+         "--no-cpu-baseline"]
+
+
+@pytest.mark.parametrize("extra", [
+    ["--gpus", "2"],                                                   # cfg2's flow: slot-range shards, records exchanged in pieces
+    ["--gpus", "3", "--exchange-chunks", "3"],                         # 29 level-1 buckets over 3 ranks: the last rank owns fewer
+    ["--gpus", "2", "--exchange", "nodes", "--table-slots", "80000000"],   # hash ownership, aggregated nodes exchanged (local tables)
+    ["--gpus", "2", "--config", "cfg5"],                               # k = 63: 16-byte records, 32-byte nodes, side tables gathered
+    ["--gpus", "3", "--config", "cfg5", "--passes", "2"],              # ... in two passes over the input
+    ["--gpus", "2", "--config", "cfg4", "--kmer", "14"],               # frequency tables, saturating reduce-scatter
+], ids=lambda e: "_".join(x.lstrip("-") for x in e))
+def test_several_ranks_on_one_gpu_build_the_whole_jobs_graph(extra):
+    """The N > 1 flows with N REAL ranks -- real handles, real kernels, every rank its own reads and its own shard -- on the one
+    GPU a test box has: `bench.py --gpus N --backend gloo --one-gpu` (RCCL refuses two ranks on one device, so the collectives
+    are staged through host memory: multigpu.py 'transport'; everything else is the code the 8-GPU run executes).  After its
+    timed loop bench.py adds up count / k-mer total / node digest / DepthStat over the ranks and compares them with the WHOLE
+    job rebuilt on rank 0 by the atomic engine (cfg4: checksums of the owned counter ranges against the whole-job table); a
+    mismatch is a non-zero exit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--backend", "gloo", "--one-gpu"] + SMALL + extra,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == int(extra[1])
+    assert out["verified"] and "== the" in out["verified"] and not out["verified"].startswith("not run"), out["verified"]
+    if "cfg4" not in extra:
+        assert out["config"]["nodes"] > 1000000
