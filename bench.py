@@ -17,6 +17,10 @@ Workload (--config): cfg2 (default) = BASELINE.json configs[1] PER GPU at every 
 reads, k = 31, 30x of a 50 Mb genome per GPU => weak scaling); cfg3 = configs[2], 200 M reads of a
 1 Gb genome into one table of 8.6 G slots at N = 8 (25 M reads per GPU; fewer GPUs run their share).
 
+After the timed loop at N > 1 the ranks' results (node digest, DepthStat, counts) are added up and compared with the WHOLE
+job rebuilt on rank 0 by the atomic engine (`verified`; --no-verify skips it).  --backend gloo --one-gpu runs the same N-rank
+flows with all ranks on GPU 0 and host-staged collectives: a correctness rehearsal for one-GPU boxes, not a measurement.
+
 Prints ONE JSON line on rank 0 (contract in the task description).  `roofline` is the WHOLE step:
 algorithmic bytes of the step (33.25 B per k-mer) / ms_per_step against the 8 TB/s
 spec peak (`frac`) and against the copy bandwidth measured in the same run (`frac_of_measured`);
