@@ -9,6 +9,16 @@ import os
 
 import numpy as np
 
+# ONE HIP runtime per process.  torch ships its own libamdhip64 / libhsa-runtime64; if libdbgk.so (linked against /opt/rocm) is
+# loaded FIRST, both copies end up in the process and torch's finds no device ("No HIP GPUs are available").  With torch's loaded
+# first the library binds to that copy (same soname) and everything -- zero-copy tensors over the library's buffers, pinned
+# tensors recognised by dbgk_push_reads -- shares one runtime (profiles/ubench/hip_runtime_order.py shows both orders).  A C++
+# caller never sees this; it only concerns Python processes that use both.
+try:
+    import torch  # noqa: F401  (plumbing: load order only)
+except ImportError:
+    pass
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DBGK_LIB") or os.path.join(HERE, "lib", "libdbgk.so")  # DBGK_LIB: A/B runs of two builds in one session
 

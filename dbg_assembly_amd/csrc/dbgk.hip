@@ -68,7 +68,8 @@ struct StageSlot {
 	uint64_t *d_offsets = nullptr;
 	uint32_t *d_start = nullptr;
 	uint32_t *d_dead = nullptr;
-	hipEvent_t done = nullptr;
+	hipEvent_t done = nullptr;      // the kernels that read the device buffers have run
+	hipEvent_t copied = nullptr;    // the host-to-device copies of the batch have run (copy stream)
 	bool busy = false;
 };
 
@@ -178,6 +179,8 @@ struct dbgk_handle {
 	// large device-to-host copies (the host KmerSet): slices through pinned buffers, host threads moving them on
 	std::vector<void *> d2h_stage;
 	std::vector<hipEvent_t> d2h_ev;
+	hipEvent_t source_read = nullptr; // dbgk_push_reads from a pinned caller buffer: the last host-to-device copy out of it
+	hipStream_t copy_stream = nullptr; // host-to-device copies of the batches: batch i+1 travels while the kernels of batch i run
 
 	std::vector<TimedSpan> spans, free_spans;
 	float phase_ms[PH_COUNT] = {0};
@@ -322,6 +325,11 @@ static void free_handle(dbgk_handle *h)
 		if (p) (void)hipHostFree(p);
 	for (hipEvent_t e : h->d2h_ev)
 		if (e) (void)hipEventDestroy(e);
+	if (h->source_read) (void)hipEventDestroy(h->source_read);
+	if (h->copy_stream) {
+		(void)hipStreamSynchronize(h->copy_stream);
+		(void)hipStreamDestroy(h->copy_stream);
+	}
 	for (auto &s : h->slots) {
 		if (s.h_bases) (void)hipHostFree(s.h_bases);
 		if (s.h_offsets) (void)hipHostFree(s.h_offsets);
@@ -330,6 +338,7 @@ static void free_handle(dbgk_handle *h)
 		if (s.d_start) (void)hipFree(s.d_start);
 		if (s.d_dead) (void)hipFree(s.d_dead);
 		if (s.done) (void)hipEventDestroy(s.done);
+		if (s.copied) (void)hipEventDestroy(s.copied);
 	}
 	for (auto &v : {&h->spans, &h->free_spans})
 		for (auto &s : *v) {
@@ -1535,6 +1544,24 @@ static void staged_copy(char *dst, const char *src, size_t n, std::vector<std::t
 	memcpy(dst, src, std::min(n, per));
 }
 
+// Is the caller's buffer page-locked memory the GPU reads directly (hipHostMalloc / hipHostRegister -- a torch pinned tensor, a
+// parser's own pinned arena)?  Then dbgk_push_reads copies host-to-device straight out of it: the staging copy, which is what
+// bounds the pageable path (~30 GB/s against the link's 57), does not happen.
+static bool device_readable_host(const char *p, size_t n)
+{
+	static const bool off = getenv("DBGK_NO_PINNED_SOURCE") && atoi(getenv("DBGK_NO_PINNED_SOURCE"));
+	if (off || !p || !n) return false;
+	for (const char *q : {p, p + n - 1}) {
+		hipPointerAttribute_t a;
+		if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+			(void)hipGetLastError(); // plain malloc'ed memory: "invalid value", not an error of ours
+			return false;
+		}
+		if (a.type != hipMemoryTypeHost) return false;
+	}
+	return true;
+}
+
 static int ensure_slot(dbgk_handle *h, StageSlot &s)
 {
 	if (s.d_bases) return DBGK_OK;
@@ -1546,6 +1573,28 @@ static int ensure_slot(dbgk_handle *h, StageSlot &s)
 	if (hipMalloc(&s.d_start, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
 	if (hipMalloc(&s.d_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
 	HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+	return DBGK_OK;
+}
+
+// The host-to-device copies of a batch (sequences from `src`, offsets from the slot's pinned array) on the handle's COPY stream; the
+// compute stream waits for them.  The copy of batch i+1 so overlaps the kernels of batch i (and the table reset in front of the
+// first batch) instead of queueing behind them.  The slot's device buffers are free: the caller has waited for s.done.
+static int h2d_batch(dbgk_handle *h, StageSlot &s, const char *src, uint64_t nb, uint64_t n_offsets, bool last_of_pinned_source)
+{
+	static const bool serial = getenv("DBGK_COPY_ON_COMPUTE_STREAM") && atoi(getenv("DBGK_COPY_ON_COMPUTE_STREAM")); // measurements
+	if (!serial && !h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+	hipStream_t cs = serial ? h->stream : h->copy_stream;
+	if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, src, nb, hipMemcpyHostToDevice, cs));
+	HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, n_offsets * 8, hipMemcpyHostToDevice, cs));
+	if (last_of_pinned_source) { // the caller's buffer is free again once the LAST copy out of it has run: waited for on return
+		if (!h->source_read) HIPCHK(hipEventCreateWithFlags(&h->source_read, hipEventDisableTiming));
+		HIPCHK(hipEventRecord(h->source_read, cs));
+	}
+	if (!serial) {
+		HIPCHK(hipEventRecord(s.copied, cs));
+		HIPCHK(hipStreamWaitEvent(h->stream, s.copied, 0));
+	}
 	return DBGK_OK;
 }
 
@@ -1602,8 +1651,8 @@ extern "C" int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads)
 		rc = flush_records(h);
 		if (rc) return rc;
 	}
-	if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
-	HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream));
+	rc = h2d_batch(h, s, s.h_bases, nb, n_reads + 1, false);
+	if (rc) return rc;
 	rc = launch_batch(h, s.d_bases, s.d_offsets, n_reads, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
 	if (rc) return rc;
 	h->pending_kmers += batch_windows;
@@ -1621,25 +1670,34 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 	int rc = use_device(h);
 	if (rc) return rc;
 	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
-	auto windows_of = [&](uint64_t len) { const uint64_t rl = len > max_len ? max_len : len; return rl >= K ? rl - K + 1 : 0ull; };
 	// PARTITION engine: the record store holds store_capacity occurrences; a batch that would not fit is
 	// preceded by a flush (records -> table, dbgk_flush).  Batches are cut to the room that is left only when
 	// the store is at least one staging batch large; a smaller store (expected_kmers a gross under-estimate)
 	// takes whole batches and sends the excess through its overflow lists as before.
 	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
 	const bool cut_to_room = streaming && h->store_capacity >= h->cap_bases && !h->wpart; // (a wide store is built once: no point in filling it to the brim)
+	const bool pinned_source = n_reads && device_readable_host(bases + offsets[0], offsets[n_reads] - offsets[0]);
 	uint64_t r0 = 0;
 	while (r0 < n_reads) {
-		// largest [r0, r1) that fits the staging buffers (and the record store)
-		uint64_t r1 = r0, batch_windows = 0;
+		// largest [r0, r1) that fits the staging buffers (and the record store).  ONE read-only pass over the offsets validates them
+		// and gathers everything the launch needs (windows, longest read, equal lengths); the rebased copy for the device is
+		// written later, while the sequences are on their way
+		uint64_t r1 = r0, batch_windows = 0, len_max = 0;
 		const uint64_t base0 = offsets[r0];
 		const uint64_t room = h->store_capacity > h->pending_kmers ? h->store_capacity - h->pending_kmers : 0;
-		while (r1 < n_reads && (r1 - r0) < h->cap_reads && offsets[r1 + 1] - base0 <= h->cap_bases) {
-			if (offsets[r1 + 1] < offsets[r1]) return DBGK_ERR_ARG;
-			const uint64_t w = windows_of(offsets[r1 + 1] - offsets[r1]);
+		const uint64_t r_end = std::min<uint64_t>(n_reads, r0 + h->cap_reads);
+		const uint64_t first_len = offsets[r0 + 1] >= base0 ? offsets[r0 + 1] - base0 : 0;
+		bool uniform = true;
+		for (uint64_t prev = base0; r1 < r_end; r1++) {
+			const uint64_t next = offsets[r1 + 1];
+			if (next < prev) return DBGK_ERR_ARG;
+			if (next - base0 > h->cap_bases) break;
+			const uint64_t len = next - prev, rl = len > max_len ? max_len : len, w = rl >= K ? rl - K + 1 : 0ull;
 			if (cut_to_room && batch_windows + w > room && (r1 > r0 || h->pending_kmers > 0)) break;
 			batch_windows += w;
-			r1++;
+			len_max = len > len_max ? len : len_max;
+			uniform = uniform && len == first_len;
+			prev = next;
 		}
 		if (streaming && !(h->wpart && h->wbuilt) && h->pending_kmers > 0 &&
 		    (r1 == r0 || (!cut_to_room && h->pending_kmers + batch_windows > h->store_capacity))) {
@@ -1648,6 +1706,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			if (r1 == r0) continue; // cut again with the whole store free
 		}
 		if (r1 == r0) return DBGK_ERR_ARG; // a single read larger than max_batch_bases
+		if (h->seed && len_max >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
 		StageSlot &s = h->slots[h->next_slot];
 		rc = ensure_slot(h, s);
 		if (rc) return rc;
@@ -1661,21 +1720,17 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			std::vector<std::thread> &w;
 			~Join() { for (auto &t : w) if (t.joinable()) t.join(); }
 		} join_copiers{copiers};
-		if (nb) staged_copy(s.h_bases, bases + base0, nb, copiers);
-		int has_long = 0;
-		int64_t uniform_len = nr ? (int64_t)(offsets[r0 + 1] - offsets[r0]) : 0;
-		uint64_t len_max = 0;
-		for (uint64_t i = 0; i <= nr; i++) {
-			if (offsets[r0 + i] < base0 || (i && offsets[r0 + i] < offsets[r0 + i - 1])) return DBGK_ERR_ARG;
-			s.h_offsets[i] = offsets[r0 + i] - base0;
-			if (i && s.h_offsets[i] - s.h_offsets[i - 1] > (uint64_t)h->cfg.max_read_len) has_long = 1;
-			if (i && (int64_t)(s.h_offsets[i] - s.h_offsets[i - 1]) != uniform_len) uniform_len = 0;
-			if (i) len_max = std::max<uint64_t>(len_max, s.h_offsets[i] - s.h_offsets[i - 1]);
-			if (h->seed && i && s.h_offsets[i] - s.h_offsets[i - 1] >= (1ull << 30)) return DBGK_ERR_ARG; // pos is a 30-bit field
+		if (nb && !pinned_source) staged_copy(s.h_bases, bases + base0, nb, copiers);
+		const int has_long = len_max > max_len ? 1 : 0;
+		const int64_t uniform_len = uniform ? (int64_t)first_len : 0;
+		{
+			const uint64_t *src = offsets + r0;
+			uint64_t *dst = s.h_offsets;
+			for (uint64_t i = 0; i <= nr; i++) dst[i] = src[i] - base0;
 		}
 		for (auto &t : copiers) t.join();
-		if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, s.h_bases, nb, hipMemcpyHostToDevice, h->stream));
-		HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, (nr + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		rc = h2d_batch(h, s, pinned_source ? bases + base0 : s.h_bases, nb, nr + 1, pinned_source && r1 == n_reads);
+		if (rc) return rc;
 		rc = launch_batch(h, s.d_bases, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
 		if (rc) return rc;
 		h->pending_kmers += batch_windows;
@@ -1684,6 +1739,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 		h->next_slot ^= 1;
 		r0 = r1;
 	}
+	if (pinned_source && h->source_read) HIPCHK(hipEventSynchronize(h->source_read)); // as with the staged path: `bases` may be reused on return
 	return DBGK_OK;
 }
 

@@ -165,7 +165,10 @@ int dbgk_reset(dbgk_handle *h);
  * separators (ASCII, contract ACGTNacgtn; N counts as A like seqKmer.cpp:9-19; any other byte is
  * outside the contract -- undefined behaviour in the reference, an unspecified base here), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
  * HOST buffers; the call copies them through pinned double buffers and returns once the batch is
- * queued (asynchronous w.r.t. the device).                                                       */
+ * queued (asynchronous w.r.t. the device).  If `bases` is page-locked memory the GPU can read (hipHostMalloc,
+ * hipHostRegister: detected with hipPointerGetAttributes) the sequences are copied host-to-device straight out of
+ * it -- no staging copy, which is what bounds the pageable path -- and the call returns when the last of those
+ * copies has run.  Either way the buffers may be reused on return.                                */
 int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 
 /* the same without the copy: dbgk_push_acquire returns the handle's next pinned staging buffers -- room for cap_bases sequence

@@ -814,3 +814,23 @@ def test_comm_resize_across_shards_and_host_staged_copies(capi, oracle, n_shards
         assert oracle.check_host_table(array, flags, bigger, st.count) == 0
         occ = np.unpackbits(flags)[:bigger].astype(bool)
         assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)
+
+
+def test_push_reads_from_page_locked_memory_skips_the_staging_copy(capi, oracle):
+    """dbgk_push_reads from a pinned caller buffer (torch pinned tensor == hipHostMalloc): host-to-device copies come straight
+    out of the caller's memory, in several batches; same graph as from pageable memory and as the oracle; the buffer may be
+    overwritten as soon as the call returns"""
+    import torch
+    PO = oracle.synth_params(300000, 150, cfg=2)
+    bases, offsets = oracle.synth_reads(PO, 0, 20000)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.01)
+    pinned = torch.empty(len(bases), dtype=torch.uint8).pin_memory()
+    view = pinned.numpy()
+    for engine, slots, expected in ((capi.ENGINE_DIRECT, 10000019, 0), (capi.ENGINE_PARTITION, capi.find_next_prime_ref(1 << 26), 20000 * 120)):
+        with capi.Graph(k=31, table_slots=slots, engine=engine, expected_kmers=expected, max_batch_bases=1 << 19) as g:
+            view[:] = bases
+            g.push_reads(view, offsets)
+            view[:] = 65      # every copy out of the buffer has run when the call returns
+            st = g.finalize()
+            assert (int(st.count), int(st.total_kmers)) == (ref.count, ref.total_kmers)
+            assert np.array_equal(g.export_sorted(), ref.nodes)
