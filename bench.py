@@ -243,17 +243,20 @@ def verify_whole_job(args, torch, capi, g, res, P, world, rank, dev_index, devic
     need = v_size * node_bytes + n_reads * 200 + (6 << 30)
     if free < need:
         return "not run: %.1f GB free on rank 0, the rebuild of the whole job needs %.1f" % (free / 1e9, need / 1e9)
-    with capi.Graph(k=args.kmer, table_slots=v_size, max_read_len=250, device=dev_index,
-                    engine=capi.ENGINE_WIDE if wide else capi.ENGINE_DIRECT, expected_kmers=0) as v:
-        for r in range(world):
-            rb, ro, rnb = v.synth_reads_device(P, r * n_reads, n_reads)
-            v.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
-            v.sync()
-            rb.free()
-            ro.free()
-        st = v.finalize()
-        want = [v.digest()] + [int(x) for x in v.link_stats(2).depth_stat]
-        want_scalars = (int(st.count), int(st.total_kmers), int(st.total_reads))
+    try:
+        with capi.Graph(k=args.kmer, table_slots=v_size, max_read_len=250, device=dev_index,
+                        engine=capi.ENGINE_WIDE if wide else capi.ENGINE_DIRECT, expected_kmers=0) as v:
+            for r in range(world):
+                rb, ro, rnb = v.synth_reads_device(P, r * n_reads, n_reads)
+                v.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
+                v.sync()
+                rb.free()
+                ro.free()
+            st = v.finalize()
+            want = [v.digest()] + [int(x) for x in v.link_stats(2).depth_stat]
+            want_scalars = (int(st.count), int(st.total_kmers), int(st.total_reads))
+    except capi.DbgkError as e:   # the check could not be made (memory): say so, the measurement stands
+        return "not run: the rebuild of the whole job on rank 0 failed (%s)" % e
     got_scalars = (int(res["count"]), int(res["total_kmers"]), int(res["total_reads"]))
     same = got_scalars == want_scalars and got[1:] == want[1:] and (got[0] == want[0] or not sharded)
     if not same:
@@ -428,21 +431,26 @@ def main_kfreq(args, result_out):
             if free < n_counts + (4 << 30):
                 verified = "not run: %.1f GB free on rank 0, the whole-job table needs %.1f" % (free / 1e9, n_counts / 1e9)
             else:
-                with capi.Graph(k=k, table_slots=0, max_read_len=250, device=dev_index, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
-                    for r in range(world):
-                        rb, ro, rnb = g2.synth_reads_device(P, r * n_reads, n_reads)
-                        g2.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
-                        g2.sync()
-                        rb.free()
-                        ro.free()
-                    st2 = g2.finalize()
-                    ptr2, _ = g2.kfreq_device_counts()
-                    want = [v & ((1 << 64) - 1) for v in sums(wrap_device_memory(ptr2, n_counts, device).view(torch.int64))]
-                    whole_distinct = int(st2.count)
-                if got != want:
+                try:
+                    with capi.Graph(k=k, table_slots=0, max_read_len=250, device=dev_index, engine=capi.ENGINE_KFREQ, expected_kmers=0) as g2:
+                        for r in range(world):
+                            rb, ro, rnb = g2.synth_reads_device(P, r * n_reads, n_reads)
+                            g2.push_reads_device(rb.ptr, ro.ptr, n_reads, rnb)
+                            g2.sync()
+                            rb.free()
+                            ro.free()
+                        st2 = g2.finalize()
+                        ptr2, _ = g2.kfreq_device_counts()
+                        want = [v & ((1 << 64) - 1) for v in sums(wrap_device_memory(ptr2, n_counts, device).view(torch.int64))]
+                        whole_distinct = int(st2.count)
+                except capi.DbgkError as e:   # the check could not be made (memory): say so, the measurement stands
+                    want = None
+                    verified = "not run: the whole-job table on rank 0 failed (%s)" % e
+                if want is not None and got != want:
                     sys.exit("bench.py cfg4: the reduce-scattered tables of the %d ranks differ from the table of the whole job "
                              "(checksums %r, expected %r)" % (world, got, want))
-                verified = ("two 64-bit checksums over the counters every rank owns after the reduce-scatter, added over the %d ranks == the same "
+                if want is not None:
+                    verified = ("two 64-bit checksums over the counters every rank owns after the reduce-scatter, added over the %d ranks == the same "
                             "checksums of the table the atomic kernel builds on rank 0 from ALL ranks' reads (%d distinct canonical k-mers)"
                             % (world, whole_distinct))
     if rank == 0:
