@@ -329,6 +329,11 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				if (i + 1u < n) {
 					const uint64_t b2 = L.stage[src + i + 1u];
 					const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
+#if defined(DBGK_NT_COPYOUT)
+					if ((DBGK_NT_COPYOUT & 1) && bucket_is_b1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8 *>(o + i));
+					else if ((DBGK_NT_COPYOUT & 2) && !bucket_is_b1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8 *>(o + i));
+					else
+#endif
 					*reinterpret_cast<u32x4_a8 *>(o + i) = v;
 				} else {
 					o[i] = a;
