@@ -1258,15 +1258,21 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			uint32_t idx[kBatch];
 			unsigned long long got[kBatch];
 			bool probing[kBatch];
-			// first probe of all four records: the claims are in flight together
+			// first probe of all four records: the claims are in flight together.  A wave whose 64 lanes hold no record u at all --
+			// the tail of a region's last batch; most of the batch when a flush of a streaming build brings only a couple of
+			// thousand records per region -- skips that claim and that add: an LDS atomic costs the same with 0 lanes as with 64
+			bool wave_has[kBatch];
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) wave_has[u] = __builtin_amdgcn_ballot_w64(recs[u] != ~0ull) != 0ull;
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
 				idx[u] = (uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u);
+				got[u] = 0ull;
 				// (a lane without a record compares against all-ones, which no slot ever holds: a plain read)
 #if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 3
 				got[u] = (recs[u] >> 6) + 1ull; // timing experiment: no claims (results are wrong)
 #else
-				got[u] = atomicCAS(&L.ident[idx[u]], recs[u] != ~0ull ? 0ull : ~0ull, (recs[u] >> 6) + 1ull);
+				if (wave_has[u]) got[u] = atomicCAS(&L.ident[idx[u]], recs[u] != ~0ull ? 0ull : ~0ull, (recs[u] >> 6) + 1ull);
 #endif
 			}
 			bool any = false;
@@ -1320,7 +1326,8 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 #if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 2
 				got[u] = dl + dr; // timing experiment: no adds (results are wrong)
 #else
-				got[u] = atomicAdd(&L.links[idx[u]], ((unsigned long long)dr << 32) | dl);
+				got[u] = 0ull;
+				if (wave_has[u]) got[u] = atomicAdd(&L.links[idx[u]], ((unsigned long long)dr << 32) | dl);
 #endif
 			}
 #pragma unroll
