@@ -1249,8 +1249,10 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	U.n_lanes = n_reads * Q;
 	U.lq = 0;
 	U.tile_blocks = 0; // 0: no regular tiles
+	// (the regular form also assumes k >= 17 -- the rolls then only touch the high words --, reads that fill their lanes exactly,
+	// and a graph handle: no KFREQ neighbour codes)
 	if ((Q & (Q - 1)) == 0 && Q <= (uint64_t)kL1Threads && (((uint64_t)kL1Threads / Q) * L) % 16 == 0 &&
-	    ((uint64_t)kL1Threads / Q) * L / 16 + 8 <= (uint64_t)kPkWords) {
+	    ((uint64_t)kL1Threads / Q) * L / 16 + 8 <= (uint64_t)kPkWords && k >= 17 && Q * C == (uint64_t)W && !h->kfreq) {
 		while ((1ull << U.lq) < Q) U.lq++;
 		U.tile_blocks = (uint32_t)(((uint64_t)kL1Threads / Q) * L / 16);
 	}

@@ -532,7 +532,10 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // is 0 (poly-A / poly-T): rare, the caller then feeds the key-0 side node.
 // WIDE_D: how hash / size is computed -- 0: size < 2^31 (one multiply-high with a 32-bit remainder fix-up), 1: size < 2^32
 // (two 2-by-1 division steps), 2: any size (64-bit multiply-high by floor(2^64 / size), 64-bit remainder)
-template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds>
+// SPECIAL (regular tiles of the equal-length kernel, k >= 17, every lane's NPOS windows valid): the rolls work on the 32-bit halves
+// -- with 2k > 32 the head mask only touches the high word and the entering complement base only the high word of rc -- and the
+// per-position validity test is gone.
+template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds, bool SPECIAL = false>
 __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
 {
@@ -550,12 +553,21 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
 		const uint64_t key = rev ? c.rc : c.kbit;
 		// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
-		uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
-		asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
-		const uint32_t links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
-		uint32_t rev_bit = rev ? 1u : 0u;
-		asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
-		rev_mask = (rev_mask << 1) | rev_bit;  // position i ends up at bit NPOS - 1 - i
+		uint32_t links;
+		if constexpr (SPECIAL) { // the packed words are selected, the two codes extracted once
+			uint32_t wa = rev ? nbc : c.lw, wb = rev ? lwc : c.nb;
+			asm volatile("" : "+v"(wa), "+v"(wb)); // two selects, not a branch
+			links = (((wa >> sh) & 3u) << 3) | ((wb >> sh) & 3u); // (never a KFREQ handle: the host keeps those on the general form)
+		} else {
+			uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
+			asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
+			links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
+		}
+		if (!SPECIAL || i == 0u || i == (uint32_t)NPOS - 1u) { // (SPECIAL: only a read's first and last window are ever patched below)
+			uint32_t rev_bit = rev ? 1u : 0u;
+			asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
+			rev_mask = SPECIAL ? (rev_mask | (rev_bit << ((uint32_t)NPOS - 1u - i))) : ((rev_mask << 1) | rev_bit);  // position i ends up at bit NPOS - 1 - i
+		}
 		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 		uint64_t q;
 		uint32_t slot, bucket; // slot: its low 32 bits (r <= 24 of them are recorded); bucket = slot >> r
@@ -572,18 +584,26 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
 		const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
 		L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
-		const bool valid = (c.valid >> i) & 1u;
+		const bool valid = SPECIAL ? true : (bool)((c.valid >> i) & 1u);
 		const bool zero = key == 0ull;
 		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
 		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kL1MaxB + (tid & 63u);
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 		// roll to the next position (DBGgraph.cpp:71-73)
-		c.kbit = ((c.kbit << 2) | right) & head_mask;
-		c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
+		if constexpr (SPECIAL) {
+			const uint32_t klo = (uint32_t)c.kbit, khi = (uint32_t)(c.kbit >> 32);
+			const uint32_t nhi = __builtin_amdgcn_alignbit(khi, klo, 30u) & (uint32_t)(head_mask >> 32), nlo = (klo << 2) | right;
+			c.kbit = ((uint64_t)nhi << 32) | nlo;
+			const uint64_t r2 = c.rc >> 2;
+			c.rc = ((uint64_t)((uint32_t)(r2 >> 32) | ((right ^ 3u) << (rc_shift - 32u))) << 32) | (uint32_t)r2;
+		} else {
+			c.kbit = ((c.kbit << 2) | right) & head_mask;
+			c.rc = (c.rc >> 2) | ((uint64_t)(3u - right) << rc_shift);
+		}
 	}
 	// windows without a left / right neighbour: that side's code becomes 4 = none
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
-	for (uint32_t fix = G.kf ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
+	for (uint32_t fix = (!SPECIAL && G.kf) ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
 		const uint32_t i = (uint32_t)__builtin_ctz(fix);
 		const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
 		uint64_t rec = L.stage[i * kL1Threads + tid];
@@ -985,7 +1005,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
 			c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
 		}
-		const bool zero_seen = l1_positions<WIDE_D, C, SLds>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile
 		r0 += stride_r;
