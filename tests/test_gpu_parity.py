@@ -834,3 +834,53 @@ def test_push_reads_from_page_locked_memory_skips_the_staging_copy(capi, oracle)
             st = g.finalize()
             assert (int(st.count), int(st.total_kmers)) == (ref.count, ref.total_kmers)
             assert np.array_equal(g.export_sorted(), ref.nodes)
+
+
+@pytest.mark.parametrize("k,L", [(31, 150), (23, 150), (31, 94), (17, 136), (32, 151)])
+def test_equal_length_reads_in_regular_tiles_equal_oracle(capi, oracle, k, L):
+    """The regular-tile form of the equal-length level-1 kernel (every tile = 1024 / Q whole reads from a 16-byte boundary,
+    Q a power of two, reads that fill their lanes exactly, k >= 17: rolls on 32-bit halves, no per-position validity test)
+    on the inputs its short cuts could get wrong: poly-A / poly-T reads and long A / T runs inside reads (key 0 is kept
+    aside), a read's first and last window (no left / right neighbour), lower case and N, both strands; 5 whole tiles
+    and a remainder that takes the general form.  (k, L) cover 15 and 16 windows per lane, 4 / 8 lanes per read, k = 17
+    (the entering complement base lands on bit 0 of the high word) and k = 32 (mask of all ones)."""
+    rng = random.Random(31000 + 100 * k + L)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    genome = "".join(rng.choice("ACGT") for _ in range(6000))
+    genome = genome[:2000] + "A" * (k + 5) + genome[2000:4000] + "T" * (2 * k) + genome[4000:]
+    reads = []
+    lanes_per_read = {(31, 150): 8, (23, 150): 8, (31, 94): 4, (17, 136): 8, (32, 151): 8}[(k, L)]
+    n = 5 * (1024 // lanes_per_read) + 37
+    for i in range(n):
+        x = rng.random()
+        if x < 0.03:
+            r = "A" * L
+        elif x < 0.05:
+            r = "T" * L
+        else:
+            s = rng.randint(0, len(genome) - L)
+            r = genome[s:s + L]
+            if rng.random() < 0.5:
+                r = "".join(comp[c] for c in reversed(r))
+            r = list(r)
+            for j in range(L):
+                y = rng.random()
+                if y < 0.004:
+                    r[j] = rng.choice("ACGT")
+                elif y < 0.006:
+                    r[j] = rng.choice("Nn")
+            r = "".join(r)
+            if rng.random() < 0.1:
+                r = r.lower()
+        reads.append(r.encode())
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=k, max_read_len=250, init_hash_size=0.001)
+    with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(1 << 26), max_read_len=250, engine=capi.ENGINE_PARTITION,
+                    expected_kmers=len(bases)) as g:
+        g.push_reads(bases, offsets)
+        st = g.finalize()
+        assert g.timings().uniform_launches >= 1
+        assert (int(st.count), int(st.total_kmers), int(st.total_reads)) == (ref.count, ref.total_kmers, ref.total_reads)
+        nodes = g.export_sorted()
+        assert np.array_equal(nodes, ref.nodes)
+        assert nodes[0]["kmer"] == 0 and (nodes[0]["l_link"] or nodes[0]["r_link"])   # poly-A / poly-T seen
