@@ -1311,6 +1311,8 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			// 64-bit compare-swap and CU), so the walks of a thread's four records are NOT four loops (each as long as its slowest
 			// lane) but ONE: every lane steps the first of its records that is still walking -- a fifth of the records walk at all,
 			// most lanes have none or one, and the loop ends after as many steps as the busiest lane needs in total.
+			// (One unconditional compare-swap per step instead of the read and the conditional compare-swap: no change, 4.77 against
+			// 4.83 ms alone, 9.16 / 8.85 against 9.09 / 8.83 in the pair -- profiles/r03_walk_cas_ab.txt.)
 			if (any) {
 				uint32_t pend = (probing[0] ? 1u : 0u) | (probing[1] ? 2u : 0u) | (probing[2] ? 4u : 0u) | (probing[3] ? 8u : 0u);
 				while (pend) { // ONE exit, no breaks
