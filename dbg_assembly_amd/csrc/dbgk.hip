@@ -135,6 +135,7 @@ struct dbgk_handle {
 	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
 	bool kfreq = false;
+	bool kf_blocks = false;       // KFREQ through the PARTITION engine in its direct-block form (geom.kf == 2, dbgk_partition.h)
 	uint8_t *counts = nullptr;
 	uint64_t n_counts = 0;
 	uint64_t kf_distinct = 0, kf_sum = 0;
@@ -675,7 +676,8 @@ static int wide_build_from_records(dbgk_handle *h)
 
 static int reset_state(dbgk_handle *h)
 {
-	if (h->kfreq) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
+	// (direct-block form: the build writes every block of the table, also the empty ones -- nothing to zero)
+	if (h->kfreq && !(h->part && h->kf_blocks)) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
 	if (h->wide) {
 		if (h->wpart) { // the region build overwrites every slot of the main table: zero it only if something writes it before
 			h->wzero_pending = true;
@@ -727,6 +729,43 @@ static int plan_partition(dbgk_handle *h)
 	memset(&h->store, 0, sizeof h->store);
 	memset(&h->geom, 0, sizeof h->geom);
 	h->tslots = h->size;
+	if (h->kfreq && h->kf_blocks) { // direct blocks: `size` = 4^k, slot = the key with its block index permuted (kf_slot_of_key)
+		PartGeom &G = h->geom;
+		const uint32_t bits = 2u * (uint32_t)h->cfg.kmer_size; // >= 26
+		// level-1 bucket = slot >> r: 256 buckets where the table allows (the wave-per-bucket level-1 kernel), level 2 then
+		// splits a bucket into its 2^(r - 16) <= 1024 blocks in one pass
+		const uint32_t r = std::max(20u, std::min(26u, bits - 8u));
+		G.size = h->size;
+		G.magic = h->magic;
+		if (h->size < (1ull << 32)) G.div = make_div32_magic((uint32_t)h->size);
+		G.r = r;
+		G.n1 = (uint32_t)(h->size >> r);
+		G.n2 = 1u << (r - kKfBlockBits);
+		G.n_final = (uint32_t)(h->size >> kKfBlockBits);
+		G.n_ranks = 1;
+		G.rank = 0;
+		G.B = G.n1;
+		G.n_sub = kSubStores;
+		G.b_lo = 0;
+		G.nb_own = G.n1;
+		G.slot_lo = 0;
+		G.slot_hi = h->size;
+		G.n_regions_own = G.n_final;
+		const double per_slot = (double)h->cfg.expected_kmers / (double)h->size;
+		// a level-1 bucket sums 2^(r - 16) blocks of very different weight (canonical k-mers favour small key values): more slack
+		// than the hashed form's 5 %; a single block may hold 2.2 times the average
+		G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.2 / (double)G.n_sub) + 65536 / G.n_sub + 8192;
+		G.cap2 = (uint64_t)(per_slot * (double)(1ull << kKfBlockBits) * 2.6) + 1024;
+		G.r_rec = r;
+		G.l2_shift = kKfBlockBits - (uint32_t)kRegionBits; // level 2 splits by block, not by 4096-slot region
+		G.kf = 2u;
+		G.kf_mask = (uint32_t)((1ull << (bits - kKfBlockBits)) - 1ull);
+		if (G.n1 > (uint32_t)kL1MaxB || G.n2 > (uint32_t)kMaxBuckets) return DBGK_OK; // (cannot happen for 13 <= k <= 18)
+		h->shard_rank = 0;
+		h->part = true;
+		h->three = false;
+		return DBGK_OK;
+	}
 	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
 	const int want = h->cfg.engine == DBGK_ENGINE_SEEDIDX ? DBGK_ENGINE_DIRECT // the seed index uses the plain table
 	                 : h->cfg.engine == DBGK_ENGINE_KFREQ ? DBGK_ENGINE_AUTO   // KFREQ: only if the geometry is feasible
@@ -918,6 +957,12 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_BUILD_ATTR(1, false, false, false); DBGK_BUILD_ATTR(2, false, false, false); DBGK_BUILD_ATTR(3, false, false, false);
 	DBGK_BUILD_ATTR(1, false, false, true);  DBGK_BUILD_ATTR(2, false, false, true);  DBGK_BUILD_ATTR(3, false, false, true);
 #undef DBGK_BUILD_ATTR
+	DBGK_LDS_ATTR((k_kf_build_blocks<false, true>), sizeof(KfBlockLds));
+	DBGK_LDS_ATTR((k_kf_build_blocks<true, true>), sizeof(KfBlockLds));
+	DBGK_LDS_ATTR((k_kf_build_blocks<false, false>), sizeof(KfBlockLds));
+	DBGK_LDS_ATTR((k_kf_build_blocks<true, false>), sizeof(KfBlockLds));
+	DBGK_LDS_ATTR((k_kf_build_blocks<false, false, true>), sizeof(KfBlockLds));
+	DBGK_LDS_ATTR((k_kf_build_blocks<true, false, true>), sizeof(KfBlockLds));
 	return DBGK_OK;
 }
 
@@ -960,7 +1005,13 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	// occurrence were a new key.  Without expected_kmers: direct atomics on the byte table.
 	static const bool kf_direct = getenv("DBGK_KFREQ_DIRECT") != nullptr;
 	const bool kf_part = kfreq && cfg->expected_kmers > 0 && cfg->shard_count == 0 && !kf_direct;
-	if (kf_part) {
+	// k >= 13 (a table of 2^26 bytes and more): the direct-block form -- regions ARE 64-KiB blocks of the table
+	// (dbgk_partition.h, kf_slot_of_key); smaller k (or DBGK_KFREQ_HASHED=1, measurements): the hashed form
+	static const bool kf_hashed = getenv("DBGK_KFREQ_HASHED") && atoi(getenv("DBGK_KFREQ_HASHED"));
+	h->kf_blocks = kf_part && cfg->kmer_size >= 13 && !kf_hashed;
+	if (h->kf_blocks) {
+		h->size = 1ull << (2 * cfg->kmer_size);
+	} else if (kf_part) {
 		const uint64_t want = std::max<uint64_t>(1ull << 26, cfg->expected_kmers / 2);
 		h->size = std::min<uint64_t>(want, (1ull << 32) - (1ull << 23)) | 1ull;
 	}
@@ -977,7 +1028,8 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 				h->size = 3;
 				h->magic = make_mod_magic(h->size);
 			}
-			h->geom.kf = h->part ? 1u : 0u;
+			if (!h->part) h->kf_blocks = false;
+			h->geom.kf = h->part ? (h->kf_blocks ? 2u : 1u) : 0u;
 			h->tslots = 0;
 		}
 	}
@@ -1409,7 +1461,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
-		const int wide = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
+		const int wide = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // (direct blocks: the 64-bit slot path)
 		const bool ragged = umode == 2;
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
@@ -1477,7 +1529,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu()); // 140 KiB of LDS: one workgroup per CU
 		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-		const int wide_d = h->geom.size >= (1ull << 32) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
+		const int wide_d = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
 		const int force_lin = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
 		if (!dbg_mode && (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u))) { // many level-1 buckets: the linear form
 #define DBGK_LAUNCH_FLAT_LIN(DEAD, WD)                                                                                                       \
@@ -1854,6 +1906,15 @@ static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_regi
 	static const int per_cu = getenv("DBGK_BUILD_PER_CU") ? std::max(1, atoi(getenv("DBGK_BUILD_PER_CU"))) : 2; // tuning knob
 	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * (uint32_t)per_cu); // persistent: two 66-KiB workgroups fit a CU
 	const RedoList redo = redo_list(h);
+	if (h->geom.kf == 2u) { // KFREQ, direct blocks
+#define DBGK_KFB(INCR, FAST) \
+	hipLaunchKernelGGL((k_kf_build_blocks<INCR, FAST>), dim3(grid), dim3(kBuildThreads), sizeof(KfBlockLds), stream, h->geom, h->store, h->counts, \
+	                   h->d_ctr, first_region, n_regions, cursor, redo)
+		if (build_fast()) { if (h->incr) DBGK_KFB(true, true); else DBGK_KFB(false, true); }
+		else { if (h->incr) DBGK_KFB(true, false); else DBGK_KFB(false, false); }
+#undef DBGK_KFB
+		return;
+	}
 	Node *counts = reinterpret_cast<Node *>(h->counts);
 #define DBGK_BUILD(D, KF, INCR, FAST, TABLE) \
 	hipLaunchKernelGGL((k_build_regions<D, KF, INCR, FAST>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, TABLE, h->d_ctr, \
@@ -1878,6 +1939,15 @@ static void launch_build_redo(dbgk_handle *h, hipStream_t stream)
 	const uint32_t grid = (uint32_t)h->n_cu * 2u;
 	const RedoList redo = redo_list(h);
 	unsigned int *cursor = h->region_cursor + kMaxBuildLaunches;
+	if (h->geom.kf == 2u) {
+		if (h->incr)
+			hipLaunchKernelGGL((k_kf_build_blocks<true, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(KfBlockLds), stream, h->geom, h->store,
+			                   h->counts, h->d_ctr, 0u, 0u, cursor, redo);
+		else
+			hipLaunchKernelGGL((k_kf_build_blocks<false, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(KfBlockLds), stream, h->geom, h->store,
+			                   h->counts, h->d_ctr, 0u, 0u, cursor, redo);
+		return;
+	}
 	Node *counts = reinterpret_cast<Node *>(h->counts);
 #define DBGK_REDO(KF, INCR, TABLE) \
 	hipLaunchKernelGGL((k_build_regions<0, KF, INCR, false, true>), dim3(grid), dim3(kBuildThreads), sizeof(BuildLds), stream, h->geom, h->store, TABLE, \
@@ -2008,13 +2078,14 @@ static int build_from_records(dbgk_handle *h)
 	if (rc) return rc;
 	if (build_fast()) launch_build_redo(h, h->stream); // regions with a link counter beyond 255: rebuilt exactly (before their spill nodes are merged)
 	if (h->kfreq) {
+		Counters *track = h->kf_blocks ? h->d_ctr : nullptr; // direct blocks: the table summary is kept as the table is written
 		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap, 0,
-		                   reinterpret_cast<uint32_t *>(h->counts));
+		                   reinterpret_cast<uint32_t *>(h->counts), track);
 		hipLaunchKernelGGL(k_kf_apply, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.ovf, &h->store.ovf_n[0], h->store.ovf_cap, 1,
-		                   reinterpret_cast<uint32_t *>(h->counts));
+		                   reinterpret_cast<uint32_t *>(h->counts), track);
 		hipLaunchKernelGGL(k_kf_apply_table, dim3(grid_for(h, h->store.hh_size)), dim3(kBlock), 0, h->stream, h->store.hh, h->store.hh_size,
-		                   reinterpret_cast<uint32_t *>(h->counts));
-		hipLaunchKernelGGL(k_kf_key0, dim3(1), dim3(64), 0, h->stream, h->d_ctr, h->counts);
+		                   reinterpret_cast<uint32_t *>(h->counts), track);
+		hipLaunchKernelGGL(k_kf_key0, dim3(1), dim3(64), 0, h->stream, h->d_ctr, h->counts, h->kf_blocks ? 1 : 0);
 	} else if (!h->sharded) {
 		hipLaunchKernelGGL(k_merge_spill, dim3(h->n_cu), dim3(kBlock), 0, h->stream, h->store.spill, &h->store.ovf_n[1], h->store.spill_cap,
 		                   h->tref(), h->d_ctr);
@@ -2074,7 +2145,8 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 			h->pending_kmers = 0;
 		}
 	}
-	if (h->kfreq) {
+	const bool kf_tracked = h->kfreq && h->part && h->kf_blocks; // direct blocks: the summary is kept while the table is written
+	if (h->kfreq && !kf_tracked) {
 		unsigned long long res[2];
 		rc = kfreq_summary(h, 0, h->n_counts, res);
 		if (rc) return rc;
@@ -2083,6 +2155,10 @@ extern "C" int dbgk_finalize(dbgk_handle *h, dbgk_stats *out)
 	}
 	rc = read_counters(h);
 	if (rc) return rc;
+	if (kf_tracked) {
+		h->kf_distinct = h->h_ctr->kf_nonzero;
+		h->kf_sum = h->h_ctr->kf_sum;
+	}
 	h->finalized = true;
 	if (out) fill_stats(h, out);
 	if (h->kfreq) {

@@ -38,7 +38,10 @@ struct Counters {
 	unsigned long long len_min_inv;    // ~(shortest read length) of the batch (inverted so that 0 is the neutral start value)
 	unsigned long long len_max;        // longest read length of the batch
 	unsigned long long polyA_slot;     // where the key-0 node was placed for export (or ~0)
-	unsigned long long scratch[2];
+	// KFREQ, direct blocks: the table summary kept up to date by whatever writes the table (block build, overflow / heavy-hitter
+	// application, key 0) -- wrapping sums of signed changes
+	unsigned long long kf_nonzero;     // counters that are not 0 (distinct canonical k-mers)
+	unsigned long long kf_sum;         // sum of all counters (saturated values)
 };
 
 struct TableRef {
@@ -429,7 +432,8 @@ __global__ __launch_bounds__(kBlock) void k_extract_count(ReadBatch rb, uint32_t
 }
 
 // saturating add into byte v of the count table (32-bit CAS on its dword)
-__device__ __forceinline__ void kf_sat_add(uint32_t *__restrict__ count_words, uint64_t v, uint32_t add)
+// (ctr != null: the table summary in *ctr follows the change)
+__device__ __forceinline__ void kf_sat_add(uint32_t *__restrict__ count_words, uint64_t v, uint32_t add, Counters *ctr = nullptr)
 {
 	uint32_t *word = count_words + (v >> 2);
 	const uint32_t sh = (uint32_t)(v & 3u) * 8u;
@@ -439,7 +443,13 @@ __device__ __forceinline__ void kf_sat_add(uint32_t *__restrict__ count_words, u
 		const uint32_t nxt = cur + add > 255u ? 255u : cur + add;
 		if (nxt == cur) break;
 		const uint32_t prev = atomicCAS(word, old, (old & ~(0xFFu << sh)) | (nxt << sh));
-		if (prev == old) break;
+		if (prev == old) {
+			if (ctr) {
+				if (cur == 0u) atomicAdd(&ctr->kf_nonzero, 1ull);
+				atomicAdd(&ctr->kf_sum, (unsigned long long)(nxt - cur));
+			}
+			break;
+		}
 		old = prev;
 	}
 }
@@ -448,27 +458,34 @@ __device__ __forceinline__ void kf_sat_add(uint32_t *__restrict__ count_words, u
 // links}, the count is the A counter of l_link) and bucket-overflow observations (is_triple = 1: one
 // occurrence each) are added to the byte table after all regions have been emitted
 __global__ __launch_bounds__(kBlock) void k_kf_apply(const Node *__restrict__ in, const unsigned long long *__restrict__ n_ptr, uint64_t cap,
-                                                     int is_triple, uint32_t *__restrict__ count_words)
+                                                     int is_triple, uint32_t *__restrict__ count_words, Counters *ctr)
 {
 	const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
 	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
 	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-		kf_sat_add(count_words, in[i].kmer, is_triple ? 1u : ((uint32_t)in[i].links >> 24));
+		kf_sat_add(count_words, in[i].kmer, is_triple ? 1u : ((uint32_t)in[i].links >> 24), ctr);
 }
 
 // the same for the side table that aggregates the surplus of heavy hitters (empty slots are skipped)
-__global__ __launch_bounds__(kBlock) void k_kf_apply_table(const Node *__restrict__ in, uint64_t n, uint32_t *__restrict__ count_words)
+__global__ __launch_bounds__(kBlock) void k_kf_apply_table(const Node *__restrict__ in, uint64_t n, uint32_t *__restrict__ count_words, Counters *ctr)
 {
 	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
 	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-		if (in[i].kmer != 0ull) kf_sat_add(count_words, in[i].kmer, (uint32_t)in[i].links >> 24);
+		if (in[i].kmer != 0ull) kf_sat_add(count_words, in[i].kmer, (uint32_t)in[i].links >> 24, ctr);
 }
 
 // key 0 (poly-A / poly-T) never enters the record stream: its occurrences are counted in the A counter
 // of the side word
-__global__ void k_kf_key0(const Counters *__restrict__ ctr, uint8_t *__restrict__ counts)
+__global__ void k_kf_key0(Counters *__restrict__ ctr, uint8_t *__restrict__ counts, int track)
 {
-	if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = (uint8_t)((uint32_t)ctr->polyA_links >> 24);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		const uint32_t c = (uint32_t)ctr->polyA_links >> 24, was = counts[0];
+		counts[0] = (uint8_t)c;
+		if (track) { // (the side word holds the count of the whole job so far: the byte is replaced, not added to)
+			ctr->kf_nonzero += (unsigned long long)(c != 0u) - (unsigned long long)(was != 0u);
+			ctr->kf_sum += (unsigned long long)c - (unsigned long long)was;
+		}
+	}
 }
 
 // bit table of the 1-bit format: bit (128 >> (v % 8)) of byte v / 8 is set when counts[v] > cutoff

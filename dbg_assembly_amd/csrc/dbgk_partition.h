@@ -99,8 +99,34 @@ struct PartGeom {
 	uint32_t l2_shift;   // level-2 passes: bucket of a record = (record >> (6 + 12 + l2_shift)) & (n2 - 1); 0 except in the MID
 	                     // pass of a three-level partition (tables of 2^33 slots and more, see launch_l2 in dbgk.hip)
 	uint32_t kf;         // KFREQ through this engine: a record is one occurrence of the key, its neighbour fields are
-	                     // fixed (lb = 0, rb = none), so the A counter of l_link is the saturating occurrence count
+	                     // fixed (lb = 0, rb = none), so the A counter of l_link is the saturating occurrence count.
+	                     // 2: DIRECT BLOCKS -- `size` is 4^k itself and slot = kf_slot_of_key(key), see below
+	uint32_t kf_mask;    // kf == 2: 2^(2k - 16) - 1, the mask of a block index
 };
+
+// ---- KFREQ, direct blocks (kf == 2) --------------------------------------------------------------------------------
+// The frequency table is direct-addressed -- counts[key] -- so a "region" can be a BLOCK OF THE TABLE ITSELF: 2^16 consecutive
+// key values = 64 KiB of byte counters, held in LDS as they are (no hash table, no identities, no probing: one LDS add per
+// occurrence) and written back as one contiguous 64 KiB run (no random byte stores, no zeroing of the 4^k bytes beforehand,
+// no hash to invert).  Canonical k-mers are not uniform over the key space (min(x, rc(x)) starts with A 1.75 times as often as
+// the average and with T a quarter as often), so the block index is PERMUTED -- multiplied by an odd constant modulo the
+// number of blocks -- before it becomes the slot's high bits: heavy and light blocks then spread evenly over the level-1 and
+// level-2 buckets (1024 blocks per level-1 bucket at k = 17), and only a block's own record count varies (cap2 allows 2.6x).
+constexpr uint32_t kKfBlockBits = 16;
+constexpr uint32_t kKfPermMul = 0x9E3779B1u;                                   // odd
+constexpr uint32_t kKfPermInv = (uint32_t)mod_inverse_u64((uint64_t)kKfPermMul); // inverse modulo 2^32, hence modulo every 2^n <= 2^32
+
+__host__ __device__ __forceinline__ uint64_t kf_slot_of_key(uint64_t key, uint32_t block_mask)
+{
+	const uint32_t pb = ((uint32_t)(key >> kKfBlockBits) * kKfPermMul) & block_mask;
+	return ((uint64_t)pb << kKfBlockBits) | (key & ((1ull << kKfBlockBits) - 1ull));
+}
+
+__host__ __device__ __forceinline__ uint64_t kf_key_of_slot(uint64_t slot, uint32_t block_mask)
+{
+	const uint32_t b = ((uint32_t)(slot >> kKfBlockBits) * kKfPermInv) & block_mask;
+	return ((uint64_t)b << kKfBlockBits) | (slot & ((1ull << kKfBlockBits) - 1ull));
+}
 
 struct PartStore {
 	uint64_t *l1;                 // [n_ranks * B][n_sub][cap1]: what this rank extracted, by GLOBAL level-1 bucket and sub-store
@@ -128,6 +154,7 @@ __device__ __forceinline__ uint64_t record_key(uint64_t rec, uint32_t b1, const 
 {
 	const uint64_t v = rec >> 6;
 	const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
+	if (G.kf == 2u) return kf_key_of_slot(slot, G.kf_mask);
 	return hash_code_inverse((v >> G.r_rec) * G.size + slot);
 }
 
@@ -572,7 +599,13 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		uint64_t q;
 		uint32_t slot, bucket; // slot: its low 32 bits (r <= 24 of them are recorded); bucket = slot >> r
 		if (WIDE_D == 2) {
-			const uint64_t s64 = fast_divmod(hash_code(key), G.magic, q);
+			uint64_t s64;
+			if (G.kf == 2u) { // KFREQ, direct blocks: the slot IS the key, its block index permuted (wave-uniform branch)
+				s64 = kf_slot_of_key(key, G.kf_mask);
+				q = 0ull;
+			} else {
+				s64 = fast_divmod(hash_code(key), G.magic, q);
+			}
 			slot = (uint32_t)s64;
 			bucket = (uint32_t)(s64 >> G.r);
 		} else {
@@ -1489,6 +1522,129 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	if (t == 0) {
 		if (a) atomicAdd(&ctr->n_new, a);
 		if (b) atomicAdd(&ctr->n_conflict, b);
+	}
+}
+
+// ---- KFREQ, direct blocks: one workgroup per 64-KiB block of the count table ------------------------------------------
+// (see kf_slot_of_key).  Final bucket f = permuted block index; its records carry the key's low 16 bits, the block's place in
+// the table is kf_key_of_slot(f << 16).  FAST: one plain LDS add per occurrence on the 32-bit word that holds the byte; the
+// returned word tells whether that byte already held 255 -- then the add has carried into its neighbour, the block is flagged,
+// writes NOTHING and is rebuilt by the exact form (compare-swap loop that stops at 255, FROM_LIST) after all fast launches,
+// like a region of the graph build.  INCR: the table already holds counts (an earlier flush): the block is loaded first.
+// Every block of the launch's range is written, also those without a record: nothing zeroes the table beforehand.
+struct KfBlockLds {
+	uint32_t w[1u << (kKfBlockBits - 2u)];
+	uint32_t next_region;
+	uint32_t redo;
+};
+
+template <bool INCR, bool FAST, bool FROM_LIST = false>
+__global__ __launch_bounds__(kBuildThreads) void k_kf_build_blocks(PartGeom G, PartStore P, uint8_t *__restrict__ counts, Counters *__restrict__ ctr,
+                                                                   uint32_t first_region, uint32_t n_regions, unsigned int *__restrict__ cursor,
+                                                                   RedoList redo)
+{
+	static_assert(!(FAST && FROM_LIST), "the exact pass is what the list is for");
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	KfBlockLds &L = *reinterpret_cast<KfBlockLds *>(lds_raw);
+	const uint32_t t = fresh_tid();
+	constexpr uint32_t kNone = 0xFFFFFFFFu;
+	constexpr uint32_t kVec = (1u << kKfBlockBits) / 16u; // 16-byte vectors of a block
+	constexpr int kBatch = 4;
+	auto grab = [&]() { // one block index per workgroup, broadcast through LDS
+		if (t == 0) {
+			const unsigned int k = atomicAdd(cursor, 1u);
+			if (FROM_LIST) {
+				const unsigned int n_list = *redo.n < redo.cap ? *redo.n : redo.cap; // complete: every fast launch has finished
+				L.next_region = k < n_list ? redo.list[k] : kNone;
+			} else {
+				L.next_region = k < n_regions ? first_region + k : kNone;
+			}
+		}
+	};
+	grab();
+	lds_barrier();
+	uint32_t f = __builtin_amdgcn_readfirstlane(L.next_region);
+	uint4 *lw = reinterpret_cast<uint4 *>(L.w);
+	// the table summary (non-zero counters, their sum) follows what is written: + what a block holds when it is emitted,
+	// - what it held when it was loaded (INCR); committed once per wave at the end
+	auto nz4 = [](const uint4 &v) {
+		auto nz = [](uint32_t w) { return (uint32_t)__builtin_popcount((((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u); };
+		return nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+	};
+	auto sum4 = [](const uint4 &v) {
+		return __builtin_amdgcn_sad_u8(v.w, 0u, __builtin_amdgcn_sad_u8(v.z, 0u, __builtin_amdgcn_sad_u8(v.y, 0u, __builtin_amdgcn_sad_u8(v.x, 0u, 0u))));
+	};
+	unsigned long long d_nz = 0ull, d_sum = 0ull;
+	while (f != kNone) {
+		uint4 *blk = reinterpret_cast<uint4 *>(counts + kf_key_of_slot((uint64_t)f << kKfBlockBits, G.kf_mask));
+		uint32_t had_nz = 0u, had_sum = 0u;
+		for (uint32_t j = t; j < kVec; j += kBuildThreads) {
+			const uint4 v = INCR ? blk[j] : make_uint4(0u, 0u, 0u, 0u);
+			lw[j] = v;
+			if (INCR) { had_nz += nz4(v); had_sum += sum4(v); }
+		}
+		if (t == 0) L.redo = 0u;
+		lds_barrier(); // the image is there; everybody has read next_region
+		grab();        // the block after this one (visible behind the next barrier)
+		const uint32_t filled = (uint32_t)(P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2);
+		const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
+		bool ovf = false;
+		for (uint32_t base = 0; base < filled; base += (uint32_t)kBatch * kBuildThreads) {
+			uint64_t recs[kBatch];
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				const uint32_t i = base + (uint32_t)u * kBuildThreads + t;
+				recs[u] = i < filled ? __builtin_nontemporal_load(in + i) : ~0ull;
+			}
+#pragma unroll
+			for (int u = 0; u < kBatch; u++) {
+				if (recs[u] == ~0ull) continue; // (a wave without a record skips the LDS instruction altogether)
+				const uint32_t idx = (uint32_t)(recs[u] >> 6) & ((1u << kKfBlockBits) - 1u), sh = 8u * (idx & 3u);
+				if constexpr (FAST) {
+					const uint32_t old = atomicAdd(&L.w[idx >> 2], 1u << sh);
+					ovf = ovf || ((old >> sh) & 0xFFu) == 0xFFu;
+				} else {
+					uint32_t old = L.w[idx >> 2];
+					bool pending = true;
+					while (pending) {
+						const bool full = ((old >> sh) & 0xFFu) == 0xFFu;
+						uint32_t prev = old;
+						if (!full) prev = atomicCAS(&L.w[idx >> 2], old, old + (1u << sh));
+						pending = prev != old;
+						old = prev;
+					}
+				}
+			}
+		}
+		if (FAST && ovf) L.redo = 1u;
+		lds_barrier(); // all adds have landed, next_region and the flag are visible
+		const bool redo_block = FAST && __builtin_amdgcn_readfirstlane(L.redo) != 0u;
+		const uint32_t f_next = __builtin_amdgcn_readfirstlane(L.next_region);
+		if (!redo_block) {
+			uint32_t now_nz = 0u, now_sum = 0u;
+			for (uint32_t j = t; j < kVec; j += kBuildThreads) {
+				const uint4 v = lw[j];
+				blk[j] = v;
+				now_nz += nz4(v);
+				now_sum += sum4(v);
+			}
+			d_nz += (unsigned long long)now_nz - (unsigned long long)had_nz;
+			d_sum += (unsigned long long)now_sum - (unsigned long long)had_sum;
+		} else if (t == 0) {
+			const unsigned int j = atomicAdd(redo.n, 1u);
+			if (j < redo.cap) redo.list[j] = f; else atomicOr(&ctr->error, 2u);
+		}
+		lds_barrier(); // the image has been read: the next block may overwrite it
+		f = f_next;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		d_nz += __shfl_down(d_nz, off, 64);
+		d_sum += __shfl_down(d_sum, off, 64);
+	}
+	if ((t & 63u) == 0u) {
+		if (d_nz) atomicAdd(&ctr->kf_nonzero, d_nz);
+		if (d_sum) atomicAdd(&ctr->kf_sum, d_sum);
 	}
 }
 

@@ -61,11 +61,12 @@ def _reads(rng, n, G=4000, L=100):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,expected", [(9, 0), (13, 0), (13, 400000), (11, 1)])
+@pytest.mark.parametrize("k,expected", [(9, 0), (13, 0), (13, 400000), (11, 1), (12, 400000), (14, 350000), (13, 1), (14, 3000)])
 def test_kfreq_engine_counts_equal_oracle(oracle, k, expected):
-    """expected == 0: atomics on the direct-addressed byte table; expected > 0 (the input size is known):
-    occurrences partitioned by hash and aggregated per key in LDS (PARTITION engine), same table at the
-    end; expected = 1 under-sizes every bucket, so most occurrences take the overflow path"""
+    """expected == 0: atomics on the direct-addressed byte table; expected > 0 (the input size is known): occurrences go
+    through the PARTITION engine -- k >= 13: partitioned by (permuted) 64-KiB block of the table and added up in an LDS image of
+    the block; k < 13: partitioned by hash and aggregated per key in an LDS hash table -- same table at the end; expected = 1 or
+    far too small under-sizes every bucket, so most occurrences take the overflow path"""
     from dbg_assembly_amd import capi
     rng = random.Random(k)
     reads = _reads(rng, 3000)
