@@ -340,8 +340,9 @@ def cpu_baseline_kfreq(args, genome_len):
 
 
 def main_kfreq(args, result_out):
-    """--config cfg4: one step = reset (zero the 4^k counters) + extract every k-mer of the resident reads into records,
-    partition them, aggregate every region in LDS, emit counts[key] + the table summary.  N > 1: every rank counts its own
+    """--config cfg4: one step = extract every k-mer of the resident reads into records, partition them by 64-KiB block of the
+    table (two levels), add every block up in LDS and write it out (every block: nothing zeroes the 4^k counters beforehand),
+    table summary kept on the way.  N > 1: every rank counts its own
     reads into a whole table, then the tables are combined by the saturating reduce-scatter of multigpu.kfreq_reduce
      inside the timed step."""
     import torch
@@ -457,32 +458,36 @@ def main_kfreq(args, result_out):
         b_alg = 150.0 / kpr + 2.0   # bases + one counter byte read + one written
         achieved = kmers_step * b_alg / (ms_per_step * 1e-3) / 1e9
         l1_ms, l2_ms, build_ms, wall_ms = tm.insert_ms / args.steps, tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
+        # k >= 13: the build's regions are 64-KiB blocks of the table itself (k_kf_build_blocks): it reads every record and writes the
+        # whole table once, nothing zeroes or summarises the table separately
+        blocks = k >= 13 and not os.environ.get("DBGK_KFREQ_HASHED")
+        bname = "k_kf_build_blocks" if blocks else "k_build_regions(KF)"
         own = {"k_extract_scatter_uniform": kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * 16.0,
-               "k_build_regions(KF)": kmers_step * 8.0 + distinct * 1.0}
-        ms = {"k_extract_scatter_uniform": l1_ms, "k_scatter_l2": l2_ms, "k_build_regions(KF)": build_ms}
+               bname: kmers_step * 8.0 + (4.0 ** k if blocks else distinct * 1.0)}
+        ms = {"k_extract_scatter_uniform": l1_ms, "k_scatter_l2": l2_ms, bname: build_ms}
         copy_bw = None
         if world == 1:
             try:
                 copy_bw = g.copy_bandwidth(1 << 30, 10)
             except Exception as e:  # noqa: BLE001
                 print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
-        own_total = sum(own.values()) + 2.0 * 4 ** k   # + zeroing the table at reset and the summary pass over it
+        own_total = sum(own.values()) + (0.0 if blocks else 2.0 * 4 ** k)   # hashed form: + zeroing the table at reset and the summary pass over it
         out = {"metric": "M k-mers/s counted (k=%d, 150 bp)" % k, "value": kmers_step * world / (dt / args.steps) / 1e6, "unit": "M k-mers/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": CONFIGS["cfg4"]["workload"], "reads_per_gpu": n_reads, "kmers_per_gpu": kmers_step,
-                          "table_bytes": 4 ** k, "distinct_canonical_kmers": distinct if not multi else None, "engine": "kfreq (partitioned records)",
+                          "table_bytes": 4 ** k, "distinct_canonical_kmers": distinct if not multi else None, "engine": "kfreq (partitioned records, 64-KiB table blocks in LDS)",
                           "parallelism": "single GPU" if not multi else
                                          "reads sharded by record x%d, whole tables per GPU, saturating reduce-scatter of the counters" % world},
-               "roofline": {"bound": "hbm", "kernel": "whole step: reset -> " + " -> ".join(ms) + " -> table summary", "achieved": achieved,
+               "roofline": {"bound": "hbm", "kernel": "whole step: " + ("" if blocks else "reset -> ") + " -> ".join(ms) + ("" if blocks else " -> table summary"), "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
                             "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step, "traffic": None,
                             "own_bytes_per_step": own_total,
                             "own_traffic_ratio": own_total / (kmers_step * b_alg),
                             "note": "the algorithmic figure (3.12 B per k-mer: a byte counter read and written) is what a table small enough to "
-                                    "stay cached would cost; the 16 GiB table is random-access, so the path moves 8-byte records instead "
-                                    "(own_bytes_per_step, incl. zeroing and summarising the table): own_traffic_ratio times the algorithmic bytes",
+                                    "stay cached would cost; the 16 GiB table is random-access, so the path moves 8-byte records instead and "
+                                    "writes the table block by block (own_bytes_per_step): own_traffic_ratio times the algorithmic bytes",
                             "l2_build_wall_ms": wall_ms,
                             "kernels": {kn: {"ms_per_step": ms[kn], "own_bytes_per_step": own[kn],
                                              "own_GBs": own[kn] / (ms[kn] * 1e-3) / 1e9 if ms[kn] > 0 else None} for kn in ms}},
