@@ -61,7 +61,8 @@ def _reads(rng, n, G=4000, L=100):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,expected", [(9, 0), (13, 0), (13, 400000), (11, 1), (12, 400000), (14, 350000), (13, 1), (14, 3000)])
+@pytest.mark.parametrize("k,expected", [(9, 0), (13, 0), (13, 400000), (11, 1), (12, 400000), (14, 350000), (13, 1), (14, 3000),
+                                        (13, 100000), (14, 60000), (12, 100000)])   # (the last three: a store a third / a fifth of the input -- flushes, blocks loaded back)
 def test_kfreq_engine_counts_equal_oracle(oracle, k, expected):
     """expected == 0: atomics on the direct-addressed byte table; expected > 0 (the input size is known): occurrences go
     through the PARTITION engine -- k >= 13: partitioned by (permuted) 64-KiB block of the table and added up in an LDS image of
