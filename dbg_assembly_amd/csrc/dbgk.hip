@@ -755,7 +755,7 @@ static int plan_partition(dbgk_handle *h)
 		// a level-1 bucket sums 2^(r - 16) blocks of very different weight (canonical k-mers favour small key values): more slack
 		// than the hashed form's 5 %; a single block may hold 2.2 times the average
 		G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.2 / (double)G.n_sub) + 65536 / G.n_sub + 8192;
-		G.cap2 = (uint64_t)(per_slot * (double)(1ull << kKfBlockBits) * 2.6) + 1024;
+		G.cap2 = ((uint64_t)(per_slot * (double)(1ull << kKfBlockBits) * 2.6) + 1024 + 3) & ~3ull; // (16-bit records, read four at a time)
 		G.r_rec = r;
 		G.l2_shift = kKfBlockBits - (uint32_t)kRegionBits; // level 2 splits by block, not by 4096-slot region
 		G.kf = 2u;
@@ -874,7 +874,7 @@ static int setup_partition(dbgk_handle *h)
 	P.spill_cap = (uint64_t)G.n_regions_own * 8 + (1ull << 16);
 	P.outgoing_cap = 1ull << 16;
 	const size_t n_entries = (size_t)G.n_ranks * G.B * G.n_sub;
-	const size_t l1_bytes = n_entries * G.cap1 * 8, l2_bytes = (size_t)G.nb_own * G.n2 * G.cap2 * 8;
+	const size_t l1_bytes = n_entries * G.cap1 * 8, l2_bytes = (size_t)G.nb_own * G.n2 * G.cap2 * (G.kf == 2u ? 2 : 8); // (direct blocks: 16-bit records)
 	bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
 	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
 	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) == hipSuccess &&

@@ -317,7 +317,9 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				if (DBG == 3) {
 					out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + off) & 4095ull)] = rcd;
 				} else if (off < cap) {
-					out[(uint64_t)b * cap + off] = rcd;
+					// KFREQ, direct blocks: all a block's build needs of a record is the key's place in the block -- 16 bits instead of 64
+					if (G.kf == 2u) reinterpret_cast<uint16_t *>(out)[(uint64_t)b * cap + off] = (uint16_t)(rcd >> 6);
+					else out[(uint64_t)b * cap + off] = rcd;
 				} else { // the bucket is full: records beyond its capacity go to the overflow list
 					const uint32_t b1 = bucket_is_b1 ? b : b1_of_bucket0;
 					push_overflow(P, record_key(rcd, b1, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
@@ -1167,7 +1169,10 @@ __global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits + G.l2_shift)) & (G.n2 - 1u));
 		}
 		l2_load_tile(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
-		scatter_tile<16, DBG, true>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, P.l2 + (uint64_t)j * G.n2 * G.cap2, G.cap2, G.b_lo + j, false, G, P, ctr);
+		// (KFREQ, direct blocks: the final buckets hold 16-bit records -- the same index arithmetic on a quarter of the bytes)
+		uint64_t *out = G.kf == 2u ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint16_t *>(P.l2) + (uint64_t)j * G.n2 * G.cap2)
+		                           : P.l2 + (uint64_t)j * G.n2 * G.cap2;
+		scatter_tile<16, DBG, true>(L, rec, bkt, G.n2, P.cnt2 + (uint64_t)j * G.n2, out, G.cap2, G.b_lo + j, false, G, P, ctr);
 	}
 }
 
@@ -1586,20 +1591,17 @@ __global__ __launch_bounds__(kBuildThreads) void k_kf_build_blocks(PartGeom G, P
 		if (t == 0) L.redo = 0u;
 		lds_barrier(); // the image is there; everybody has read next_region
 		grab();        // the block after this one (visible behind the next barrier)
+		// level 2 left 16-bit records (the key's place in the block), cap2 of them per block (a multiple of 4): four per 8-byte load
 		const uint32_t filled = (uint32_t)(P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2);
-		const uint64_t *in = P.l2 + (uint64_t)f * G.cap2;
+		const uint64_t *in = reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint16_t *>(P.l2) + (uint64_t)f * G.cap2);
 		bool ovf = false;
 		for (uint32_t base = 0; base < filled; base += (uint32_t)kBatch * kBuildThreads) {
-			uint64_t recs[kBatch];
+			const uint32_t first = base + (uint32_t)kBatch * t; // this lane's four records
+			const uint64_t four = first < filled ? __builtin_nontemporal_load(in + (first >> 2)) : 0ull;
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
-				const uint32_t i = base + (uint32_t)u * kBuildThreads + t;
-				recs[u] = i < filled ? __builtin_nontemporal_load(in + i) : ~0ull;
-			}
-#pragma unroll
-			for (int u = 0; u < kBatch; u++) {
-				if (recs[u] == ~0ull) continue; // (a wave without a record skips the LDS instruction altogether)
-				const uint32_t idx = (uint32_t)(recs[u] >> 6) & ((1u << kKfBlockBits) - 1u), sh = 8u * (idx & 3u);
+				if (first + (uint32_t)u >= filled) continue; // (a wave without a record skips the LDS instruction altogether)
+				const uint32_t idx = (uint32_t)(four >> (16 * u)) & ((1u << kKfBlockBits) - 1u), sh = 8u * (idx & 3u);
 				if constexpr (FAST) {
 					const uint32_t old = atomicAdd(&L.w[idx >> 2], 1u << sh);
 					ovf = ovf || ((old >> sh) & 0xFFu) == 0xFFu;
