@@ -462,8 +462,8 @@ def main_kfreq(args, result_out):
         # whole table once, nothing zeroes or summarises the table separately
         blocks = k >= 13 and not os.environ.get("DBGK_KFREQ_HASHED")
         bname = "k_kf_build_blocks" if blocks else "k_build_regions(KF)"
-        own = {"k_extract_scatter_uniform": kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * 16.0,
-               bname: kmers_step * 8.0 + (4.0 ** k if blocks else distinct * 1.0)}
+        own = {"k_extract_scatter_uniform": kmers_step * (150.0 / kpr + 8.0), "k_scatter_l2": kmers_step * (10.0 if blocks else 16.0),
+               bname: kmers_step * (2.0 if blocks else 8.0) + (4.0 ** k if blocks else distinct * 1.0)}   # (blocks: level 2 leaves 16-bit records)
         ms = {"k_extract_scatter_uniform": l1_ms, "k_scatter_l2": l2_ms, bname: build_ms}
         copy_bw = None
         if world == 1:
