@@ -62,8 +62,8 @@ CONFIGS = {"cfg2": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, tab
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)   # (the first steps run before the clocks have settled: 14.9 against 14.4 ms with one warm-up step)
     ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the weak-scaling line): BASELINE configs[1] PER GPU -- 10 M x 150 bp reads, 50 Mb of genome "
                          "and 600 M table slots per GPU; cfg3: BASELINE configs[2] split over the GPUs that are there -- 25 M reads, "
