@@ -60,7 +60,7 @@ class ShardInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("total_reads", C.c_uint64), ("total_kmers", C.c_uint64), ("stored_kmers", C.c_uint64),
                 ("count", C.c_uint64), ("count_conflict", C.c_uint64), ("table_slots", C.c_uint64),
-                ("polyA_l_link", C.c_uint32), ("polyA_r_link", C.c_uint32)]
+                ("polyA_l_link", C.c_uint32), ("polyA_r_link", C.c_uint32), ("other_bytes", C.c_uint64)]
 
 
 class LinkStats(C.Structure):
@@ -95,6 +95,12 @@ SYMBOLS = [
     ("dbgk_push_acquire", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
     ("dbgk_push_commit", _i, [_vp, _u64]),
     ("dbgk_push_reads_device", _i, [_vp, _vp, _vp, _u64, _u64]),
+    ("dbgk_pack_bases", _i, [_vp, _u64, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_unpack_bases", _i, [_vp, _u64, _u64, _vp]),
+    ("dbgk_push_reads_packed", _i, [_vp, _vp, _vp, _u64, _u64]),
+    ("dbgk_push_commit_packed", _i, [_vp, _u64, _u64]),
+    ("dbgk_push_reads_packed_device", _i, [_vp, _vp, _vp, _u64, _u64]),
+    ("dbgk_pack_bases_device", _i, [_vp, _vp, _u64, _vp]),
     ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_sync", _i, [_vp]),
     ("dbgk_resize_table", _i, [_vp, _u64]),
@@ -142,6 +148,7 @@ SYMBOLS = [
     ("dbgk_comm_size", C.c_uint32, [_vp]),
     ("dbgk_comm_handle", _vp, [_vp, C.c_uint32]),
     ("dbgk_comm_push_reads", _i, [_vp, _vp, _vp, _u64]),
+    ("dbgk_comm_push_reads_packed", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_comm_flush", _i, [_vp]),
     ("dbgk_comm_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_comm_finalize", _i, [_vp, C.POINTER(Stats)]),
@@ -191,6 +198,24 @@ def lib():
 def _chk(status, what):
     if status != OK:
         raise DbgkError(status, what)
+
+
+def pack_bases(bases, out=None, first_base=0):
+    """ASCII bases -> 2-bit words (dbgk_pack_bases, host): -> (uint32 words, number of bytes outside ACGTNacgtn).  With `out`
+    the bases are packed into that buffer from base position first_base on (boundary words are OR-ed into)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    if out is None:
+        out = np.zeros((first_base + len(bases) + 15) // 16, dtype=np.uint32)
+    other = C.c_uint64(0)
+    _chk(lib().dbgk_pack_bases(bases.ctypes.data, len(bases), out.ctypes.data, first_base, C.byref(other)), "dbgk_pack_bases")
+    return out, other.value
+
+
+def unpack_bases(packed, n_bases, first_base=0):
+    packed = np.ascontiguousarray(packed, dtype=np.uint32)
+    out = np.empty(n_bases, dtype=np.uint8)
+    _chk(lib().dbgk_unpack_bases(packed.ctypes.data, first_base, n_bases, out.ctypes.data), "dbgk_unpack_bases")
+    return out
 
 
 class DeviceBuffer:
@@ -280,6 +305,47 @@ class Graph:
 
     def push_reads_device(self, d_bases, d_offsets, n_reads, n_bases):
         _chk(lib().dbgk_push_reads_device(self._h, d_bases, d_offsets, n_reads, n_bases), "dbgk_push_reads_device")
+
+    # ---- the same batches, 2 bits per base (include/dbgk.h "2-bit packed reads")
+    def push_reads_packed(self, packed, offsets, other_bytes=0):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(lib().dbgk_push_reads_packed(self._h, packed.ctypes.data, offsets.ctypes.data, len(offsets) - 1, other_bytes), "dbgk_push_reads_packed")
+
+    def push_reads_packed_ptr(self, packed_ptr, offsets_ptr, n_reads, other_bytes=0):
+        """host pointers (e.g. a pinned torch tensor's data_ptr)"""
+        _chk(lib().dbgk_push_reads_packed(self._h, packed_ptr, offsets_ptr, n_reads, other_bytes), "dbgk_push_reads_packed")
+
+    def push_reads_packed_zero_copy(self, bases, offsets):
+        """ASCII reads packed straight into the handle's pinned staging buffers (dbgk_push_acquire / dbgk_pack_bases /
+        dbgk_push_commit_packed), in pieces that fit them -- what a reader thread of the host layer does"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n, r0 = len(offsets) - 1, 0
+        while r0 < n:
+            pb, po, cb, cr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+            _chk(lib().dbgk_push_acquire(self._h, C.byref(pb), C.byref(po), C.byref(cb), C.byref(cr)), "dbgk_push_acquire")
+            base0 = int(offsets[r0])
+            r1 = int(np.searchsorted(offsets, base0 + cb.value, side="right")) - 1
+            r1 = min(max(r1, r0 + 1), r0 + cr.value, n)
+            nb = int(offsets[r1]) - base0
+            assert nb <= cb.value, "a read larger than the staging buffer"
+            C.memset(pb.value, 0, ((nb + 15) // 16) * 4)
+            other = C.c_uint64(0)
+            _chk(lib().dbgk_pack_bases(bases.ctypes.data + base0, nb, pb.value, 0, C.byref(other)), "dbgk_pack_bases")
+            rel = (offsets[r0:r1 + 1] - offsets[r0]).astype(np.uint64)
+            C.memmove(po.value, rel.ctypes.data, rel.nbytes)
+            _chk(lib().dbgk_push_commit_packed(self._h, r1 - r0, other.value), "dbgk_push_commit_packed")
+            r0 = r1
+
+    def push_reads_packed_device(self, d_packed, d_offsets, n_reads, n_bases):
+        _chk(lib().dbgk_push_reads_packed_device(self._h, d_packed, d_offsets, n_reads, n_bases), "dbgk_push_reads_packed_device")
+
+    def pack_bases_device(self, d_bases, n_bases):
+        """ASCII bases in device memory -> a DeviceBuffer of 2-bit words (dbgk_pack_bases_device)"""
+        buf = DeviceBuffer(self, ((n_bases + 15) // 16) * 4 + 64)
+        _chk(lib().dbgk_pack_bases_device(self._h, d_bases, n_bases, buf.ptr), "dbgk_pack_bases_device")
+        return buf
 
     def finalize(self):
         st = Stats()

@@ -71,6 +71,7 @@ struct StageSlot {
 	hipEvent_t done = nullptr;      // the kernels that read the device buffers have run
 	hipEvent_t copied = nullptr;    // the host-to-device copies of the batch have run (copy stream)
 	bool busy = false;
+	bool acquired = false;          // handed out by dbgk_push_acquire and not committed yet
 };
 
 } // namespace
@@ -101,6 +102,7 @@ struct dbgk_handle {
 
 	bool finalized = false;
 	uint64_t total_reads = 0;
+	uint64_t host_other_bytes = 0; // bytes outside ACGTNacgtn that a host packer met (dbgk_push_reads_packed / dbgk_push_commit_packed)
 
 	// first-seen tracking (DBGK_FLAG_TRACK_FIRST_SEEN, DIRECT engine)
 	bool track = false;
@@ -131,6 +133,8 @@ struct dbgk_handle {
 	unsigned long long *w_side_n = nullptr;
 	unsigned long long wsaved_totals[2] = {0, 0}; // total_kmers, stored_kmers before a repeated pass over the input
 	uint64_t wsaved_reads = 0;
+	unsigned long long wsaved_other = 0;          // ... and Counters::other_bytes
+	uint64_t wsaved_host_other = 0;
 	uint32_t shard_rank = 0;      // shard_index of a sharded handle (any engine)
 	bool seed = false;            // SEEDIDX engine: node payload = first occurrence + uniqueness
 	// KFREQ engine: counts[4^k] instead of a node table
@@ -602,8 +606,10 @@ static int wide_end_pass(dbgk_handle *h)
 	}
 	if (h->wgeom.pass > 0) { // the input was read again: its totals were counted in pass 0
 		HIPCHK(hipMemcpyAsync(&h->d_ctr->total_kmers, h->wsaved_totals, 16, hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(&h->d_ctr->other_bytes, &h->wsaved_other, 8, hipMemcpyHostToDevice, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		h->total_reads = h->wsaved_reads;
+		h->host_other_bytes = h->wsaved_host_other;
 	}
 	h->wpass_open = false;
 	h->wpasses_done = h->wgeom.pass + 1;
@@ -623,8 +629,10 @@ static int wide_begin_pass(dbgk_handle *h, uint32_t p)
 	HIPCHK(hipMemsetAsync(h->wstore.cnt1, 0, (size_t)G.n_l1 * 4, h->stream));
 	if (p > 0) {
 		HIPCHK(hipMemcpyAsync(h->wsaved_totals, &h->d_ctr->total_kmers, 16, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(&h->wsaved_other, &h->d_ctr->other_bytes, 8, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		h->wsaved_reads = h->total_reads;
+		h->wsaved_host_other = h->host_other_bytes;
 	}
 	h->wpass_open = true;
 	h->wplanned = false;
@@ -715,6 +723,7 @@ static int reset_state(dbgk_handle *h)
 	HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
 	h->finalized = false;
 	h->total_reads = 0;
+	h->host_other_bytes = 0;
 	return DBGK_OK;
 }
 
@@ -1357,9 +1366,11 @@ static int wide_uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
                         int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */,
-                        uint64_t len_max = 0 /* longest read of the batch (with uniform_len >= 0) */)
+                        uint64_t len_max = 0 /* longest read of the batch (with uniform_len >= 0) */,
+                        const uint32_t *d_packed = nullptr /* the batch as 2-bit codes instead of d_bases (then null) */)
 {
 	if (n_reads == 0) return DBGK_OK;
+	if (h->seed && d_packed) return DBGK_ERR_ARG; // the seed index cuts its windows at 'N', which two bits cannot say
 	if (h->seed) has_long = 1; // the dead bitmap carries the 'N' positions
 	const uint64_t words = bitmap_words(n_bases);
 	TimedSpan sp;
@@ -1420,7 +1431,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	h->total_reads += n_reads;
 	if (n_bases == 0) return DBGK_OK;
 
-	ReadBatch rb{d_bases, n_bases, d_start, has_long ? d_dead : nullptr, h->cfg.kmer_size};
+	ReadBatch rb{d_bases, n_bases, d_start, has_long ? d_dead : nullptr, h->cfg.kmer_size, d_packed, &h->d_ctr->other_seen};
 	const uint64_t n_chunks = (n_bases + 15) >> 4;
 	rc = span_begin(h, PH_INSERT, sp);
 	if (rc) return rc;
@@ -1489,14 +1500,18 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 				ReadBatch rr = rb;
 				rr.n_bases = full_tiles * reads_per_tile * U.L;
 				const int grid_r = (int)std::min<uint64_t>(full_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu());
-#define DBGK_LAUNCH_REG(WIDE, CC)                                                                                                                  \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds), h->stream, rr, \
+#define DBGK_LAUNCH_REG(WIDE, CC, PK)                                                                                                                  \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true, PK>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds), h->stream, rr, \
 	                   UR, d_offsets, h->geom, h->store, h->d_ctr)
-				if (c15) { if (wide == 2) DBGK_LAUNCH_REG(2, 15); else if (wide == 1) DBGK_LAUNCH_REG(1, 15); else DBGK_LAUNCH_REG(0, 15); }
-				else { if (wide == 2) DBGK_LAUNCH_REG(2, 16); else if (wide == 1) DBGK_LAUNCH_REG(1, 16); else DBGK_LAUNCH_REG(0, 16); }
+				if (d_packed) {
+					if (c15) { if (wide == 2) DBGK_LAUNCH_REG(2, 15, true); else if (wide == 1) DBGK_LAUNCH_REG(1, 15, true); else DBGK_LAUNCH_REG(0, 15, true); }
+					else { if (wide == 2) DBGK_LAUNCH_REG(2, 16, true); else if (wide == 1) DBGK_LAUNCH_REG(1, 16, true); else DBGK_LAUNCH_REG(0, 16, true); }
+				} else if (c15) { if (wide == 2) DBGK_LAUNCH_REG(2, 15, false); else if (wide == 1) DBGK_LAUNCH_REG(1, 15, false); else DBGK_LAUNCH_REG(0, 15, false); }
+				else { if (wide == 2) DBGK_LAUNCH_REG(2, 16, false); else if (wide == 1) DBGK_LAUNCH_REG(1, 16, false); else DBGK_LAUNCH_REG(0, 16, false); }
 #undef DBGK_LAUNCH_REG
 				const uint64_t done_reads = full_tiles * reads_per_tile;
-				rb.bases += done_reads * U.L;
+				if (d_packed) rb.packed += done_reads * U.L / 16; // (a whole number of words: a tile is a multiple of 16 bases)
+				else rb.bases += done_reads * U.L;
 				rb.n_bases -= done_reads * U.L;
 				U.n_lanes = (n_reads - done_reads) * U.Q;
 				rest_only = U.n_lanes == 0;
@@ -1574,6 +1589,9 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		hipLaunchKernelGGL((k_extract_insert<false, false>), dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, h->tref(), h->d_ctr,
 		                   (unsigned long long *)nullptr, (uint64_t)0);
 	}
+	// bytes outside ACGTNacgtn were read as 'A'; if a kernel met one (Counters::other_seen) this batch's are counted now --
+	// every workgroup of the launch leaves at once otherwise.  A packed batch has none: its packer counted them.
+	if (!d_packed) hipLaunchKernelGGL(k_count_other_bytes, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, d_bases, n_bases, h->d_ctr);
 	HIPCHK(hipGetLastError());
 	return span_end(h, sp);
 }
@@ -1667,6 +1685,7 @@ extern "C" int dbgk_push_acquire(dbgk_handle *h, char **bases, uint64_t **offset
 		HIPCHK(hipEventSynchronize(s.done));
 		s.busy = false;
 	}
+	s.acquired = true;
 	*bases = s.h_bases;
 	*offsets = s.h_offsets;
 	if (cap_bases) *cap_bases = h->cap_bases;
@@ -1674,17 +1693,19 @@ extern "C" int dbgk_push_acquire(dbgk_handle *h, char **bases, uint64_t **offset
 	return DBGK_OK;
 }
 
-extern "C" int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads)
+static int push_commit_impl(dbgk_handle *h, uint64_t n_reads, bool packed)
 {
 	if (!h) return DBGK_ERR_ARG;
 	if (h->finalized) return DBGK_ERR_STATE;
+	if (packed && h->seed) return DBGK_ERR_ARG;
 	if (n_reads == 0) return DBGK_OK;
 	if (n_reads > h->cap_reads) return DBGK_ERR_ARG;
 	if (h->seed && h->total_reads + n_reads > 0xFFFFFFFFull) return DBGK_ERR_ARG;
 	int rc = use_device(h);
 	if (rc) return rc;
 	StageSlot &s = h->slots[h->next_slot];
-	if (!s.h_offsets || s.busy) return DBGK_ERR_STATE; // dbgk_push_acquire first
+	if (!s.h_offsets || s.busy || !s.acquired) return DBGK_ERR_STATE; // dbgk_push_acquire first, one commit per acquire
+	s.acquired = false;
 	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
 	if (s.h_offsets[0] != 0) return DBGK_ERR_ARG;
 	uint64_t batch_windows = 0, len_max = 0;
@@ -1705,15 +1726,25 @@ extern "C" int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads)
 		rc = flush_records(h);
 		if (rc) return rc;
 	}
-	rc = h2d_batch(h, s, s.h_bases, nb, n_reads + 1, false);
+	rc = h2d_batch(h, s, s.h_bases, packed ? ((nb + 15) >> 4) * 4 : nb, n_reads + 1, false);
 	if (rc) return rc;
-	rc = launch_batch(h, s.d_bases, s.d_offsets, n_reads, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max);
+	rc = launch_batch(h, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max,
+	                  packed ? reinterpret_cast<const uint32_t *>(s.d_bases) : nullptr);
 	if (rc) return rc;
 	h->pending_kmers += batch_windows;
 	HIPCHK(hipEventRecord(s.done, h->stream));
 	s.busy = true;
 	h->next_slot ^= 1;
 	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads) { return push_commit_impl(h, n_reads, false); }
+
+extern "C" int dbgk_push_commit_packed(dbgk_handle *h, uint64_t n_reads, uint64_t other_bytes)
+{
+	const int rc = push_commit_impl(h, n_reads, true);
+	if (rc == DBGK_OK) h->host_other_bytes += other_bytes;
+	return rc;
 }
 
 extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, uint64_t n_reads)
@@ -1768,6 +1799,7 @@ extern "C" int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t
 			HIPCHK(hipEventSynchronize(s.done));
 			s.busy = false;
 		}
+		s.acquired = false; // (the slot is overwritten: a batch acquired before this call and not committed is gone)
 		const uint64_t nb = offsets[r1] - base0, nr = r1 - r0;
 		std::vector<std::thread> copiers;
 		struct Join { // every exit path below waits for the copy threads
@@ -1827,6 +1859,165 @@ extern "C" int dbgk_push_reads_device(dbgk_handle *h, const char *d_bases, const
 	return rc;
 }
 
+// dbgk_push_reads for a batch that is already 2 bits per base (include/dbgk.h).  Same cutting into staging batches; a batch
+// must start on a word of its own on the device, so one that starts in the middle of a source word is shifted into place while
+// it is copied into the pinned staging buffer (host threads; the copy is a quarter of the ASCII one).  A page-locked source is
+// read by the copy engine directly whenever the batch starts on a word boundary -- later batches are cut where that holds.
+extern "C" void dbgk_internal_shift_packed(const uint32_t *src, uint64_t first_base, uint64_t n_words, uint64_t src_words, uint32_t *dst);
+
+extern "C" int dbgk_push_reads_packed(dbgk_handle *h, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes)
+{
+	if (!h || !offsets || (n_reads && !packed && offsets[n_reads] != offsets[0])) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	if (h->seed) return DBGK_ERR_ARG; // windows of the seed index are cut at 'N'
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
+	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
+	const bool cut_to_room = streaming && h->store_capacity >= h->cap_bases && !h->wpart;
+	const uint64_t src_words = n_reads ? (offsets[n_reads] + 15) >> 4 : 0;
+	const bool pinned_source = n_reads && offsets[n_reads] > offsets[0] &&
+	                           device_readable_host(reinterpret_cast<const char *>(packed + (offsets[0] >> 4)), (src_words - (offsets[0] >> 4)) * 4);
+	bool source_in_flight = false;
+	struct WaitSource { // every exit path waits for the copies that still read the caller's buffer
+		dbgk_handle *h; bool &on;
+		~WaitSource() { if (on && h->source_read) (void)hipEventSynchronize(h->source_read); }
+	} wait_source{h, source_in_flight};
+	uint64_t r0 = 0;
+	while (r0 < n_reads) {
+		uint64_t r1 = r0, batch_windows = 0, len_max = 0;
+		const uint64_t base0 = offsets[r0];
+		const uint64_t room = h->store_capacity > h->pending_kmers ? h->store_capacity - h->pending_kmers : 0;
+		const uint64_t r_end = std::min<uint64_t>(n_reads, r0 + h->cap_reads);
+		const uint64_t first_len = offsets[r0 + 1] >= base0 ? offsets[r0 + 1] - base0 : 0;
+		bool uniform = true;
+		for (uint64_t prev = base0; r1 < r_end; r1++) {
+			const uint64_t next = offsets[r1 + 1];
+			if (next < prev) return DBGK_ERR_ARG;
+			if (next - base0 > h->cap_bases) break;
+			const uint64_t len = next - prev, rl = len > max_len ? max_len : len, w = rl >= K ? rl - K + 1 : 0ull;
+			if (cut_to_room && batch_windows + w > room && (r1 > r0 || h->pending_kmers > 0)) break;
+			batch_windows += w;
+			len_max = len > len_max ? len : len_max;
+			uniform = uniform && len == first_len;
+			prev = next;
+		}
+		if (r1 < n_reads && r1 > r0 + 64 && (offsets[r1] & 15u)) { // end the batch where the next one starts on a word boundary, if that is near
+			for (uint64_t back = 1; back <= 64; back++)
+				if ((offsets[r1 - back] & 15u) == 0) {
+					uint64_t w2 = 0, lm = 0; // recount what the shorter batch holds
+					bool uni = true;
+					for (uint64_t i = r0; i < r1 - back; i++) {
+						const uint64_t len = offsets[i + 1] - offsets[i], rl = len > max_len ? max_len : len;
+						w2 += rl >= K ? rl - K + 1 : 0ull;
+						lm = std::max(lm, len);
+						uni = uni && len == first_len;
+					}
+					r1 -= back; batch_windows = w2; len_max = lm; uniform = uni;
+					break;
+				}
+		}
+		if (streaming && !(h->wpart && h->wbuilt) && h->pending_kmers > 0 &&
+		    (r1 == r0 || (!cut_to_room && h->pending_kmers + batch_windows > h->store_capacity))) {
+			rc = flush_records(h);
+			if (rc) return rc;
+			if (r1 == r0) continue;
+		}
+		if (r1 == r0) return DBGK_ERR_ARG; // a single read larger than max_batch_bases
+		StageSlot &s = h->slots[h->next_slot];
+		rc = ensure_slot(h, s);
+		if (rc) return rc;
+		if (s.busy) {
+			HIPCHK(hipEventSynchronize(s.done));
+			s.busy = false;
+		}
+		s.acquired = false;
+		const uint64_t nb = offsets[r1] - base0, nr = r1 - r0, n_words = (nb + 15) >> 4;
+		const bool direct = pinned_source && (base0 & 15u) == 0;
+		std::vector<std::thread> copiers;
+		struct Join {
+			std::vector<std::thread> &w;
+			~Join() { for (auto &t : w) if (t.joinable()) t.join(); }
+		} join_copiers{copiers};
+		if (n_words && !direct) {
+			uint32_t *dst = reinterpret_cast<uint32_t *>(s.h_bases);
+			static const int want = getenv("DBGK_COPY_THREADS") ? atoi(getenv("DBGK_COPY_THREADS")) : 8;
+			const uint64_t min_piece = 1u << 20; // words
+			const uint64_t pieces = want > 1 ? std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)want, n_words / min_piece)) : 1;
+			const uint64_t per = (n_words + pieces - 1) / pieces;
+			for (uint64_t pc = 1; pc < pieces; pc++) {
+				const uint64_t lo = pc * per, hi = std::min(n_words, lo + per);
+				if (lo < hi) copiers.emplace_back([=]() { dbgk_internal_shift_packed(packed, base0 + 16 * lo, hi - lo, src_words, dst + lo); });
+			}
+			dbgk_internal_shift_packed(packed, base0, std::min(n_words, per), src_words, dst);
+		}
+		const int has_long = len_max > max_len ? 1 : 0;
+		const int64_t uniform_len = uniform ? (int64_t)first_len : 0;
+		{
+			const uint64_t *src = offsets + r0;
+			uint64_t *dst = s.h_offsets;
+			for (uint64_t i = 0; i <= nr; i++) dst[i] = src[i] - base0;
+		}
+		for (auto &t : copiers) t.join();
+		rc = h2d_batch(h, s, direct ? reinterpret_cast<const char *>(packed + (base0 >> 4)) : s.h_bases, n_words * 4, nr + 1, direct);
+		if (rc) return rc;
+		source_in_flight = source_in_flight || direct;
+		rc = launch_batch(h, nullptr, s.d_offsets, nr, nb, s.d_start, s.d_dead, has_long, uniform_len, len_max, reinterpret_cast<const uint32_t *>(s.d_bases));
+		if (rc) return rc;
+		h->pending_kmers += batch_windows;
+		HIPCHK(hipEventRecord(s.done, h->stream));
+		s.busy = true;
+		h->next_slot ^= 1;
+		r0 = r1;
+	}
+	h->host_other_bytes += other_bytes;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_reads_packed_device(dbgk_handle *h, const uint32_t *d_packed, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases)
+{
+	if (!h || !d_offsets || (n_bases && !d_packed)) return DBGK_ERR_ARG;
+	if (((uintptr_t)d_packed & 15u) || ((uintptr_t)d_offsets & 7u)) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	if (h->seed) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	const uint64_t words = bitmap_words(n_bases);
+	if (words > h->dev_bits_words) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (h->dev_start) (void)hipFree(h->dev_start);
+		if (h->dev_dead) (void)hipFree(h->dev_dead);
+		h->dev_start = h->dev_dead = nullptr;
+		h->dev_bits_words = 0;
+		if (hipMalloc(&h->dev_start, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		if (hipMalloc(&h->dev_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		h->dev_bits_words = words;
+	}
+	if (((h->part && !h->sharded) || (h->wpart && !h->wbuilt)) && h->pending_kmers > 0 && h->pending_kmers + n_bases > h->store_capacity) {
+		rc = flush_records(h);
+		if (rc) return rc;
+	}
+	rc = launch_batch(h, nullptr, d_offsets, n_reads, n_bases, h->dev_start, h->dev_dead, -1, -1, 0, d_packed);
+	if (rc == DBGK_OK) h->pending_kmers += n_bases;
+	return rc;
+}
+
+// ASCII -> 2-bit on the device (the host twin is dbgk_pack_bases): d_packed gets (n_bases + 15) / 16 words; bytes outside
+// ACGTNacgtn become 'A' and are added to the handle's stats.other_bytes
+extern "C" int dbgk_pack_bases_device(dbgk_handle *h, const char *d_bases, uint64_t n_bases, uint32_t *d_packed)
+{
+	if (!h || (n_bases && (!d_bases || !d_packed))) return DBGK_ERR_ARG;
+	if (((uintptr_t)d_bases & 15u) || ((uintptr_t)d_packed & 3u)) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n_bases == 0) return DBGK_OK;
+	const uint64_t n_chunks = (n_bases + 15) >> 4;
+	hipLaunchKernelGGL(k_pack_bases, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, d_bases, n_bases, d_packed, h->d_ctr);
+	hipLaunchKernelGGL(k_count_other_bytes, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, d_bases, n_bases, h->d_ctr);
+	HIPCHK(hipGetLastError());
+	return DBGK_OK;
+}
+
 extern "C" int dbgk_flush(dbgk_handle *h)
 {
 	if (!h) return DBGK_ERR_ARG;
@@ -1866,6 +2057,7 @@ static void fill_stats(const dbgk_handle *h, dbgk_stats *out)
 	out->table_slots = h->tslots;
 	out->polyA_l_link = (uint32_t)(c.polyA_links & 0xFFFFFFFFu);
 	out->polyA_r_link = (uint32_t)(c.polyA_links >> 32);
+	out->other_bytes = c.other_bytes + h->host_other_bytes;
 }
 
 // PARTITION engine: records -> final buckets -> table regions, then the stragglers
@@ -3003,7 +3195,7 @@ extern "C" int dbgk_extract_kmers(dbgk_handle *h, const char *bases, const uint6
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_off, n_reads, nb, h->cfg.kmer_size,
 		                   h->cfg.max_read_len, d_start, d_dead, d_ctr);
-		ReadBatch rb{d_bases, nb, d_start, d_dead, h->cfg.kmer_size};
+		ReadBatch rb{d_bases, nb, d_start, d_dead, h->cfg.kmer_size, nullptr, &d_ctr->other_seen};
 		hipLaunchKernelGGL(k_extract_store<true>, dim3(grid_for(h, (nb + 15) >> 4)), dim3(kBlock), 0, h->stream, rb, d_kmer, d_l,
 		                   d_r, d_v);
 		e = hipGetLastError();

@@ -659,14 +659,18 @@ extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
 	return DBGK_OK;
 }
 
-extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+// `packed` != null: the batch is 2 bits per base (dbgk_push_reads_packed), `bases` is unused
+static int comm_push_impl(dbgk_comm *c, const char *bases, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes)
 {
 	if (!c || !offsets) return DBGK_ERR_ARG;
 	if (c->finalized) return DBGK_ERR_STATE;
 	dbgk_handle *h = c->h[c->next_push];
+	auto push = [&](dbgk_handle *m, const uint64_t *off, uint64_t n, uint64_t other) {
+		return packed ? dbgk_push_reads_packed(m, packed, off, n, other) : dbgk_push_reads(m, bases, off, n);
+	};
 	if (c->kfreq) { // the member streams through its own record store
 		c->next_push = (c->next_push + 1) % (uint32_t)c->h.size();
-		return dbgk_push_reads(h, bases, offsets, n_reads);
+		return push(h, offsets, n_reads, other_bytes);
 	}
 	uint64_t windows = 0;
 	const uint64_t K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
@@ -698,7 +702,7 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 		std::vector<std::string> errs(n);
 		auto push_piece = [&](uint32_t i) {
 			dbgk_handle *m = c->h[(c->next_push + i) % n];
-			if (cut[i + 1] > cut[i]) rcs[i] = dbgk_push_reads(m, bases, offsets + cut[i], cut[i + 1] - cut[i]);
+			if (cut[i + 1] > cut[i]) rcs[i] = push(m, offsets + cut[i], cut[i + 1] - cut[i], i == 0 ? other_bytes : 0);
 			if (rcs[i]) errs[i] = g_last_error; // (the message is per thread)
 		};
 		std::vector<std::thread> th;
@@ -718,7 +722,19 @@ extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint6
 		if (rc) return rc;
 	}
 	c->next_push = (c->next_push + 1) % n;
-	return dbgk_push_reads(h, bases, offsets, n_reads);
+	return push(h, offsets, n_reads, other_bytes);
+}
+
+extern "C" int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+	return comm_push_impl(c, bases, nullptr, offsets, n_reads, 0);
+}
+
+extern "C" int dbgk_comm_push_reads_packed(dbgk_comm *c, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes)
+{
+	if (!packed && n_reads && offsets && offsets[n_reads] != offsets[0]) return DBGK_ERR_ARG;
+	static const uint32_t none = 0;
+	return comm_push_impl(c, nullptr, packed ? packed : &none, offsets, n_reads, other_bytes);
 }
 
 // KFREQ: the reduce-scatter of SURVEY 8(e)-4 with the exact combination rule (saturating byte add) instead of a
@@ -846,6 +862,7 @@ static void comm_sum_stats(dbgk_comm *c, dbgk_stats *out)
 		out->stored_kmers += st.stored_kmers;
 		out->count += st.count; // only shard 0 counts the key-0 node
 		out->count_conflict += st.count_conflict;
+		out->other_bytes += st.other_bytes;
 	}
 	out->table_slots = c->h[0]->size;
 	if (c->kfreq) {

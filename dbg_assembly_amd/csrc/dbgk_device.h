@@ -157,23 +157,74 @@ __host__ __device__ __forceinline__ uint64_t node_digest(uint64_t kmer, uint64_t
 }
 
 // ---- 2-bit codec ----------------------------------------------------------------------------
-// 4 ASCII bases (one little-endian dword, first base in the low byte) -> 8 bits, first base in
-// bits 7..6.  A,a,N,n -> 0; C,c -> 1; G,g -> 2; T,t -> 3 (seqKmer.cpp:9-19).  Other bytes are
-// outside the input contract and map to an unspecified base.
-__device__ __forceinline__ uint32_t pack4_ascii(uint32_t w)
+// A,a,N,n -> 0; C,c -> 1; G,g -> 2; T,t -> 3 (seqKmer.cpp:9-19).  For those ten letters the code is
+// ((c >> 1) ^ (c >> 2)) & 3.  EVERY OTHER BYTE (IUPAC codes, '-', '*', bytes >= 128; undefined behaviour in the
+// reference, whose alphabet[] maps them to 4 and then indexes KmerRCOrVal[4] out of bounds, DBGgraph.cpp:71-73)
+// IS READ AS 'A', like N, and counted (dbgk_stats.other_bytes) -- in every engine, the host packer
+// (dbgk_pack_bases), the oracle and the checkers.  The kernels get there in two steps: the formula packs, a
+// five-instruction detector says whether any of the four bytes is outside the ten letters, and only then (rare)
+// the word is repacked byte by byte.
+// 4 ASCII bases (one little-endian dword, first base in the low byte) -> 8 bits, first base in bits 7..6.
+__device__ __forceinline__ uint32_t pack4_formula(uint32_t w)
 {
-	uint32_t x = (w >> 1) & 0x03030303u;                 // A0 C1 T2 G3
-	x ^= (x >> 1) & 0x01010101u;                         // swap G/T -> A0 C1 G2 T3
-	uint32_t t = (w & 0x5F5F5F5Fu) ^ 0x4E4E4E4Eu;        // zero byte where the base is N / n
-	uint32_t nz = (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; // 0x80 where byte != 0
-	x &= (nz >> 7) * 3u;                                  // N -> 0
+	const uint32_t x = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
 	return (x * 0x40100401u) >> 24;                       // gather the four 2-bit codes MSB-first
 }
 
-// 16 ASCII bases -> one dword of 2-bit codes, base 0 in bits 31..30
-__device__ __forceinline__ uint32_t pack16_ascii(const uint4 v)
+// non-zero iff some byte of w is none of ACGTNacgtn: bits 3..1 of a letter -- A 0, C 1, T 2, G 3, N 7 -- select the
+// upper-case letter they would have to belong to (v_perm_b32 as an 8-entry byte table, 0xFF where no letter lives);
+// the byte with bit 5 cleared either is that letter or it is not one of the ten
+__device__ __forceinline__ uint32_t other4_ascii(uint32_t w)
 {
-	return (pack4_ascii(v.x) << 24) | (pack4_ascii(v.y) << 16) | (pack4_ascii(v.z) << 8) | pack4_ascii(v.w);
+	const uint32_t expect = __builtin_amdgcn_perm(0x4EFFFFFFu, 0x47544341u, (w >> 1) & 0x07070707u);
+	return (w & 0xDFDFDFDFu) ^ expect;
+}
+
+// the exact form: a byte outside the ten letters becomes 'A' (code 0)
+__device__ __forceinline__ uint32_t pack4_exact(uint32_t w)
+{
+	uint32_t out = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 4; i++) {
+		const uint32_t c = (w >> (8u * i)) & 0xFFu, u = c & 0xDFu;
+		const bool letter = u == 0x41u || u == 0x43u || u == 0x47u || u == 0x54u || u == 0x4Eu;
+		const uint32_t code = letter ? ((c >> 1) ^ (c >> 2)) & 3u : 0u;
+		out |= code << (6u - 2u * i);
+	}
+	return out;
+}
+
+// `other_seen` (Counters::other_seen, through ReadBatch) is raised when a byte outside the ten letters is met; the bytes
+// are then COUNTED by k_count_other_bytes, once per base (tiles overlap, so the extraction kernels cannot count)
+__device__ __forceinline__ uint32_t pack4_ascii(uint32_t w, unsigned int *other_seen)
+{
+	uint32_t p = pack4_formula(w);
+	if (__builtin_expect(other4_ascii(w) != 0u, 0)) {
+		p = pack4_exact(w);
+		atomicOr(other_seen, 1u);
+	}
+	return p;
+}
+
+// one ASCII base -> its code
+__device__ __forceinline__ uint32_t code_ascii(uint32_t c, unsigned int *other_seen)
+{
+	return pack4_ascii((c & 0xFFu) | 0x41414100u, other_seen) >> 6;
+}
+
+// 16 ASCII bases -> one dword of 2-bit codes, base 0 in bits 31..30
+__device__ __forceinline__ uint32_t pack16_ascii(const uint4 v, unsigned int *other_seen)
+{
+	const uint32_t bad = other4_ascii(v.x) | other4_ascii(v.y) | other4_ascii(v.z) | other4_ascii(v.w);
+	uint32_t p = (pack4_formula(v.x) << 24) | (pack4_formula(v.y) << 16) | (pack4_formula(v.z) << 8) | pack4_formula(v.w);
+	if (__builtin_expect(bad != 0u, 0)) {
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		p = 0u;
+#pragma unroll 1
+		for (uint32_t j = 0; j < 4; j++) p = (p << 8) | pack4_exact(w[j]);
+		atomicOr(other_seen, 1u);
+	}
+	return p;
 }
 
 // reverse complement of a 2-bit packed k-mer (seqKmer.cpp:89-97): complement = ~, reverse the 32

@@ -1,7 +1,9 @@
 // dbgk_kernels.h -- the HIP kernels of the k-mer graph construction path (gfx950 only).
 //
 // Data layout in HBM:
-//   bases       ASCII read bases back to back, no separators (what dbgk_push_reads* receives)
+//   bases       ASCII read bases back to back, no separators (what dbgk_push_reads* receives), OR
+//   packed      the same bases as 2-bit codes, 16 per dword, base 0 in bits 31..30 (what dbgk_push_reads_packed*
+//               receives; exactly what pack16_ascii makes of 16 ASCII bases, so every kernel consumes either form)
 //   start_bits  1 bit per base position, LSB-first in dwords: set where a read starts
 //   dead_bits   1 bit per base position: set on bases beyond maxReadLen of their read (only
 //               allocated/used when a batch contains such reads)
@@ -42,6 +44,11 @@ struct Counters {
 	// application, key 0) -- wrapping sums of signed changes
 	unsigned long long kf_nonzero;     // counters that are not 0 (distinct canonical k-mers)
 	unsigned long long kf_sum;         // sum of all counters (saturated values)
+	// input bytes that are none of ACGTNacgtn (read as 'A', dbgk_device.h): other_seen is raised by whichever extraction kernel
+	// meets one, k_count_other_bytes then counts the batch's (only then: the kernel leaves at once while the flag is clear)
+	unsigned long long other_bytes;
+	unsigned int       other_seen;
+	unsigned int       pad0;
 };
 
 struct TableRef {
@@ -51,12 +58,29 @@ struct TableRef {
 };
 
 struct ReadBatch {
-	const char *bases;
+	const char *bases;         // ASCII, or null when the batch came 2-bit packed
 	uint64_t n_bases;
 	const uint32_t *start_bits;
 	const uint32_t *dead_bits; // may be null
 	int k;
+	const uint32_t *packed;    // 2-bit codes, 16 bases per dword (base 0 in bits 31..30), (n_bases + 15) / 16 words; or null
+	unsigned int *other_seen;  // &Counters::other_seen
 };
+
+// the packed word of bases [16 * chunk, 16 * chunk + 16) of a PACKED batch; bases past the end read as 'A' like the ASCII tail
+__device__ __forceinline__ uint32_t packed_word(const ReadBatch &rb, uint64_t chunk)
+{
+	const uint64_t off = chunk * 16u;
+	if (off + 16u <= rb.n_bases) return rb.packed[chunk];
+	if (off >= rb.n_bases) return 0u;
+	return rb.packed[chunk] & ~(0xFFFFFFFFu >> (2u * (uint32_t)(rb.n_bases - off)));
+}
+// 2-bit code of base p (p < n_bases)
+__device__ __forceinline__ uint32_t base_code(const ReadBatch &rb, uint64_t p)
+{
+	if (rb.packed) return (rb.packed[p >> 4] >> (30u - 2u * (uint32_t)(p & 15u))) & 3u;
+	return code_ascii((uint32_t)(uint8_t)rb.bases[p], rb.other_seen);
+}
 
 // ---------------------------------------------------------------------------------------------
 // reductions
@@ -180,11 +204,14 @@ __global__ __launch_bounds__(kBlock) void k_mark(const uint64_t *__restrict__ of
 // ---------------------------------------------------------------------------------------------
 // window extraction for the 16 positions owned by one lane
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load_packed_chunk(const char *__restrict__ bases, uint64_t n_bases, uint64_t chunk)
+__device__ __forceinline__ uint32_t load_packed_chunk(const ReadBatch &rb, uint64_t chunk)
 {
+	if (rb.packed) return packed_word(rb, chunk); // (wave-uniform)
+	const char *__restrict__ bases = rb.bases;
+	const uint64_t n_bases = rb.n_bases;
 	const uint64_t off = chunk * 16u;
 	if (off + 16u <= n_bases) {
-		return pack16_ascii(*reinterpret_cast<const uint4 *>(bases + off));
+		return pack16_ascii(*reinterpret_cast<const uint4 *>(bases + off), rb.other_seen);
 	}
 	if (off >= n_bases) return 0u;
 	uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // tail chunk: pad with 'A'
@@ -192,7 +219,7 @@ __device__ __forceinline__ uint32_t load_packed_chunk(const char *__restrict__ b
 		const uint32_t c = (uint8_t)bases[off + i];
 		w[i >> 2] = (w[i >> 2] & ~(0xFFu << ((i & 3u) * 8u))) | (c << ((i & 3u) * 8u));
 	}
-	return pack16_ascii(make_uint4(w[0], w[1], w[2], w[3]));
+	return pack16_ascii(make_uint4(w[0], w[1], w[2], w[3]), rb.other_seen);
 }
 
 // 64 bits of a position bitmap starting at bit position p0 (p0 % 16 == 0)
@@ -217,13 +244,13 @@ __device__ __forceinline__ LaneWindow load_lane_window(const ReadBatch &rb, uint
 {
 	LaneWindow w;
 	w.p0 = chunk * 16u;
-	const uint32_t w0 = load_packed_chunk(rb.bases, rb.n_bases, chunk);
-	const uint32_t w1 = load_packed_chunk(rb.bases, rb.n_bases, chunk + 1);
-	const uint32_t w2 = load_packed_chunk(rb.bases, rb.n_bases, chunk + 2);
+	const uint32_t w0 = load_packed_chunk(rb, chunk);
+	const uint32_t w1 = load_packed_chunk(rb, chunk + 1);
+	const uint32_t w2 = load_packed_chunk(rb, chunk + 2);
 	w.hi = ((uint64_t)w0 << 32) | w1;
 	w.lo = (uint64_t)w2 << 32;
 	w.prev_code = 0;
-	if (chunk > 0) w.prev_code = pack4_ascii((uint32_t)(uint8_t)rb.bases[w.p0 - 1]) >> 6;
+	if (chunk > 0) w.prev_code = base_code(rb, w.p0 - 1);
 	w.S = load_bits64(rb.start_bits, w.p0);
 	w.D = HAS_DEAD ? load_bits64(rb.dead_bits, w.p0) : 0ull;
 	return w;
@@ -1163,6 +1190,41 @@ __global__ __launch_bounds__(kBlock) void k_synth_reads(dbgk_synth_params P, uin
 		}
 	}
 	for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r <= n_reads; r += stride) offsets[r] = r * L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bytes outside ACGTNacgtn (dbgk_device.h: read as 'A'): counted per batch, but only once an extraction kernel has met one
+// (Counters::other_seen) -- every workgroup looks at the flag first and leaves, so a clean input pays one empty launch
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t count_other4(uint32_t w)
+{
+	const uint32_t d = other4_ascii(w);
+	return (uint32_t)__builtin_popcount((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_other_bytes(const char *__restrict__ bases, uint64_t n_bases, Counters *__restrict__ ctr)
+{
+	if (*reinterpret_cast<volatile unsigned int *>(&ctr->other_seen) == 0u) return; // (kernel-uniform)
+	__shared__ unsigned long long red[kBlock / 64];
+	unsigned long long n = 0;
+	const uint64_t n_vec = n_bases >> 4, stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_vec; i += stride) {
+		const uint4 v = reinterpret_cast<const uint4 *>(bases)[i];
+		n += count_other4(v.x) + count_other4(v.y) + count_other4(v.z) + count_other4(v.w);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		for (uint64_t p = n_vec << 4; p < n_bases; p++) n += count_other4((uint32_t)(uint8_t)bases[p] | 0x41414100u);
+	const unsigned long long tot = block_sum(n, red);
+	if (threadIdx.x == 0 && tot) atomicAdd(&ctr->other_bytes, tot);
+}
+
+// ASCII -> 2-bit packed on the device (dbgk_pack_bases_device; the host twin is dbgk_pack_bases): one lane per 16 bases
+__global__ __launch_bounds__(kBlock) void k_pack_bases(const char *__restrict__ bases, uint64_t n_bases, uint32_t *__restrict__ packed,
+                                                      Counters *__restrict__ ctr)
+{
+	ReadBatch rb{bases, n_bases, nullptr, nullptr, 0, nullptr, &ctr->other_seen};
+	const uint64_t n_chunks = (n_bases + 15u) >> 4, stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < n_chunks; c += stride) packed[c] = load_packed_chunk(rb, c);
 }
 
 } // namespace dbgk

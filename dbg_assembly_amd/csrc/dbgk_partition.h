@@ -472,14 +472,24 @@ __device__ __forceinline__ RawChunk load_raw(const ReadBatch &rb, uint64_t chunk
 	r.a0 = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
 	r.halo = r.a0;
 	r.prevb = 0x41u;
-	if (GUARDED) {
+	if (rb.packed) { // a 2-bit packed batch (wave-uniform): .x holds the packed word itself, prevb the code of the base before
+		r.a0.x = r.halo.x = r.prevb = 0u;
+		if (GUARDED) {
+			if (chunk < n_chunks) r.a0.x = packed_word(rb, chunk);
+			if (lane < 2u && halo_chunk < n_chunks) r.halo.x = packed_word(rb, halo_chunk);
+		} else {
+			r.a0.x = rb.packed[chunk];
+			if (lane < 2u) r.halo.x = rb.packed[halo_chunk];
+		}
+		if (lane == 0u && chunk > 0u && (!GUARDED || chunk * 16u - 1u < rb.n_bases)) r.prevb = rb.packed[chunk - 1u] & 3u;
+	} else if (GUARDED) {
 		if (chunk < n_chunks) r.a0 = load_ascii16(rb.bases, rb.n_bases, chunk);
 		if (lane < 2u && halo_chunk < n_chunks) r.halo = load_ascii16(rb.bases, rb.n_bases, halo_chunk);
 	} else {
 		r.a0 = *reinterpret_cast<const uint4 *>(rb.bases + chunk * 16u);
 		if (lane < 2u) r.halo = *reinterpret_cast<const uint4 *>(rb.bases + halo_chunk * 16u);
 	}
-	if (lane == 0u && chunk > 0u && (!GUARDED || chunk * 16u - 1u < rb.n_bases)) r.prevb = (uint8_t)rb.bases[chunk * 16u - 1u];
+	if (!rb.packed && lane == 0u && chunk > 0u && (!GUARDED || chunk * 16u - 1u < rb.n_bases)) r.prevb = (uint8_t)rb.bases[chunk * 16u - 1u];
 	const uint64_t p0 = chunk * 16u;
 	const uint64_t wi = p0 >> 5; // the bitmaps are padded by 4 words, safe for every chunk < n_chunks
 	r.s0 = r.s1 = r.s2 = r.d0 = r.d1 = r.d2 = 0u;
@@ -509,19 +519,25 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 	const uint32_t k = (uint32_t)rb.k;
 	const uint32_t lane = fresh_tid() & 63u;
 	const uint64_t p0 = chunk * 16u;
-	const uint32_t w0 = pack16_ascii(raw.a0);
 	// only lanes 0 and 1 hold halo chunks: broadcast their raw words and pack them on the scalar unit
 	// instead of packing a dummy in all 64 lanes
 	const uint4 h0 = make_uint4(__builtin_amdgcn_readlane(raw.halo.x, 0), __builtin_amdgcn_readlane(raw.halo.y, 0),
 	                            __builtin_amdgcn_readlane(raw.halo.z, 0), __builtin_amdgcn_readlane(raw.halo.w, 0));
 	const uint4 h1 = make_uint4(__builtin_amdgcn_readlane(raw.halo.x, 1), __builtin_amdgcn_readlane(raw.halo.y, 1),
 	                            __builtin_amdgcn_readlane(raw.halo.z, 1), __builtin_amdgcn_readlane(raw.halo.w, 1));
-	const uint32_t hw0 = pack16_ascii(h0), hw1 = pack16_ascii(h1);
+	uint32_t w0, hw0, hw1, pb;
+	if (rb.packed) { // (wave-uniform) the words came packed
+		w0 = raw.a0.x; hw0 = h0.x; hw1 = h1.x;
+		pb = __builtin_amdgcn_readlane(raw.prevb, 0);
+	} else {
+		w0 = pack16_ascii(raw.a0, rb.other_seen);
+		hw0 = pack16_ascii(h0, rb.other_seen); hw1 = pack16_ascii(h1, rb.other_seen);
+		pb = code_ascii(__builtin_amdgcn_readlane(raw.prevb, 0), rb.other_seen);
+	}
 	uint32_t w1 = __shfl_down(w0, 1, 64), w2 = __shfl_down(w0, 2, 64);
 	if (lane == 63u) { w1 = hw0; w2 = hw1; }
 	if (lane == 62u) w2 = hw0;
 	uint32_t prev = __shfl_up(w0, 1, 64) & 3u; // last base of the previous lane's chunk
-	const uint32_t pb = pack4_ascii(__builtin_amdgcn_readlane(raw.prevb, 0)) >> 6;
 	if (lane == 0u) prev = pb;
 	if (chunk == 0u) prev = 0u;
 	const uint64_t S = bits64_from_words(raw.s0, raw.s1, raw.s2, (uint32_t)(p0 & 31u));
@@ -922,12 +938,15 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // REG: regular tiles (see UniformGeom) -- the per-tile address arithmetic (64-bit read offsets, divisions by Q, guarded loads)
 // collapses to a few 32-bit operations; the host launches this form over the whole tiles of a batch and the general form over
 // the reads that are left
-template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false>
+// PACKED (regular tiles only; the other forms test rb.packed at run time): the batch came 2-bit packed -- a tile is tile_blocks
+// WORDS, one or two per lane, and nothing is packed on the way into LDS
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false, bool PACKED = false>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	static_assert(!LIN || C == 8 || C == 12, "the linear form stages 8 or 12 records per thread");
 	static_assert(!REG || (!RAGGED && !LIN), "regular tiles: equal-length reads, wave-per-bucket form");
+	static_assert(!PACKED || REG, "the other forms test rb.packed at run time");
 	using ULds = typename std::conditional<LIN, UniformLdsLin<LIN ? C : 8>, UniformLds>::type;
 	using SLds = typename std::conditional<LIN, ScatterLdsLin<LIN ? C : 8>, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -949,8 +968,9 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	auto read_start = [&](uint64_t r) -> uint64_t { return RAGGED ? offsets[r] : r * U.L; };
 	// everything a lane needs of a tile, requested one tile ahead: its 16-byte blocks of the tile's byte
 	// range (block t and block t + 1024), where that range starts, and the lane's own read
+	using Block = typename std::conditional<PACKED, uint32_t, uint4>::type; // what a lane holds of a 16-base block
 	struct RawU {
-		uint4 a, b;
+		Block a, b;
 		uint64_t B0;       // first byte of the tile's range (16-aligned)
 		uint64_t p;        // flat position of the lane's first window
 		uint32_t n_blocks; // 16-byte blocks of the range
@@ -959,7 +979,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	};
 	auto fetch = [&](uint64_t tile, uint64_t rr, uint32_t c_first) {
 		RawU raw;
-		raw.a = raw.b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+		if constexpr (PACKED) raw.a = raw.b = 0u;
+		else raw.a = raw.b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
 		raw.B0 = raw.p = 0;
 		raw.n_blocks = raw.cc = raw.W = 0;
 		if (tile >= n_tiles) return raw;
@@ -967,9 +988,15 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		if constexpr (REG) { // every tile: kL1Threads / Q whole reads from a 16-byte boundary, all of them inside the buffer
 			raw.B0 = tile * ((uint64_t)U.tile_blocks * 16u);
 			raw.n_blocks = U.tile_blocks;
-			const uint4 *blocks = reinterpret_cast<const uint4 *>(rb.bases + raw.B0);
-			if (t < raw.n_blocks) raw.a = blocks[t];
-			if (t + kL1Threads < raw.n_blocks) raw.b = blocks[t + kL1Threads];
+			if constexpr (PACKED) {
+				const uint32_t *words = rb.packed + (raw.B0 >> 4);
+				if (t < raw.n_blocks) raw.a = words[t];
+				if (t + kL1Threads < raw.n_blocks) raw.b = words[t + kL1Threads];
+			} else {
+				const uint4 *blocks = reinterpret_cast<const uint4 *>(rb.bases + raw.B0);
+				if (t < raw.n_blocks) raw.a = blocks[t];
+				if (t + kL1Threads < raw.n_blocks) raw.b = blocks[t + kL1Threads];
+			}
 			raw.cc = t & (U.Q - 1u);
 			raw.p = raw.B0 + (t >> U.lq) * U.L + (uint32_t)C * raw.cc;
 			raw.W = U.W;
@@ -986,8 +1013,15 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		uint64_t end = read_start(rr + drl) + (uint32_t)C * (xl - drl * U.Q) + (uint32_t)C + k + 2u;
 		end = min(end, (rb.n_bases + 15u) & ~15ull);
 		raw.n_blocks = end > raw.B0 ? min((uint32_t)((end - raw.B0 + 15u) >> 4), (uint32_t)kPkWords) : 0u;
-		if (t < raw.n_blocks) raw.a = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t);
-		if (t + kL1Threads < raw.n_blocks) raw.b = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t + kL1Threads);
+		if constexpr (!PACKED) {
+			if (rb.packed) { // (wave-uniform) .x holds the packed word
+				if (t < raw.n_blocks) raw.a.x = packed_word(rb, (raw.B0 >> 4) + t);
+				if (t + kL1Threads < raw.n_blocks) raw.b.x = packed_word(rb, (raw.B0 >> 4) + t + kL1Threads);
+			} else {
+				if (t < raw.n_blocks) raw.a = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t);
+				if (t + kL1Threads < raw.n_blocks) raw.b = load_ascii16(rb.bases, rb.n_bases, (raw.B0 >> 4) + t + kL1Threads);
+			}
+		}
 		// this lane
 		const uint32_t x = c_first + t;
 		const uint32_t dr = (x * U.qmagic) >> 22;
@@ -1006,8 +1040,16 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t tid = fresh_tid();
 		// pack the tile's bytes (block tid, block tid + 1024) into LDS, 16 bases per word
-		if (tid < raw.n_blocks) UL.pk[tid] = pack16_ascii(raw.a);
-		if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b);
+		if constexpr (PACKED) {
+			if (tid < raw.n_blocks) UL.pk[tid] = raw.a;
+			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = raw.b;
+		} else if (rb.packed) {
+			if (tid < raw.n_blocks) UL.pk[tid] = raw.a.x;
+			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = raw.b.x;
+		} else {
+			if (tid < raw.n_blocks) UL.pk[tid] = pack16_ascii(raw.a, rb.other_seen);
+			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b, rb.other_seen);
+		}
 		uint32_t bkt[16];
 #pragma unroll
 		for (int j = 0; j < SLds::kBpt; j++) L.hist[SLds::kBpt * tid + j] = 0;

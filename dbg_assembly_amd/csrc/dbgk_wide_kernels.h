@@ -145,10 +145,10 @@ __global__ __launch_bounds__(kBlock) void k_wide_extract_insert(ReadBatch rb, WT
 	for (uint64_t chunk = (uint64_t)blockIdx.x * kBlock + threadIdx.x; chunk < n_chunks; chunk += stride) {
 		const uint64_t p0 = chunk * 16u;
 		// 80 bases from p0 (window of the last position + its right neighbour: 15 + 63 + 1), MSB first
-		uint64_t A = ((uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk) << 32) | load_packed_chunk(rb.bases, rb.n_bases, chunk + 1);
-		uint64_t B = ((uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk + 2) << 32) | load_packed_chunk(rb.bases, rb.n_bases, chunk + 3);
-		uint64_t C = (uint64_t)load_packed_chunk(rb.bases, rb.n_bases, chunk + 4) << 32;
-		uint32_t prev = chunk ? pack4_ascii((uint32_t)(uint8_t)rb.bases[p0 - 1]) >> 6 : 0u;
+		uint64_t A = ((uint64_t)load_packed_chunk(rb, chunk) << 32) | load_packed_chunk(rb, chunk + 1);
+		uint64_t B = ((uint64_t)load_packed_chunk(rb, chunk + 2) << 32) | load_packed_chunk(rb, chunk + 3);
+		uint64_t C = (uint64_t)load_packed_chunk(rb, chunk + 4) << 32;
+		uint32_t prev = chunk ? base_code(rb, p0 - 1) : 0u;
 		uint64_t S0, S1, D0 = 0, D1 = 0;
 		load_bits128(rb.start_bits, p0, rb.n_bases, S0, S1);
 		if (HAS_DEAD) load_bits128(rb.dead_bits, p0, rb.n_bases, D0, D1);

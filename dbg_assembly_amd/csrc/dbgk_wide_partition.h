@@ -172,8 +172,8 @@ __device__ __forceinline__ WChunk16 wide_decode_chunk16(const ReadBatch &rb, uin
 	const bool live = chunk < n_chunks;
 	const uint64_t p0 = chunk * 16u;
 	const uint64_t wave_chunk0 = chunk - lane;
-	const uint32_t w0 = live ? load_packed_chunk(rb.bases, rb.n_bases, chunk) : 0u;
-	const uint32_t hw = (lane < 4u) ? load_packed_chunk(rb.bases, rb.n_bases, wave_chunk0 + 64u + lane) : 0u; // (0 beyond the end)
+	const uint32_t w0 = live ? load_packed_chunk(rb, chunk) : 0u;
+	const uint32_t hw = (lane < 4u) ? load_packed_chunk(rb, wave_chunk0 + 64u + lane) : 0u; // (0 beyond the end)
 	const uint32_t h0 = __builtin_amdgcn_readlane(hw, 0), h1 = __builtin_amdgcn_readlane(hw, 1), h2 = __builtin_amdgcn_readlane(hw, 2),
 	               h3 = __builtin_amdgcn_readlane(hw, 3);
 	uint32_t w1 = __shfl_down(w0, 1, 64), w2 = __shfl_down(w0, 2, 64), w3 = __shfl_down(w0, 3, 64), w4 = __shfl_down(w0, 4, 64);
@@ -183,7 +183,7 @@ __device__ __forceinline__ WChunk16 wide_decode_chunk16(const ReadBatch &rb, uin
 	if (lane == 60u) w4 = h0;
 	uint32_t prev = __shfl_up(w0, 1, 64) & 3u; // last base of the previous lane's chunk
 	uint32_t pb = 0u;
-	if (lane == 0u && live && chunk > 0u) pb = pack4_ascii((uint32_t)(uint8_t)rb.bases[p0 - 1u]) >> 6;
+	if (lane == 0u && live && chunk > 0u) pb = base_code(rb, p0 - 1u);
 	pb = __builtin_amdgcn_readlane(pb, 0);
 	if (lane == 0u) prev = pb;
 	if (chunk == 0u) prev = 0u;
@@ -445,8 +445,13 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 	auto fetch = [&](const Range &R, uint4 &a, uint4 &b) {
 		const uint32_t t = fresh_tid();
 		a = b = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-		if (t < R.n_blocks) a = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t);
-		if (t + kWL1Threads < R.n_blocks) b = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t + kWL1Threads);
+		if (rb.packed) { // (wave-uniform) a 2-bit packed batch: .x holds the packed word
+			if (t < R.n_blocks) a.x = packed_word(rb, (R.B0 >> 4) + t);
+			if (t + kWL1Threads < R.n_blocks) b.x = packed_word(rb, (R.B0 >> 4) + t + kWL1Threads);
+		} else {
+			if (t < R.n_blocks) a = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t);
+			if (t + kWL1Threads < R.n_blocks) b = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t + kWL1Threads);
+		}
 	};
 	Range R = range_of(blockIdx.x);
 	uint4 ra, rb2;
@@ -456,10 +461,18 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 		const uint64_t lane0 = tile * kWL1Threads;
 		const uint64_t r0 = R.r0, B0 = R.B0;
 		const uint32_t c0 = R.c0, n_blocks = R.n_blocks;
-		if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? pack16_ascii(ra) : 0u; // (+ 8 words of 'A' padding: a lane reads seven words from its first)
-		if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? pack16_ascii(rb2) : 0u;
-		for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
-			pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + b)) : 0u;
+		// (+ 8 words of 'A' padding: a lane reads seven words from its first)
+		if (rb.packed) {
+			if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? ra.x : 0u;
+			if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? rb2.x : 0u;
+			for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
+				pk[b] = b < n_blocks ? packed_word(rb, (B0 >> 4) + b) : 0u;
+		} else {
+			if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? pack16_ascii(ra, rb.other_seen) : 0u;
+			if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? pack16_ascii(rb2, rb.other_seen) : 0u;
+			for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
+				pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + b), rb.other_seen) : 0u;
+		}
 		R = range_of(tile + gridDim.x);
 		fetch(R, ra, rb2); // in flight during this tile
 		L.hist[tid] = 0u;

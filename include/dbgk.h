@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DBGK_ABI_VERSION 4
+#define DBGK_ABI_VERSION 5
 
 /* status codes */
 #define DBGK_OK               0
@@ -117,6 +117,9 @@ typedef struct dbgk_stats {
 	uint64_t table_slots;
 	uint32_t polyA_l_link;     /* links of the key-0 (poly-A / poly-T) node (:153-164)             */
 	uint32_t polyA_r_link;
+	uint64_t other_bytes;      /* sequence bytes that are none of ACGTNacgtn.  The reference maps them to
+	                              4 and then reads out of bounds (seqKmer.cpp:9-19, DBGgraph.cpp:71-73);
+	                              here EVERY engine reads them as 'A', like N, and counts them (ABI 5) */
 } dbgk_stats;
 
 /* first pass of the consumer (DBG_contig/contig.cpp:107-181) computed on the device table */
@@ -162,8 +165,9 @@ int dbgk_reset(dbgk_handle *h);
 
 /* replaces one block iteration of parse_one_reads_file: thread_parseBlock + thread_updatekmers
  * (DBGgraph.cpp:38-120,126-213) for `n_reads` reads.  bases = the sequences back to back with no
- * separators (ASCII, contract ACGTNacgtn; N counts as A like seqKmer.cpp:9-19; any other byte is
- * outside the contract -- undefined behaviour in the reference, an unspecified base here), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
+ * separators (ASCII; ACGT in either case, N / n counts as A like seqKmer.cpp:9-19; any other byte -- IUPAC codes,
+ * '-', '*', bytes >= 128: undefined behaviour in the reference -- is read as A as well and counted in
+ * dbgk_stats.other_bytes), offsets[n_reads+1] = start of each read in `bases`, offsets[0] == 0.
  * HOST buffers; the call copies them through pinned double buffers and returns once the batch is
  * queued (asynchronous w.r.t. the device).  If `bases` is page-locked memory the GPU can read (hipHostMalloc,
  * hipHostRegister: detected with hipPointerGetAttributes) the sequences are copied host-to-device straight out of
@@ -177,6 +181,30 @@ int dbgk_push_reads(dbgk_handle *h, const char *bases, const uint64_t *offsets, 
  * per commit; dbgk_push_reads may be mixed in between batches.                                                        */
 int dbgk_push_acquire(dbgk_handle *h, char **bases, uint64_t **offsets, uint64_t *cap_bases, uint64_t *cap_reads);
 int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads);
+
+/* ---- 2-bit packed reads ------------------------------------------------------------------------
+ * The reference's alphabet is two bits wide by definition (alphabet[], seqKmer.cpp:9-19: A a N n -> 0, C c -> 1, G g -> 2,
+ * T t -> 3), so a reader can hand the reads over packed -- a quarter of the bytes over PCIe, and the level-1 kernels skip
+ * their ASCII decode.  FORMAT: the bases of all reads back to back (no separators, like `bases` above), 16 per 32-bit word,
+ * base i in bits 31 - 2 * (i % 16) .. 30 - 2 * (i % 16) of word i / 16 (first base in the top bits, as seq2bit packs a
+ * k-mer, seqKmer.cpp:34-41); offsets[] count BASES, offsets[0] may be any base position of `packed`.
+ * dbgk_pack_bases: the packer (host, any thread; AVX2 when the CPU has it): n_bases ASCII bytes -> bits of `packed` starting at
+ *   base position first_base.  Bytes outside ACGTNacgtn become A and are counted: *other_bytes += their number.  Words that a
+ *   call covers only partly (its first / last) are OR-ed into atomically, so several threads may pack neighbouring ranges of
+ *   one buffer -- such boundary words must be zero beforehand.  dbgk_unpack_bases is its inverse (upper-case letters).
+ * dbgk_push_reads_packed: dbgk_push_reads for such a buffer in HOST memory (page-locked memory is read by the copy engine
+ *   directly); other_bytes = what the packer counted for these reads, added to dbgk_stats.other_bytes.
+ * dbgk_push_commit_packed: commit for a batch that was written PACKED into the buffers of dbgk_push_acquire (the `bases`
+ *   buffer taken as uint32_t words, offsets[0] = 0; a batch still holds at most cap_bases bases).
+ * dbgk_push_reads_packed_device: the packed words and the offsets are in device memory (d_packed 16-byte aligned, readable
+ *   through word (n_bases + 15) / 16 - 1); dbgk_pack_bases_device makes such a buffer from ASCII bases in device memory.
+ * Every engine takes packed batches except DBGK_ENGINE_SEEDIDX, whose windows are cut at 'N' (DBGK_ERR_ARG).             */
+int dbgk_pack_bases(const char *bases, uint64_t n_bases, uint32_t *packed, uint64_t first_base, uint64_t *other_bytes);
+int dbgk_unpack_bases(const uint32_t *packed, uint64_t first_base, uint64_t n_bases, char *bases);
+int dbgk_push_reads_packed(dbgk_handle *h, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes);
+int dbgk_push_commit_packed(dbgk_handle *h, uint64_t n_reads, uint64_t other_bytes);
+int dbgk_push_reads_packed_device(dbgk_handle *h, const uint32_t *d_packed, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases);
+int dbgk_pack_bases_device(dbgk_handle *h, const char *d_bases, uint64_t n_bases, uint32_t *d_packed);
 
 /* same, for reads already resident in device memory of the handle's GPU (both pointers 16-byte
  * aligned, readable through the end of the last read).  Nothing is copied; the buffers must stay
@@ -421,6 +449,7 @@ int dbgk_comm_destroy(dbgk_comm *c);
 uint32_t dbgk_comm_size(const dbgk_comm *c);
 dbgk_handle *dbgk_comm_handle(dbgk_comm *c, uint32_t i);
 int dbgk_comm_push_reads(dbgk_comm *c, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+int dbgk_comm_push_reads_packed(dbgk_comm *c, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes);
 /* records -> table on every shard now (dbgk_flush for a communicator); a push does it when a store is full */
 int dbgk_comm_flush(dbgk_comm *c);
 /* enlarge_kmerset_parallel (kmerSet.cpp:132-189) for the table of a communicator: flushes, creates shards of a table of new_slots

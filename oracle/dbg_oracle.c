@@ -31,11 +31,27 @@ const signed char orc_alphabet[128] = {
 	4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4,
 };
 
-/* The reference indexes alphabet[] with a plain char (seqKmer.cpp:38, DBGgraph.cpp:71): bytes
- * >= 128 are undefined behaviour there.  The oracle's input contract is ACGTNacgtn only. */
+/* The reference indexes alphabet[] with a plain char (seqKmer.cpp:38, DBGgraph.cpp:71): bytes >= 128 index it out of
+ * bounds, and every byte that maps to 4 (anything but ACGTNacgtn) then indexes KmerRCOrVal[4] out of bounds (DBGgraph.cpp:73) --
+ * undefined behaviour, so there is nothing to restate.  THIS BUILD'S RULE, applied by every GPU engine, the host packer
+ * (dbgk_pack_bases) and this oracle alike: such a byte is read as 'A' (as N already is, seqKmer.cpp:15,17) and counted
+ * (orc_count_other_bytes here, dbgk_stats.other_bytes there).  For ACGTNacgtn nothing changes: the goldens made by the real
+ * reference still pin every line below. */
 static inline int code_of(char c)
 {
-	return orc_alphabet[(unsigned char)c & 127];
+	const unsigned char u = (unsigned char)c;
+	const int v = u < 128 ? orc_alphabet[u] : 4;
+	return v == 4 ? 0 : v;
+}
+
+uint64_t orc_count_other_bytes(const char *seq, uint64_t n)
+{
+	uint64_t other = 0;
+	for (uint64_t i = 0; i < n; i++) {
+		const unsigned char u = (unsigned char)seq[i];
+		other += (u >= 128 || orc_alphabet[u] == 4) ? 1u : 0u;
+	}
+	return other;
 }
 
 uint64_t orc_seq2bit(const char *seq, int n)

@@ -28,6 +28,7 @@ extern "C" {
 
 /* ---- seqKmer codec (DBG_contig/seqKmer.cpp) ---------------------------------------------- */
 extern const signed char orc_alphabet[128];                  /* seqKmer.cpp:9-19   */
+uint64_t orc_count_other_bytes(const char *seq, uint64_t n); /* bytes that are none of ACGTNacgtn: read as 'A' (this build's rule, dbg_oracle.c) */
 uint64_t orc_seq2bit(const char *seq, int n);                 /* seqKmer.cpp:34-41  */
 void     orc_bit2seq(uint64_t kbit, int k, char *out);        /* seqKmer.cpp:45-52 (out: k+1 bytes) */
 uint64_t orc_rev_com_kbit(uint64_t kbit, int k);              /* seqKmer.cpp:89-97  */

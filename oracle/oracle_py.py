@@ -68,6 +68,8 @@ def lib():
     L.orc_seq2bit.restype = u64
     L.orc_seq2bit.argtypes = [C.c_char_p, C.c_int]
     L.orc_bit2seq.argtypes = [u64, C.c_int, C.c_char_p]
+    L.orc_count_other_bytes.restype = u64
+    L.orc_count_other_bytes.argtypes = [C.c_char_p, u64]
     L.orc_rev_com_kbit.restype = u64
     L.orc_rev_com_kbit.argtypes = [u64, C.c_int]
     L.orc_pow_integer.restype = u64
@@ -124,6 +126,12 @@ def pack_reads(seqs):
     np.cumsum(lens, out=offsets[1:])
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
     return bases, offsets
+
+
+def count_other_bytes(bases):
+    """bytes that are none of ACGTNacgtn: the reference reads out of bounds on them, this build reads them as 'A' and counts them"""
+    b = np.ascontiguousarray(bases, dtype=np.uint8).tobytes()
+    return int(lib().orc_count_other_bytes(b, len(b)))
 
 
 def synth_reads(params, first, n_reads):

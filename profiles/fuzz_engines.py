@@ -18,7 +18,7 @@ from dbg_assembly_amd import capi  # noqa: E402
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
 
 
-def make_reads(rng, n, G, L, n_rate, repeat, uniform=False, nearly=False):
+def make_reads(rng, n, G, L, n_rate, repeat, uniform=False, nearly=False, other_rate=0.0):
     g = "".join(rng.choice("ACGT") for _ in range(G))
     if repeat:
         unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40)))
@@ -42,7 +42,9 @@ def make_reads(rng, n, G, L, n_rate, repeat, uniform=False, nearly=False):
                 r[j] = rng.choice("Nn")
             elif x < 0.02 + n_rate:
                 r[j] = r[j].lower()
-        out.append("".join(r).encode())
+            elif x < 0.02 + n_rate + other_rate:   # bytes outside ACGTNacgtn: every engine reads them as 'A' and counts them
+                r[j] = rng.choice("RYKMSWBDHVryswx-*.\x00\x7f\x80\xc1\xff@[`{")
+        out.append("".join(r).encode("latin-1"))
     if nearly:
         if rng.random() < 0.5:
             out += [b"A" * L] * rng.randint(1, 400) + [b"T" * rng.randint(max(1, L - 50), L)] * rng.randint(1, 50)
@@ -66,15 +68,38 @@ def pack(reads):
     return bases, offs
 
 
-def push_in_batches(g, reads, rng, may_flush=False):
+def push_in_batches(g, reads, rng, may_flush=False, entry=0):
     """may_flush: unsharded PARTITION handle -- now and then the records are flushed into the table between
-    pushes (the streaming mode: later region builds load the nodes back into LDS)"""
+    pushes (the streaming mode: later region builds load the nodes back into LDS)
+    entry: how a batch reaches the library -- 0 ASCII (dbgk_push_reads), 1 packed on the host into a buffer with a random
+    lead-in, so that batches start in the middle of a word (dbgk_push_reads_packed), 2 packed straight into the pinned staging
+    buffers (dbgk_push_acquire / dbgk_pack_bases / dbgk_push_commit_packed), 3 packed on the device (dbgk_pack_bases_device /
+    dbgk_push_reads_packed_device)"""
     cuts = sorted(rng.sample(range(len(reads)), min(len(reads), rng.randint(0, 3))))
     for a, b in zip([0] + cuts, cuts + [len(reads)]):
         if b > a:
             if os.environ.get("FUZZ_VERBOSE"):
-                print("   push reads [%d, %d) of %d, %d bases" % (a, b, len(reads), sum(len(r) for r in reads[a:b])), flush=True)
-            g.push_reads(*pack(reads[a:b]))
+                print("   push reads [%d, %d) of %d, %d bases, entry %d" % (a, b, len(reads), sum(len(r) for r in reads[a:b]), entry), flush=True)
+            bases, offs = pack(reads[a:b])
+            if entry == 1:
+                lead = rng.randint(0, 40)
+                words = np.zeros((lead + len(bases) + 15) // 16 + 1, dtype=np.uint32)
+                capi.pack_bases(np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(lead)), dtype=np.uint8), out=words)
+                _, other = capi.pack_bases(bases, out=words, first_base=lead)
+                g.push_reads_packed(words, offs + np.uint64(lead), other)
+            elif entry == 2:
+                g.push_reads_packed_zero_copy(bases, offs)
+            elif entry == 3 and len(bases):
+                d_b, d_o = capi.DeviceBuffer(g, len(bases) + 64), capi.DeviceBuffer(g, offs.nbytes)
+                d_b.from_host(bases)
+                d_o.from_host(offs)
+                d_p = g.pack_bases_device(d_b.ptr, len(bases))
+                g.push_reads_packed_device(d_p.ptr, d_o.ptr, len(offs) - 1, len(bases))
+                g.sync()
+                for d in (d_b, d_o, d_p):
+                    d.free()
+            else:
+                g.push_reads(bases, offs)
             if may_flush and rng.random() < 0.4:
                 g.flush()
 
@@ -85,13 +110,13 @@ def pick_expected(rng, actual):
     return rng.choice([max(1, actual), 3 * actual + 1, 1 if actual < 300000 else actual])
 
 
-def build_sharded(reads, k, size, n_shards, rng, max_read_len, actual):
+def build_sharded(reads, k, size, n_shards, rng, max_read_len, actual, entry=0):
     expected = pick_expected(rng, actual)  # every shard of a job is created with the SAME geometry (size, k, expected_kmers)
     graphs = [capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected,
                          shard_count=n_shards, shard_index=i, max_read_len=max_read_len) for i in range(n_shards)]
     try:
         for i, g in enumerate(graphs):
-            push_in_batches(g, reads[i::n_shards], rng)
+            push_in_batches(g, reads[i::n_shards], rng, entry=entry)
             g.sync()
         infos = [g.shard_info() for g in graphs]
         c0 = graphs[0]
@@ -147,7 +172,7 @@ def build_sharded(reads, k, size, n_shards, rng, max_read_len, actual):
                 graphs[0].add_polyA(stats[s].polyA_l_link, stats[s].polyA_r_link)
         final = [g.refresh_stats() for g in graphs]
         return (sum(int(f.count) for f in final), sum(int(s.total_kmers) for s in stats), sum(int(s.stored_kmers) for s in stats),
-                sum(g.digest() for g in graphs) % (1 << 64))
+                sum(g.digest() for g in graphs) % (1 << 64), sum(int(s.other_bytes) for s in stats))
     finally:
         for g in graphs:
             g.close()
@@ -176,24 +201,27 @@ def main():
         max_read_len = rng.choice([250, 250, 100, 1000000])
         shape = rng.random()
         reads = make_reads(rng, rng.randint(1, 6000), rng.randint(max(L, 50), 60000), L, rng.choice([0.0, 0.003, 0.05]), rng.random() < 0.3,
-                           uniform=shape < 0.35, nearly=0.35 <= shape < 0.6)
+                           uniform=shape < 0.35, nearly=0.35 <= shape < 0.6, other_rate=rng.choice([0.0, 0.0, 0.002, 0.03]))
+        entry = rng.choice([0, 1, 1, 2, 3])   # how the PARTITION side receives its batches (the DIRECT side: ASCII)
+        n_other = sum(1 for r in reads for ch in r if ch not in b"ACGTNacgtn")
         slots = rng.choice([1 << 26, 70_000_000, 100_000_007, 600_000_000, 2_200_000_000, 4_200_000_000])
         size = capi.find_next_prime_ref(slots)
         with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(3_000_000), engine=capi.ENGINE_DIRECT, max_read_len=max_read_len) as g:
             push_in_batches(g, reads, rng)
             st = g.finalize()
-            want = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
+            want = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest(), int(st.other_bytes))
+            assert want[4] == n_other, ("other bytes, DIRECT engine", want[4], n_other)
         n_shards = rng.choice([0, 0, 1, 2, 3])
         try:
           if n_shards == 0:
             with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=pick_expected(rng, want[2]),
                             max_read_len=max_read_len) as g:
-                push_in_batches(g, reads, rng, may_flush=True)
+                push_in_batches(g, reads, rng, may_flush=True, entry=entry)
                 st = g.finalize()
-                got = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest())
+                got = (int(st.count), int(st.total_kmers), int(st.stored_kmers), g.digest(), int(st.other_bytes))
           else:
             g_next.clear()
-            got = build_sharded(reads, k, size, n_shards, rng, max_read_len, want[2])
+            got = build_sharded(reads, k, size, n_shards, rng, max_read_len, want[2], entry=entry)
         except capi.DbgkError as e:
             # tandem-repeat inputs put more than 1/16 of all occurrences on a handful of keys: the documented limit
             # of the partition engine's overflow store (DBGK_ERR_CAPACITY); anything else is a failure
@@ -209,14 +237,14 @@ def main():
             # only as far as the overflow stores reach, then dbgk_finalize reports DBGK_ERR_CAPACITY)
             for expected in (0, max(1, want[2]) * rng.choice([1, 2, 50])):
                 with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=max_read_len, expected_kmers=expected) as g:
-                    push_in_batches(g, reads, rng, may_flush=expected > 0)
+                    push_in_batches(g, reads, rng, may_flush=expected > 0, entry=entry if expected else rng.choice([0, 1]))
                     st = g.finalize()
                     tabs.append((int(st.count), int(st.stored_kmers), g.kfreq_counts().tobytes()))
             if tabs[0] != tabs[1] or tabs[0][1] != want[2]:
                 ok = False
                 got = ("kfreq", tabs[0][:2], tabs[1][:2])
         bad += not ok
-        print("cfg %3d k=%2d L=%3d maxlen=%7d reads=%5d slots=%10d shards=%d  %s" % (c, k, L, max_read_len, len(reads), size, n_shards,
+        print("cfg %3d k=%2d L=%3d maxlen=%7d reads=%5d slots=%10d shards=%d entry=%d other=%d  %s" % (c, k, L, max_read_len, len(reads), size, n_shards, entry, n_other,
                                                                                     "ok" if ok else "MISMATCH %r != %r" % (got, want)), flush=True)
     print("%d configurations, %d mismatches" % (n_cfg, bad))
     if capacity_skips:

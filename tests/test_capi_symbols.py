@@ -38,7 +38,7 @@ def test_abi_version_and_errors():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Config) == 4 + 4 + 8 + 4 + 4 + 8 + 8 + 32
-    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 8
+    assert ctypes.sizeof(capi.Stats) == 6 * 8 + 8 + 8  # + other_bytes (ABI 5)
     assert ctypes.sizeof(capi.LinkStats) == 261 * 8
     assert ctypes.sizeof(capi.SynthParams) == 48
     assert capi.NODE_DTYPE.itemsize == 16

@@ -1,0 +1,257 @@
+"""The 2-bit packed read path (include/dbgk.h "2-bit packed reads") and the rule for bytes outside ACGTNacgtn.
+
+CPU part: the host packer (dbgk_pack_bases, plain C++ in libdbgk.so -- no GPU call) against the reference's alphabet[]
+(DBG_contig/seqKmer.cpp:9-19) restated as a table, at every alignment, from several ranges into one buffer.
+GPU part (-m gpu): every engine fed packed batches -- from host memory, through the pinned staging buffers, from device
+memory -- builds what it builds from ASCII, i.e. what the real reference built (golden dumps); bytes outside the ten
+letters are read as 'A' by every engine alike and counted."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, golden_case_ids
+from helpers import case_reads, dump_sha256
+
+
+def _capi():
+    from dbg_assembly_amd import capi
+    return capi
+
+
+def _codes(raw):
+    """alphabet[] (seqKmer.cpp:9-19) as a table: A a N n -> 0, C c -> 1, G g -> 2, T t -> 3; everything else -> 0 ('A') + counted"""
+    code = np.zeros(256, dtype=np.uint32)
+    other = np.ones(256, dtype=np.uint64)
+    for ch, v in (("A", 0), ("C", 1), ("G", 2), ("T", 3), ("N", 0)):
+        for c in (ch, ch.lower()):
+            code[ord(c)] = v
+            other[ord(c)] = 0
+    return code[raw], int(other[raw].sum())
+
+
+def _pack_numpy(raw, first_base=0):
+    c, other = _codes(raw)
+    n = first_base + len(raw)
+    words = np.zeros((n + 15) // 16, dtype=np.uint32)
+    pos = np.arange(first_base, n)
+    np.bitwise_or.at(words, pos >> 4, c << (30 - 2 * (pos & 15)).astype(np.uint32))
+    return words, other
+
+
+def test_host_packer_equals_the_alphabet_table_at_every_alignment():
+    capi = _capi()
+    rng = np.random.default_rng(5)
+    every = np.arange(256, dtype=np.uint8)
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 64, 255, 256, 1000, 4099):
+        raw = np.concatenate([every, rng.integers(0, 256, size=n, dtype=np.uint8)])[:max(n, 0)] if n <= 256 else \
+            rng.choice(np.frombuffer(b"ACGTNacgtnRYK-*\x00\xff", dtype=np.uint8), size=n)
+        for first in (0, 1, 7, 15, 16, 21):
+            want, want_other = _pack_numpy(raw, first)
+            got, other = capi.pack_bases(raw, out=np.zeros(len(want) + 1, dtype=np.uint32), first_base=first)
+            assert np.array_equal(got[:len(want)], want), (n, first)
+            assert other == want_other
+            back = capi.unpack_bases(got, len(raw), first)
+            assert bytes(back) == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[_codes(raw)[0]])
+
+
+def test_host_packer_ranges_of_one_buffer_may_be_packed_independently():
+    """the reader threads of the host layer: every thread packs its own reads, at whatever base position they start"""
+    capi = _capi()
+    rng = np.random.default_rng(9)
+    raw = rng.choice(np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8), size=100003)
+    cuts = [0] + sorted(rng.integers(0, len(raw), size=12).tolist()) + [len(raw)]
+    out = np.zeros((len(raw) + 15) // 16, dtype=np.uint32)
+    other = 0
+    pieces = list(zip(cuts[:-1], cuts[1:]))
+    random.Random(1).shuffle(pieces)
+    for a, b in pieces:
+        other += capi.pack_bases(raw[a:b], out=out, first_base=a)[1]
+    want, want_other = _pack_numpy(raw)
+    assert np.array_equal(out, want) and other == want_other
+
+
+def test_oracle_reads_other_bytes_as_A(oracle):
+    """the oracle's entry rule (dbg_oracle.c code_of): a byte outside ACGTNacgtn is read as 'A' and counted"""
+    noisy = b"ACGTRYKMACGT-*ACGN\xff\x80acgtnACGTACGTACGTAAACCCGGGTTT"
+    clean = bytes(c if c in b"ACGTNacgtn" else ord("A") for c in noisy)
+    for k in (5, 17):
+        a, b = oracle.parse_read(noisy, k), oracle.parse_read(clean, k)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert oracle.count_other_bytes(np.frombuffer(noisy, dtype=np.uint8)) == sum(1 for c in noisy if c not in b"ACGTNacgtn") == 8
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------------------
+PART_SLOTS = 70000000
+
+
+@pytest.fixture(scope="module")
+def capi():
+    c = _capi()
+    assert c.lib().dbgk_device_count() >= 1, "no GPU visible: the HIP path cannot run (no CPU fallback exists)"
+    return c
+
+
+def _push(g, capi, bases, offsets, entry):
+    if entry == "host":          # packed by the caller, a lead-in of 5 bases so that the batch starts inside a word
+        words = np.zeros((5 + len(bases) + 15) // 16 + 1, dtype=np.uint32)
+        capi.pack_bases(np.frombuffer(b"GATTA", dtype=np.uint8), out=words)
+        _, other = capi.pack_bases(bases, out=words, first_base=5)
+        g.push_reads_packed(words, offsets + np.uint64(5), other)
+    elif entry == "staging":     # packed straight into the pinned staging buffers
+        g.push_reads_packed_zero_copy(bases, offsets)
+    elif entry == "device":      # packed on the device
+        if len(bases) == 0:
+            g.push_reads(bases, offsets)
+            return
+        d_b, d_o = capi.DeviceBuffer(g, len(bases) + 64), capi.DeviceBuffer(g, offsets.nbytes)
+        d_b.from_host(bases)
+        d_o.from_host(offsets)
+        d_p = g.pack_bases_device(d_b.ptr, len(bases))
+        assert np.array_equal(d_p.to_host(np.uint32, ((len(bases) + 15) // 16) * 4), capi.pack_bases(bases)[0]), "device packer != host packer"
+        g.push_reads_packed_device(d_p.ptr, d_o.ptr, len(offsets) - 1, len(bases))
+        g.sync()
+        for d in (d_b, d_o, d_p):
+            d.free()
+    else:
+        g.push_reads(bases, offsets)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["direct", "partition"])
+@pytest.mark.parametrize("case", [c for c in golden_cases() if c["name"] != "enlarge_cap_e1"],
+                         ids=[n for n in golden_case_ids() if n != "enlarge_cap_e1"])
+def test_golden_cases_through_the_packed_entry(capi, oracle, case, engine):
+    """what the real reference built from these files (tests/golden), from 2-bit packed batches: the three entries in turn"""
+    p, ref = case["params"], case["ref"]
+    files = case_reads(case, oracle)
+    n_bases = sum(int(o[-1]) for _, o in files)
+    if engine == "partition":
+        g = capi.Graph(k=p["k"], table_slots=capi.find_next_prime_ref(PART_SLOTS), max_read_len=p["max_read_len"], engine=capi.ENGINE_PARTITION,
+                       expected_kmers=max(n_bases, 1), max_batch_bases=1 << 16)
+    else:
+        g = capi.Graph(k=p["k"], table_slots=ref["size"], max_read_len=p["max_read_len"], engine=capi.ENGINE_DIRECT, max_batch_bases=1 << 16)
+    try:
+        for i, (bases, offsets) in enumerate(files):
+            _push(g, capi, bases, offsets, ("host", "staging", "device")[(i + len(case["name"])) % 3])
+        st = g.finalize()
+        assert (st.total_reads, st.total_kmers, st.count, st.other_bytes) == (ref["reads"], ref["kmers"], ref["count"], 0)
+        nodes = g.export_sorted()
+        assert dump_sha256(nodes, st.total_reads, st.total_kmers, st.count) == case["dump_sha256"]
+    finally:
+        g.close()
+
+
+def _reads_for(rng, n, L, shape):
+    g = "".join(rng.choice("ACGT") for _ in range(4000))
+    out = []
+    for _ in range(n):
+        ln = L if shape == "equal" else (L if rng.random() < 0.85 else rng.randint(L - 60, L)) if shape == "ragged" else rng.randint(0, L + 120)
+        s = rng.randint(0, len(g) - ln)
+        r = list(g[s:s + ln])
+        for j in range(len(r)):
+            if rng.random() < 0.01:
+                r[j] = rng.choice("ACGTNn")
+        out.append("".join(r).encode())
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["equal", "ragged", "mixed"])
+@pytest.mark.parametrize("entry", ["host", "staging", "device"])
+def test_every_level1_form_takes_packed_batches(capi, oracle, shape, entry):
+    """the PARTITION engine's level-1 kernels -- regular tiles + the general equal-length form (equal), the ragged form, the flat
+    kernel (mixed), each also in its linear form (DBGK_L1_LINEAR=1) -- and the other engines, packed == oracle"""
+    import os
+    rng = random.Random(len(shape) * 131 + len(entry))
+    reads = _reads_for(rng, 3000, 150, shape) + ([b"A" * 150] * 3 if shape == "equal" else [b"A" * 150, b"T" * 100, b"", b"ACGT"])
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, max_read_len=200, init_hash_size=0.001, threads=1)
+    want = ref.nodes.astype(capi.NODE_DTYPE)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    for lin in ("0", "1"):
+        os.environ["DBGK_L1_LINEAR"] = lin
+        try:
+            with capi.Graph(k=31, table_slots=size, max_read_len=200, engine=capi.ENGINE_PARTITION, expected_kmers=len(bases)) as g:
+                _push(g, capi, bases, offsets, entry)
+                st = g.finalize()
+                assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+                assert np.array_equal(g.export_sorted(), want), (shape, entry, lin)
+        finally:
+            del os.environ["DBGK_L1_LINEAR"]
+    # k-mer frequency table (atomics; partitioned blocks) and 128-bit keys (atomics; records): packed == ASCII
+    for k, engine, slots, expected in ((13, capi.ENGINE_KFREQ, 0, 0), (13, capi.ENGINE_KFREQ, 0, len(bases)), (47, capi.ENGINE_WIDE, 200003, 0),
+                                       (47, capi.ENGINE_WIDE, 1 << 26, len(bases))):
+        res = []
+        for e in ("ascii", entry):
+            with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(slots) if slots else 0, max_read_len=200, engine=engine, expected_kmers=expected) as g:
+                _push(g, capi, bases, offsets, e)
+                st = g.finalize()
+                body = g.kfreq_counts().tobytes() if engine == capi.ENGINE_KFREQ else g.wide_export_sorted().tobytes()
+                res.append((int(st.count), int(st.total_kmers), int(st.stored_kmers), body))
+        assert res[0] == res[1], (k, engine, expected, entry)
+
+
+@pytest.mark.gpu
+def test_seed_index_refuses_packed_batches(capi):
+    """its windows are cut at upper-case 'N' (link_scaffold/map_func.cpp:303-324), which two bits cannot carry"""
+    with capi.Graph(k=21, table_slots=100003, engine=capi.ENGINE_SEEDIDX) as g:
+        words, other = capi.pack_bases(np.frombuffer(b"ACGT" * 20, dtype=np.uint8))
+        with pytest.raises(capi.DbgkError) as e:
+            g.push_reads_packed(words, np.array([0, 80], dtype=np.uint64), other)
+        assert e.value.status == capi.ERR_ARG
+
+
+@pytest.mark.gpu
+def test_bytes_outside_the_alphabet_are_read_as_A_by_every_engine_and_counted(capi, oracle):
+    """IUPAC codes, '-', '*', control bytes, bytes >= 128 -- all 246 byte values that are none of ACGTNacgtn.  The reference reads
+    out of bounds on them (seqKmer.cpp:9-19, DBGgraph.cpp:71-73); here DIRECT == PARTITION == WIDE == the independent checker
+    == the oracle on the same reads with those bytes replaced by 'A', and stats.other_bytes says how many there were."""
+    import wide_checker
+    rng = random.Random(77)
+    others = bytes(c for c in range(256) if c not in b"ACGTNacgtn")
+    genome = "".join(rng.choice("ACGT") for _ in range(3000))
+    reads = []
+    for i in range(1500):
+        s = rng.randint(0, len(genome) - 150)
+        r = bytearray(genome[s:s + 150].encode())
+        for j in range(150):
+            if rng.random() < 0.02:
+                r[j] = rng.choice(others)
+        reads.append(bytes(r))
+    reads += [others, others[::-1] + b"ACGT" * 10, bytes([0xFF]) * 150, b"R" * 150, b"-" * 40]
+    n_other = sum(1 for r in reads for c in r if c not in b"ACGTNacgtn")
+    clean = [bytes(c if c in b"ACGTNacgtn" else ord("A") for c in r) for r in reads]
+    bases, offsets = oracle.pack_reads(reads)
+    cb, co = oracle.pack_reads(clean)
+    assert oracle.count_other_bytes(bases) == n_other
+    for k in (31, 17):
+        ref = oracle.build_graph(files_mem=[(cb, co)], k=k, max_read_len=250, init_hash_size=0.001, threads=1)
+        noisy = oracle.build_graph(files_mem=[(bases, offsets)], k=k, max_read_len=250, init_hash_size=0.001, threads=1)
+        assert np.array_equal(ref.nodes, noisy.nodes)
+        want = ref.nodes.astype(capi.NODE_DTYPE)
+        runs = [("direct", capi.ENGINE_DIRECT, 1000003, 0, "ascii"), ("direct, small batches", capi.ENGINE_DIRECT, 1000003, 0, "ascii-small"),
+                ("partition", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "ascii"),
+                ("partition, packed by the host", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "host"),
+                ("partition, packed on the device", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "device"),
+                ("direct, packed into the staging buffers", capi.ENGINE_DIRECT, 1000003, 0, "staging")]
+        for name, engine, slots, expected, entry in runs:
+            with capi.Graph(k=k, table_slots=slots, engine=engine, expected_kmers=expected, max_batch_bases=(1 << 14) if entry == "ascii-small" else 0) as g:
+                _push(g, capi, bases, offsets, entry)
+                st = g.finalize()
+                assert int(st.other_bytes) == n_other, (name, int(st.other_bytes), n_other)
+                assert np.array_equal(g.export_sorted(), want), name
+    # 128-bit keys against the checker that shares nothing with the library (tests/wide_checker.py)
+    for k in (31, 47):
+        nodes, total = wide_checker.build(reads, k, 250)
+        assert wide_checker.other_bytes(reads) == n_other
+        want = wide_checker.as_sorted_nodes(nodes)
+        for slots, expected, entry in ((300007, 0, "ascii"), (1 << 26, len(bases), "ascii"), (1 << 26, len(bases), "host")):
+            with capi.Graph(k=k, table_slots=capi.find_next_prime_ref(slots), engine=capi.ENGINE_WIDE, expected_kmers=expected) as g:
+                _push(g, capi, bases, offsets, entry)
+                st = g.finalize()
+                assert int(st.other_bytes) == n_other
+                assert int(st.total_kmers) == total
+                assert np.array_equal(g.wide_export_sorted(), want), (k, slots, entry)

@@ -44,11 +44,13 @@ def observations(reads, k, max_read_len=250):
     total = 0
     for read in reads:
         if isinstance(read, (bytes, bytearray, np.ndarray)):
-            read = bytes(read).decode("ascii")
+            read = bytes(read).decode("latin-1")
         if len(read) < k:
             continue
         total += len(read) - k + 1
-        norm = "".join(LETTER[CODE[ch]] for ch in read)   # N counts as A, lower case as upper case
+        # N counts as A, lower case as upper case; so does every byte outside ACGTNacgtn (the reference reads out of bounds on
+        # those, seqKmer.cpp:9-19 + DBGgraph.cpp:71-73: this build's rule, counted by other_bytes below)
+        norm = "".join(LETTER[CODE.get(ch, 0)] for ch in read)
         readlen = min(len(norm), max_read_len)
         for j in range(0, readlen - k + 1):
             word = norm[j:j + k]
@@ -64,6 +66,16 @@ def observations(reads, k, max_read_len=250):
                 rbase = COMPLEMENT[left] if left is not None else None
             out.append((key, None if lbase is None else LETTER.index(lbase), None if rbase is None else LETTER.index(rbase)))
     return out, total
+
+
+def other_bytes(reads):
+    """how many bytes of the reads are none of ACGTNacgtn (dbgk_stats.other_bytes)"""
+    n = 0
+    for read in reads:
+        if isinstance(read, (bytes, bytearray, np.ndarray)):
+            read = bytes(read).decode("latin-1")
+        n += sum(1 for ch in read if ch not in CODE)
+    return n
 
 
 def build(reads, k, max_read_len=250):
