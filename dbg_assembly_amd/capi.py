@@ -96,6 +96,7 @@ SYMBOLS = [
     ("dbgk_push_commit", _i, [_vp, _u64]),
     ("dbgk_push_reads_device", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_pack_bases", _i, [_vp, _u64, _vp, _u64, C.POINTER(_u64)]),
+    ("dbgk_pack_reads", _i, [_vp, _u64, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_unpack_bases", _i, [_vp, _u64, _u64, _vp]),
     ("dbgk_push_reads_packed", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_push_commit_packed", _i, [_vp, _u64, _u64]),
@@ -209,6 +210,21 @@ def pack_bases(bases, out=None, first_base=0):
     other = C.c_uint64(0)
     _chk(lib().dbgk_pack_bases(bases.ctypes.data, len(bases), out.ctypes.data, first_base, C.byref(other)), "dbgk_pack_bases")
     return out, other.value
+
+
+class ReadRef(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("len", C.c_uint32)]
+
+
+def pack_reads(reads, out, first_base=0):
+    """a list of bytes objects packed back to back into `out` from base position first_base on (dbgk_pack_reads) -> other bytes"""
+    refs = (ReadRef * len(reads))()
+    keep = [np.frombuffer(r, dtype=np.uint8) if len(r) else np.zeros(1, np.uint8) for r in reads]
+    for i, (r, k) in enumerate(zip(reads, keep)):
+        refs[i].seq, refs[i].len = k.ctypes.data, len(r)
+    other = C.c_uint64(0)
+    _chk(lib().dbgk_pack_reads(refs, len(reads), out.ctypes.data, first_base, C.byref(other)), "dbgk_pack_reads")
+    return other.value
 
 
 def unpack_bases(packed, n_bases, first_base=0):
@@ -640,6 +656,11 @@ class Comm:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _chk(lib().dbgk_comm_push_reads(self._c, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "dbgk_comm_push_reads")
+
+    def push_reads_packed(self, packed, offsets, other_bytes=0):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _chk(lib().dbgk_comm_push_reads_packed(self._c, packed.ctypes.data, offsets.ctypes.data, len(offsets) - 1, other_bytes), "dbgk_comm_push_reads_packed")
 
     def flush(self):
         _chk(lib().dbgk_comm_flush(self._c), "dbgk_comm_flush")

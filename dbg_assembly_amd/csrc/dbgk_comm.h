@@ -426,6 +426,23 @@ static int comm_wide_finalize(dbgk_comm *c)
 		if (rc) return rc;
 		HIPCHK(hipStreamSynchronize(c->copy_stream[d]));
 	}
+	if (n > 1) { // what every shard received must be what the others extracted for it (as in the 64-bit flow): the fill counts of the pass,
+	             // summed over the whole job on both sides -- a copy between shards that moved only part of a message fails here
+		unsigned long long sent = 0, received = 0;
+		std::vector<uint32_t> buf((size_t)G0.n_l1);
+		for (uint32_t d = 0; d < n; d++) {
+			rc = use_device(c->h[d]);
+			if (rc) return rc;
+			HIPCHK(hipMemcpy(buf.data(), c->h[d]->wstore.cnt1, buf.size() * 4, hipMemcpyDeviceToHost));
+			for (uint32_t v : buf) sent += v;
+			HIPCHK(hipMemcpy(buf.data(), c->h[d]->winbox_cnt, buf.size() * 4, hipMemcpyDeviceToHost));
+			for (uint32_t v : buf) received += v;
+		}
+		if (sent != received) {
+			g_last_error = "dbgk_comm (WIDE): records sent (" + std::to_string(sent) + ") != records received (" + std::to_string(received) + "): a copy between shards went wrong";
+			return DBGK_ERR_STATE;
+		}
+	}
 	// 4. hand-offs: a list of shard s is merged straight from s's memory when s and d share a device, through a scratch copy otherwise
 	auto offer = [&](dbgk_handle *S, const void *list, uint64_t count, int is_obs, int from_prev, dbgk_handle *D, bool side_nodes) -> int {
 		if (count == 0) return DBGK_OK;
@@ -547,6 +564,11 @@ extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
 	if (new_slots == c->h[0]->size) return DBGK_OK;
 	CommScope scope(c);
 	const uint32_t n = (uint32_t)c->h.size();
+	// A shard that has never been through a region build (nothing pushed, or nothing flushed yet: dbgk_comm_flush returns early
+	// when no records wait) holds NO table -- its memory is whatever hipMalloc returned (zero_pending): nothing to carry over
+	// from it, and scanning it would re-seat garbage.  resize_partition_table guards the single handle the same way.
+	bool any_built = false;
+	for (dbgk_handle *S : c->h) any_built = any_built || S->incr;
 	std::vector<dbgk_handle *> fresh(n, nullptr);
 	auto drop_fresh = [&]() {
 		for (dbgk_handle *f : fresh)
@@ -561,8 +583,10 @@ extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
 		one.table_slots = new_slots;
 		rc = dbgk_create(&one, &fresh[i]);
 		if (rc == DBGK_OK) rc = use_device(fresh[i]);
-		if (rc == DBGK_OK) rc = zero_table_now(fresh[i]); // nodes arrive through the atomic path
-		if (rc == DBGK_OK) fresh[i]->incr = true;        // later region builds load them back
+		if (rc == DBGK_OK && any_built) {
+			rc = zero_table_now(fresh[i]);                // nodes arrive through the atomic path
+			if (rc == DBGK_OK) fresh[i]->incr = true;    // later region builds load them back
+		}                                                 // (else: a fresh shard as dbgk_comm_create leaves it -- the first build writes every slot)
 	}
 	if (rc) {
 		drop_fresh();
@@ -574,6 +598,7 @@ extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
 		Node *scratch = nullptr;
 		for (uint32_t s = 0; s < n && rc == DBGK_OK; s++) {
 			dbgk_handle *S = c->h[s];
+			if (!S->incr) continue; // never built: no nodes
 			for (uint64_t off = 0; off < S->tslots && rc == DBGK_OK; off += chunk_nodes) {
 				const uint64_t cnt = std::min(chunk_nodes, S->tslots - off);
 				const Node *src = S->table + off;
@@ -642,10 +667,13 @@ extern "C" int dbgk_comm_resize(dbgk_comm *c, uint64_t new_slots)
 		cf.total_kmers = co.total_kmers;
 		cf.stored_kmers = co.stored_kmers;
 		cf.polyA_links = co.polyA_links;
+		cf.other_bytes = co.other_bytes;
+		cf.other_seen = co.other_seen;
 		cf.n_conflict += co.n_conflict;
 		if (hipMemcpy(F->d_ctr, &cf, sizeof cf, hipMemcpyHostToDevice) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
 		if (hipMemsetAsync(F->store.outgoing_n, 0, 8, F->stream) != hipSuccess || hipStreamSynchronize(F->stream) != hipSuccess) { rc = DBGK_ERR_HIP; break; }
 		F->total_reads = O->total_reads;
+		F->host_other_bytes = O->host_other_bytes;
 	}
 	if (rc) {
 		drop_fresh();

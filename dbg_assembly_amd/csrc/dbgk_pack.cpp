@@ -111,6 +111,61 @@ extern "C" int dbgk_pack_bases(const char *bases, uint64_t n_bases, uint32_t *pa
 	return DBGK_OK;
 }
 
+// n_reads sequences packed back to back from base position first_base on: what one reader thread does with its share of a batch.
+// The bytes are gathered into a small scratch buffer (cache resident) so that the word packer runs on 16-base groups whatever the
+// read lengths are; only the stream's first and last word can be shared with a neighbour (OR-ed in, as in dbgk_pack_bases).
+extern "C" int dbgk_pack_reads(const dbgk_read_ref *reads, uint64_t n_reads, uint32_t *packed, uint64_t first_base, uint64_t *other_bytes)
+{
+	if ((n_reads && !reads) || !packed) return DBGK_ERR_ARG;
+	constexpr size_t kScratch = 32768; // a multiple of 16
+	unsigned char scratch[kScratch];
+	size_t fill = 0;
+	uint64_t at = first_base, other = 0;
+	bool head_done = (at & 15u) == 0;
+	auto flush = [&](bool last) {
+		size_t from = 0;
+		if (!head_done) { // the stream starts inside a word: bring it to the word boundary first
+			const uint32_t room = 16u - (uint32_t)(at & 15u);
+			if (fill < room && !last) return; // (keep gathering)
+			const uint32_t n = (uint32_t)(fill < room ? fill : room);
+			const uint32_t w = pack_scalar(scratch, n, other) >> (2u * (uint32_t)(at & 15u));
+			__atomic_fetch_or(&packed[at >> 4], w, __ATOMIC_RELAXED);
+			at += n;
+			from = n;
+			head_done = (at & 15u) == 0;
+		}
+		const size_t full = (fill - from) >> 4;
+		if (full) {
+			g_pack_words(scratch + from, full, packed + (at >> 4), other);
+			at += full * 16;
+			from += full * 16;
+		}
+		if (last && from < fill) {
+			const uint32_t w = pack_scalar(scratch + from, (uint32_t)(fill - from), other);
+			__atomic_fetch_or(&packed[at >> 4], w, __ATOMIC_RELAXED);
+			at += fill - from;
+			from = fill;
+		}
+		memmove(scratch, scratch + from, fill - from);
+		fill -= from;
+	};
+	for (uint64_t i = 0; i < n_reads; i++) {
+		const unsigned char *s = reinterpret_cast<const unsigned char *>(reads[i].seq);
+		size_t left = reads[i].len;
+		while (left) {
+			const size_t take = left < kScratch - fill ? left : kScratch - fill;
+			memcpy(scratch + fill, s, take);
+			fill += take;
+			s += take;
+			left -= take;
+			if (fill == kScratch) flush(false);
+		}
+	}
+	flush(true);
+	if (other_bytes) *other_bytes += other;
+	return DBGK_OK;
+}
+
 extern "C" int dbgk_unpack_bases(const uint32_t *packed, uint64_t first_base, uint64_t n_bases, char *bases)
 {
 	if ((n_bases && !bases) || (n_bases && !packed)) return DBGK_ERR_ARG;

@@ -1,9 +1,12 @@
 // DBGgraph.cpp -- build_debruijn_graph() on an MI355X.
 //
 // Host responsibilities only: parse the (optionally gzip'ed) one-line FASTA/FASTQ files into
-// batches of raw sequence bytes, stream them to the GPU through the C ABI of include/dbgk.h, and
+// batches of sequences, stream them to the GPU through the C ABI of include/dbgk.h, and
 // materialise the finished table as the host KmerSet the reference's contig stage expects.  All
-// k-mer work (2-bit packing, canonicalisation, hashing, counting) happens in the HIP kernels.
+// k-mer work (canonicalisation, hashing, counting) happens in the HIP kernels.  The sequences travel
+// 2 BITS PER BASE: the reader threads pack them (dbgk_pack_reads -- the reference's own alphabet[],
+// seqKmer.cpp:9-19, is two bits wide) straight into the pinned staging buffers, a quarter of the bytes
+// over PCIe; DBGK_HOST_ASCII=1 hands over the raw bytes instead (the GPU then packs them).
 //
 // Reference behaviour followed here (paths relative to /root/reference/DBG_contig/):
 //   record detection            DBGgraph.cpp:244-272   (first character of a line; next line = sequence)
@@ -117,9 +120,16 @@ struct Session {
 	std::vector<uint64_t> offsets;    // offsets.size() == reads in batch + 1
 	// plain files are mapped and parsed with several threads (reads_io.h): their reads are first only NOTED (pointer into the
 	// mapping, length; offsets grows) and copied into `bases` by the same threads when the batch is handed over
-	std::vector<std::pair<const char *, uint32_t>> noted;
+	std::vector<dbgk_read_ref> noted;
 	uint64_t noted_bytes = 0;
 	int parse_threads = 4;
+	// 2-bit hand-over (default): `bases` holds packed WORDS, its size() counts BASES (a quarter of the bytes are in use;
+	// capacities are kept in bases = bytes of the ASCII form, so every limit below means the same in both modes)
+	bool packed = true;
+	uint64_t batch_other = 0;         // bytes outside ACGTNacgtn met while packing the pending batch (read as 'A', counted)
+	std::thread creator;              // dbgk_create runs beside the reading of the first file window
+	int create_rc = DBGK_OK;
+	std::string create_err;
 	bool zero_copy = false;           // one GPU: batches are assembled in the handle's pinned staging buffers (dbgk_push_acquire / _commit)
 	uint64_t *staged_offsets = nullptr;
 	uint64_t staged_cap_reads = 0;
@@ -153,6 +163,22 @@ struct Stopwatch { // adds its lifetime to a counter
 	~Stopwatch() { acc += now_s() - t0; }
 };
 
+void fail(Session &S, int rc, const char *what);
+
+// the handle is created on a thread of its own while the first window of the first file is read: wait for it here
+void ensure_created(Session &S)
+{
+	if (!S.creator.joinable()) return;
+	S.creator.join();
+	if (S.create_rc != DBGK_OK) {
+		if (S.status == DBGK_OK) {
+			S.status = S.create_rc;
+			cerr << "\nAlert message: dbgk_create failed: " << dbgk_strerror(S.create_rc) << " [" << S.create_err << "]; the input is ignored" << endl;
+		}
+		S.zero_copy = false;
+	}
+}
+
 void fail(Session &S, int rc, const char *what)
 {
 	if (S.status == DBGK_OK) {
@@ -178,6 +204,7 @@ inline float clamped_load_factor()
 // (the PARTITION engine flushes its record store for it)
 void exact_count(Session &S)
 {
+	ensure_created(S);
 	if (S.status != DBGK_OK) return;
 	Stopwatch sw(S.t_count);
 	int rc = S.comm ? dbgk_comm_flush(S.comm) : (S.partition ? dbgk_flush(S.h) : DBGK_OK);
@@ -211,6 +238,7 @@ void reserve_device_slots(Session &S)
 // zero-copy batches: the staging buffers of the handle's next slot become the batch buffer
 void acquire_staging(Session &S)
 {
+	ensure_created(S);
 	if (!S.zero_copy || S.bases.external || S.bases.size() || S.status != DBGK_OK) return;
 	char *mem = nullptr;
 	uint64_t cap_bases = 0;
@@ -232,14 +260,34 @@ void materialize_noted(Session &S)
 	S.bases.grow_uninitialized(S.noted_bytes);
 	const int T = std::max(1, std::min(S.parse_threads, (int)(S.noted.size() / 4096 + 1)));
 	const size_t per = (S.noted.size() + (size_t)T - 1) / (size_t)T;
+	std::vector<uint64_t> other((size_t)T, 0);
+	uint32_t *words = reinterpret_cast<uint32_t *>(S.bases.data());
+	if (S.packed) {
+		// every thread packs its reads as ONE 2-bit stream from the base position its share starts at; the words where two
+		// shares meet (and the last one, if the batch ends inside it) are OR-ed into from both sides: zero beforehand.  The word
+		// the appended range STARTS inside belongs to what is already there (its unused low bits are zero) and stays.
+		const uint64_t p_start = S.offsets[first], p_end = S.offsets[first + S.noted.size()];
+		for (int t = 0; t <= T; t++) {
+			const uint64_t p = t == T ? p_end : S.offsets[first + std::min(S.noted.size(), per * (size_t)t)];
+			if (t == T && (p & 15u) == 0) continue;                              // nothing of this batch reaches that word
+			if ((p >> 4) == (p_start >> 4) && (p_start & 15u)) continue;        // holds earlier bases
+			if (t > 0 && t < T && (p & 15u) == 0 && p == p_end) continue;       // (an empty share at the end)
+			words[p >> 4] = 0u;
+		}
+	}
 	auto copy = [&](int t) {
 		const size_t a = std::min(S.noted.size(), per * (size_t)t), b = std::min(S.noted.size(), a + per);
-		for (size_t i = a; i < b; i++) memcpy(S.bases.data() + S.offsets[first + i], S.noted[i].first, S.noted[i].second);
+		if (S.packed) {
+			if (b > a) dbgk_pack_reads(&S.noted[a], b - a, words, S.offsets[first + a], &other[(size_t)t]);
+			return;
+		}
+		for (size_t i = a; i < b; i++) memcpy(S.bases.data() + S.offsets[first + i], S.noted[i].seq, S.noted[i].len);
 	};
 	std::vector<std::thread> th;
 	for (int t = 1; t < T; t++) th.emplace_back(copy, t);
 	copy(0);
 	for (auto &x : th) x.join();
+	for (uint64_t o : other) S.batch_other += o;
 	S.noted.clear();
 	S.noted_bytes = 0;
 }
@@ -254,19 +302,25 @@ void flush_batch(Session &S)
 		return;
 	}
 	if (S.bases.external && n_reads > S.staged_cap_reads) S.bases.reserve(S.bases.cap + 1); // (more reads than offsets fit: hand over by copy)
+	ensure_created(S);
 	reserve_device_slots(S);
 	if (S.status == DBGK_OK) {
 		Stopwatch sw(S.t_push);
 		int rc;
+		const uint32_t *words = reinterpret_cast<const uint32_t *>(S.bases.data());
 		if (S.bases.external && n_reads <= S.staged_cap_reads) { // the batch sits in the staging buffer already
 			memcpy(S.staged_offsets, S.offsets.data(), (n_reads + 1) * sizeof(uint64_t));
-			rc = dbgk_push_commit(S.h, n_reads);
+			rc = S.packed ? dbgk_push_commit_packed(S.h, n_reads, S.batch_other) : dbgk_push_commit(S.h, n_reads);
+		} else if (S.packed) {
+			rc = S.comm ? dbgk_comm_push_reads_packed(S.comm, words, S.offsets.data(), n_reads, S.batch_other)
+			            : dbgk_push_reads_packed(S.h, words, S.offsets.data(), n_reads, S.batch_other);
 		} else {
 			rc = S.comm ? dbgk_comm_push_reads(S.comm, S.bases.data(), S.offsets.data(), n_reads)
 			            : dbgk_push_reads(S.h, S.bases.data(), S.offsets.data(), n_reads);
 		}
 		if (rc != DBGK_OK) fail(S, rc, "dbgk_push_reads");
 	}
+	S.batch_other = 0;
 	S.bases.detach(); // (a staging buffer goes back to the handle; the next batch takes the other one)
 	Total_reads_num += n_reads;
 	if (Total_reads_num >= S.next_progress) {
@@ -309,7 +363,16 @@ inline void add_read(Session &S, const char *seq, size_t len)
 {
 	acquire_staging(S);
 	if (S.bases.external && S.bases.size() + len > S.bases.cap && S.bases.size()) flush_batch(S), acquire_staging(S);
-	S.bases.append(seq, len);
+	if (S.packed) { // the read's codes go behind what is there; the words it newly reaches are cleared first (its ends are OR-ed in)
+		const size_t at = S.bases.size();
+		S.bases.grow_uninitialized(len);
+		uint32_t *words = reinterpret_cast<uint32_t *>(S.bases.data());
+		const size_t w0 = (at + 15) >> 4, w1 = (at + len + 15) >> 4;
+		if (w1 > w0) memset(words + w0, 0, (w1 - w0) * sizeof(uint32_t));
+		dbgk_pack_bases(seq, len, words, at, &S.batch_other);
+	} else {
+		S.bases.append(seq, len);
+	}
 	S.offsets.push_back(S.bases.size());
 	S.bound_since += windows_of(len);
 	S.pos += len;
@@ -321,7 +384,7 @@ inline void add_read(Session &S, const char *seq, size_t len)
 inline void note_read(Session &S, const char *seq, size_t len)
 {
 	if (S.zero_copy && S.offsets.back() + len > S.batch_limit + (1u << 16) && S.offsets.size() > 1) flush_batch(S); // keep the batch inside the staging buffer
-	S.noted.push_back({seq, (uint32_t)len});
+	S.noted.push_back(dbgk_read_ref{seq, (uint32_t)len});
 	S.noted_bytes += len;
 	S.offsets.push_back(S.offsets.back() + len);
 	S.bound_since += windows_of(len);
@@ -417,6 +480,7 @@ static KmerSet *replay_reference_layout(Session &S, const std::vector<dbgk_node>
 static void release_session()
 {
 	if (!g_session) return;
+	if (g_session->creator.joinable()) g_session->creator.join();
 	if (g_session->h) dbgk_destroy(g_session->h);
 	if (g_session->comm) dbgk_comm_destroy(g_session->comm);
 	delete g_session;
@@ -463,6 +527,7 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 	const uint64_t bound = input_size_bound(reads_files);
 	const bool records = bound > 0 && initial_size >= kPartitionMinSlots && initial_size <= kPartitionMaxSlots && !getenv("DBGK_WIDE_DIRECT");
 	cfg.expected_kmers = records ? bound : 0; // unknown input size (compressed files): fused extract + atomic insert
+	if (records) cfg.n_passes = 1; // this caller follows the pass protocol: as many passes over the input files as the geometry needs
 	if (records && getenv("DBGK_WIDE_PASSES")) cfg.n_passes = (uint64_t)std::max(1, atoi(getenv("DBGK_WIDE_PASSES"))); // more passes than the geometry needs (small devices, tests)
 	S->device_slots = initial_size;
 	std::vector<int32_t> devices;
@@ -529,6 +594,8 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 		rc = S->comm ? dbgk_comm_finalize(S->comm, &st) : dbgk_finalize(S->h, &st);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
 	}
+	if (S->status == DBGK_OK && st.other_bytes)
+		cerr << "\nAlert message: " << st.other_bytes << " sequence bytes are none of ACGTNacgtn; they were read as A (like N)" << endl;
 	const double t_export0 = now_s();
 	KmerSet128 *result = NULL;
 	if (S->status == DBGK_OK) {
@@ -591,6 +658,8 @@ void build_debruijn_graph(vector<string> &reads_files)
 	if (const char *mb = getenv("DBGK_BATCH_MB")) S->batch_limit = std::max<uint64_t>(1, strtoull(mb, NULL, 10)) << 20;
 	if (const char *bb = getenv("DBGK_BATCH_BYTES")) S->batch_limit = std::max<uint64_t>(1024, strtoull(bb, NULL, 10)); // tests: many small batches
 	S->bases.reserve(S->batch_limit + (1u << 16));
+	S->packed = !getenv("DBGK_HOST_ASCII");
+	S->parse_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
 	if (KmerSize > 32) return build_debruijn_graph_wide(reads_files, S, initial_size);
 	if (kset_wide) {
 		free_hash128(kset_wide);
@@ -647,12 +716,20 @@ void build_debruijn_graph(vector<string> &reads_files)
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_comm_create");
 		else cerr << "k-mer table of " << S->device_slots << " entries over " << devices.size() << " GPU shards" << endl;
 	} else {
-		rc = dbgk_create(&cfg, &S->h);
-		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
-		S->zero_copy = rc == DBGK_OK && !getenv("DBGK_NO_ZERO_COPY"); // batches are parsed straight into the pinned staging buffers
+		// the handle (device table, record stores, streams: ~0.1 s) is made on a thread of its own while the first window of the
+		// first file is being read; whoever needs it first waits for it (ensure_created)
+		rc = DBGK_OK;
+		S->zero_copy = !getenv("DBGK_NO_ZERO_COPY"); // batches are parsed straight into the pinned staging buffers
+		const double t0c = now_s();
+		S->creator = std::thread([S, cfg, t0c]() {
+			S->create_rc = dbgk_create(&cfg, &S->h);
+			if (S->create_rc != DBGK_OK) S->create_err = dbgk_last_error();
+			S->t_create = now_s() - t0c;
+		});
+		if (getenv("DBGK_CREATE_SYNC")) ensure_created(*S);
 	}
 
-	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
+	if (S->comm) S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
 	cerr << "The initialization memory used:  " << initHashSize * 16 << " G" << endl;
 	time_end = clock();
@@ -667,6 +744,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 			S->t_parse += (now_s() - t0) - (S->t_push + S->t_count - dev0);
 		}
 		dbgk_stats st;
+		ensure_created(*S);
 		if (S->status == DBGK_OK && (S->comm ? dbgk_comm_refresh_stats(S->comm, &st) : dbgk_refresh_stats(S->h, &st)) == DBGK_OK)
 			Kmer_total_num = st.total_kmers;
 		cerr << "\nTotal number of reads loaded into memory: " << Total_reads_num << endl;
@@ -678,11 +756,14 @@ void build_debruijn_graph(vector<string> &reads_files)
 	// hand the graph over as a host KmerSet
 	dbgk_stats st;
 	memset(&st, 0, sizeof st);
+	ensure_created(*S);
 	if (S->status == DBGK_OK) {
 		Stopwatch sw(S->t_finalize);
 		rc = S->comm ? dbgk_comm_finalize(S->comm, &st) : dbgk_finalize(S->h, &st);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_finalize");
 	}
+	if (S->status == DBGK_OK && st.other_bytes)
+		cerr << "\nAlert message: " << st.other_bytes << " sequence bytes are none of ACGTNacgtn; they were read as A (like N)" << endl;
 	const double t_export0 = now_s();
 	KmerSet *result = NULL;
 	if (S->status == DBGK_OK && S->ref_layout) {

@@ -91,10 +91,12 @@ typedef struct dbgk_config {
 	                              the exchange protocol, useful for testing it on one GPU)        */
 	uint32_t shard_index;      /* 0 .. shard_count-1                                               */
 	uint64_t flags;            /* DBGK_FLAG_*                                                      */
-	uint64_t n_passes;         /* DBGK_ENGINE_WIDE through records: read the input this many times, every pass
-	                              keeping the records of a part of the level-1 buckets (dbgk_wide_begin_pass);
-	                              0 = as few as the geometry needs (1 unless the table has more than 1024
-	                              level-1 buckets per pass, counted over all shards)                  */
+	uint64_t n_passes;         /* DBGK_ENGINE_WIDE through records: read the input (at least) this many times, every
+	                              pass keeping the records of a part of the level-1 buckets (dbgk_wide_begin_pass);
+	                              the geometry may need more (a pass fans out to at most 1024 level-1 buckets, counted
+	                              over all shards): ask dbgk_wide_pass_info.  0 on an unsharded handle = the plain
+	                              create / push / finalize flow, never the pass protocol: a table one pass cannot
+	                              cover is then built by the atomic kernels.  0 on a sharded handle = as few as needed */
 	uint64_t reserved[1];
 } dbgk_config;
 
@@ -200,6 +202,14 @@ int dbgk_push_commit(dbgk_handle *h, uint64_t n_reads);
  *   through word (n_bases + 15) / 16 - 1); dbgk_pack_bases_device makes such a buffer from ASCII bases in device memory.
  * Every engine takes packed batches except DBGK_ENGINE_SEEDIDX, whose windows are cut at 'N' (DBGK_ERR_ARG).             */
 int dbgk_pack_bases(const char *bases, uint64_t n_bases, uint32_t *packed, uint64_t first_base, uint64_t *other_bytes);
+/* the same for n_reads sequences that lie anywhere in memory (a parser's view of a file window), packed back to back from base
+ * position first_base on -- one call per reader thread and share of a batch; only the first and the last word of the call's range are
+ * OR-ed into (zero beforehand where a neighbour shares them)                                                                   */
+typedef struct dbgk_read_ref {
+	const char *seq;
+	uint32_t    len;
+} dbgk_read_ref;
+int dbgk_pack_reads(const dbgk_read_ref *reads, uint64_t n_reads, uint32_t *packed, uint64_t first_base, uint64_t *other_bytes);
 int dbgk_unpack_bases(const uint32_t *packed, uint64_t first_base, uint64_t n_bases, char *bases);
 int dbgk_push_reads_packed(dbgk_handle *h, const uint32_t *packed, const uint64_t *offsets, uint64_t n_reads, uint64_t other_bytes);
 int dbgk_push_commit_packed(dbgk_handle *h, uint64_t n_reads, uint64_t other_bytes);
@@ -493,7 +503,9 @@ int dbgk_reset_timings(dbgk_handle *h);
 /* HIP stream of the handle as an opaque pointer (hipStream_t), for callers that time with events */
 void *dbgk_stream(dbgk_handle *h);
 
-/* device-to-device copy bandwidth probe (GB/s) used as the measured-HBM denominator             */
+/* the measured-HBM denominator of the roofline (GB/s, bytes read + bytes written): the best of the runtime's device-to-device
+ * memcpy and this library's own streaming copy kernels (16 bytes per lane, default and non-temporal policy, 1 and 2 workgroups
+ * per CU) over two buffers of `bytes` each (use >= 2 GiB: far beyond the 256 MiB Infinity Cache), `iters` copies per variant   */
 int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int iters, double *gbps);
 /* random 64-byte gather over a buffer of `bytes` (the practical random-access ceiling of the engines
  * that touch one random node per k-mer occurrence): n_accesses sectors fetched, GB/s and G sectors/s             */

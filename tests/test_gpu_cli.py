@@ -82,6 +82,58 @@ def test_cli_streams_through_a_small_record_store(tmp_path, name):
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
 
 
+@pytest.mark.parametrize("name", ["mixed150_k31", "fastq_gz_k31", "lowercase_k31", "enlarge_b50"])
+def test_cli_ascii_hand_over_equals_the_packed_one(tmp_path, name):
+    """the reader threads pack the reads to 2 bits per base by default (every other CLI test); DBGK_HOST_ASCII=1 hands the raw bytes
+    over and the GPU packs them: same graph, with many small batches as well"""
+    case = [c for c in golden_cases() if c["name"] == name][0]
+    for extra in ({"DBGK_HOST_ASCII": "1"}, {"DBGK_HOST_ASCII": "1", "DBGK_BATCH_BYTES": "4096"}, {"DBGK_BATCH_BYTES": "4099"},
+                  {"DBGK_BATCH_BYTES": "4099", "DBGK_NO_ZERO_COPY": "1"}, {"DBGK_PARSE_SEQUENTIAL": "1", "DBGK_BATCH_BYTES": "5000"}):
+        r, dump, _ = run_cli(tmp_path, case, extra)
+        assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"], extra
+        assert "none of ACGTNacgtn" not in r.stderr
+
+
+@pytest.mark.parametrize("engine", [2, 1], ids=["partition", "direct"])
+def test_cli_reads_with_bytes_outside_the_alphabet(tmp_path, oracle, engine):
+    """IUPAC codes, gaps, bytes >= 128 in a FASTA file: the reference reads out of bounds on them (seqKmer.cpp:9-19,
+    DBGgraph.cpp:71-73); here they are read as 'A' -- the graph is the oracle's graph of the reads with those bytes replaced
+    by 'A' -- and one warning line says how many there were; packed and ASCII hand-over, plain and gzip'ed file alike"""
+    import gzip
+    import random
+    rng = random.Random(5)
+    genome = "".join(rng.choice("ACGT") for _ in range(4000)).encode()
+    reads, n_other = [], 0
+    for _ in range(1200):
+        s0 = rng.randint(0, len(genome) - 150)
+        r = bytearray(genome[s0:s0 + 150])
+        for j in range(150):
+            if rng.random() < 0.02:
+                r[j] = rng.choice(b"RYKMSWBDHVrykm-*.?\x80\xff")
+                n_other += 1
+        reads.append(bytes(r))
+    clean = [bytes(c if c in b"ACGTNacgtn" else ord("A") for c in r) for r in reads]
+    cb, co = oracle.pack_reads(clean)
+    ref = oracle.build_graph(files_mem=[(cb, co)], k=31, max_read_len=250, init_hash_size=0.001, threads=1)
+    plain, gz = tmp_path / "reads.fa", tmp_path / "reads.fa.gz"
+    body = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads))
+    plain.write_bytes(body)
+    with gzip.open(gz, "wb") as fh:
+        fh.write(body)
+    for path, extra in ((plain, {}), (plain, {"DBGK_HOST_ASCII": "1"}), (gz, {}), (gz, {"DBGK_HOST_ASCII": "1"})):
+        libf = tmp_path / "reads.lib"
+        libf.write_text(str(path) + "\n")
+        dump = tmp_path / "dump.txt"
+        env = dict(os.environ, DBGK_DUMP=str(dump), DBGK_ENGINE=str(engine), DBGK_BATCH_BYTES="30000")
+        env.update(extra)
+        r = subprocess.run([CLI, "-k", "31", "-f", "2", "-t", "4", "-i", "0.001", "-o", str(tmp_path / "out"), str(libf)], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Alert message: %d sequence bytes are none of ACGTNacgtn; they were read as A (like N)" % n_other in r.stderr, (path, extra)
+        _, nodes = oracle.parse_dump(str(dump))
+        assert len(nodes) == ref.count and all((nodes[f] == ref.nodes[f]).all() for f in ("kmer", "l_link", "r_link")), (path, extra)
+
+
 LAYOUT_CASES = [c for c in FILE_CASES if c["name"] in ("mixed150_k31", "enlarge_b50", "block_b7", "polyA_k31", "fastq_gz_k31",
                                                         "lengths_k31_r100", "even_k32", "saturate_k31")]
 

@@ -816,6 +816,30 @@ def test_comm_resize_across_shards_and_host_staged_copies(capi, oracle, n_shards
         assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)
 
 
+def test_comm_resize_before_anything_was_built(capi, oracle):
+    """dbgk_comm_resize right after dbgk_comm_create, and again after pushes that were never flushed: a shard that has not been
+    through a region build holds no table (uninitialised memory) -- nothing may be carried over from it (round-3 advisor finding:
+    the scan re-seated garbage nodes).  The job afterwards is the oracle's; the reads go in 2-bit packed."""
+    rng = random.Random(12)
+    reads = rand_reads(rng, 1500, G=20000)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size, bigger, biggest = (capi.find_next_prime_ref(PART_SLOTS + d) for d in (0, 40_000_000, 90_000_000))
+    with capi.Comm(k=31, table_slots=size, devices=[0, 0, 0], expected_kmers=400000, max_batch_bases=1 << 16) as c:
+        c.resize(bigger)                                  # nothing pushed at all
+        st0 = c.refresh_stats()
+        assert (int(st0.count), int(st0.total_kmers), int(st0.table_slots)) == (1, 0, bigger)
+        half = len(reads) // 2
+        lo = int(offsets[half])
+        words, other = capi.pack_bases(bases)
+        c.push_reads_packed(words, offsets[:half + 1], other)
+        c.resize(biggest)                                 # (flushes what was pushed, then carries those nodes over)
+        c.push_reads(bases[lo:], offsets[half:] - offsets[half])
+        st = c.finalize()
+        assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+        assert c.digest() == oracle.nodes_digest(ref.nodes)
+
+
 def test_push_reads_from_page_locked_memory_skips_the_staging_copy(capi, oracle):
     """dbgk_push_reads from a pinned caller buffer (torch pinned tensor == hipHostMalloc): host-to-device copies come straight
     out of the caller's memory, in several batches; same graph as from pageable memory and as the oracle; the buffer may be

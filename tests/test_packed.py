@@ -71,6 +71,26 @@ def test_host_packer_ranges_of_one_buffer_may_be_packed_independently():
     assert np.array_equal(out, want) and other == want_other
 
 
+def test_host_packer_for_scattered_reads():
+    """dbgk_pack_reads: sequences anywhere in memory, packed back to back from any base position (a reader thread's share)"""
+    capi = _capi()
+    rng = random.Random(3)
+    for first in (0, 3, 16, 29):
+        reads = [bytes(rng.choice(b"ACGTNacgtnRY*") for _ in range(rng.choice([0, 1, 15, 16, 17, 150, 151, 40000]))) for _ in range(40)]
+        flat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+        want, want_other = _pack_numpy(flat, first)
+        out = np.zeros(len(want) + 1, dtype=np.uint32)
+        assert capi.pack_reads(reads, out, first) == want_other
+        assert np.array_equal(out[:len(want)], want), first
+    # two "threads" sharing a boundary word
+    reads = [b"ACGTT" * 7, b"G" * 21, b"TTTTACGT" * 3]
+    flat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    out = np.zeros((len(flat) + 15) // 16, dtype=np.uint32)
+    capi.pack_reads(reads[1:], out, len(reads[0]))
+    capi.pack_reads(reads[:1], out, 0)
+    assert np.array_equal(out, _pack_numpy(flat)[0])
+
+
 def test_oracle_reads_other_bytes_as_A(oracle):
     """the oracle's entry rule (dbg_oracle.c code_of): a byte outside ACGTNacgtn is read as 'A' and counted"""
     noisy = b"ACGTRYKMACGT-*ACGN\xff\x80acgtnACGTACGTACGTAAACCCGGGTTT"

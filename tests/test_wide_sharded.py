@@ -164,7 +164,9 @@ def test_wide_single_handle_table_beyond_2_32_slots_reads_its_input_in_passes_PA
     bases, offsets = oracle.synth_reads(P, 0, n_reads)
     want, total = oracle.wide_build(bases, offsets, k, 250)
     size = capi.find_next_prime_ref(4_400_000_000)
-    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as g:
+    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88) as g:   # n_passes = 0: the plain flow
+        assert g.wide_pass_info()[0] == 1 and g.store_room()[1] == 0, "an unsharded handle that did not ask for passes must not get the pass protocol"
+    with capi.Graph(k=k, table_slots=size, engine=capi.ENGINE_WIDE, expected_kmers=n_reads * 88, n_passes=1) as g:   # "at least one pass, as many as it takes"
         n_passes, _ = g.wide_pass_info()
         assert n_passes == 2
         for p in range(n_passes):
