@@ -157,6 +157,7 @@ SYMBOLS = [
     ("dbgk_comm_link_stats", _i, [_vp, C.c_int32, C.POINTER(LinkStats)]),
     ("dbgk_comm_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_comm_resize", _i, [_vp, _u64]),
+    ("dbgk_comm_export_host_table_links", _i, [_vp, _u64, _vp, _vp, C.c_int32, _vp, _vp, _vp, _u64, C.POINTER(_u64), _vp, _u64, C.POINTER(_u64), _vp]),
     ("dbgk_comm_wide_export_sorted", _i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("dbgk_comm_wide_export_host_table", _i, [_vp, _u64, _vp, _vp]),
     ("dbgk_comm_kfreq_export_counts", _i, [_vp, _u64, _u64, _vp]),
@@ -656,6 +657,21 @@ class Comm:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _chk(lib().dbgk_comm_push_reads(self._c, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "dbgk_comm_push_reads")
+
+    def export_host_table_links(self, host_size, count, cutoff=2):
+        """dbgk_comm_export_host_table_links -> (array, nul_flag, klink u16[size], del_flag, tip slots, branch slots, LinkStats)"""
+        array = np.zeros(host_size, dtype=NODE_DTYPE)
+        flags = np.zeros(host_size // 8 + 1, dtype=np.uint8)
+        klink = np.zeros(host_size, dtype=np.uint16)
+        dele = np.zeros(host_size // 8 + 1, dtype=np.uint8)
+        cap = int(count)
+        tips, branches = np.zeros(max(cap, 1), dtype=np.uint64), np.zeros(max(cap, 1), dtype=np.uint64)
+        nt, nb = C.c_uint64(), C.c_uint64()
+        st = LinkStats()
+        _chk(lib().dbgk_comm_export_host_table_links(self._c, host_size, array.ctypes.data, flags.ctypes.data, cutoff, klink.ctypes.data, dele.ctypes.data,
+                                                     tips.ctypes.data, cap, C.byref(nt), branches.ctypes.data, cap, C.byref(nb), C.byref(st)),
+             "dbgk_comm_export_host_table_links")
+        return array, flags, klink, dele, tips[:nt.value], branches[:nb.value], st
 
     def push_reads_packed(self, packed, offsets, other_bytes=0):
         packed = np.ascontiguousarray(packed, dtype=np.uint32)

@@ -1049,6 +1049,68 @@ extern "C" int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbg
 	return DBGK_OK;
 }
 
+// dbgk_export_host_table_links for the table of a communicator (calculate_kmer_links' first pass, DBG_contig/contig.cpp:107-181,
+// for exactly the table that is handed over).  Slot numbers -- and with them the ascending order of tip_nodes / branch_nodes -- are
+// those of ONE table of host_size slots, so the shards' nodes are first brought together in such a table on the first member's
+// device (a temporary handle: the shard tables travel there in pieces and are merged in, the device counterpart of the re-seating
+// dbgk_comm_export_host_table does on the host when host_size differs from the device table); everything after that is the
+// single-handle export, bit for bit.  Needs host_size * 16 bytes (+ the link arrays) free on that device.
+extern "C" int dbgk_comm_export_host_table_links(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, int32_t kmer_freq_cutoff,
+                                                 uint16_t *klink, uint8_t *del_flag, uint64_t *tip_nodes, uint64_t tip_capacity, uint64_t *n_tips,
+                                                 uint64_t *branch_nodes, uint64_t branch_capacity, uint64_t *n_branches, dbgk_link_stats *stats)
+{
+	if (!c || !array || !nul_flag || !klink || !del_flag || !n_tips || !n_branches || host_size < 3) return DBGK_ERR_ARG;
+	if (!c->finalized || c->wide || c->kfreq) return DBGK_ERR_STATE;
+	dbgk_stats tot;
+	comm_sum_stats(c, &tot);
+	if (tot.count > host_size) return DBGK_ERR_TABLE_FULL;
+	dbgk_config one = c->cfg;
+	one.device_id = c->devices[0];
+	one.engine = DBGK_ENGINE_DIRECT;
+	one.shard_count = one.shard_index = 0;
+	one.table_slots = host_size;
+	one.expected_kmers = 0;
+	one.flags = 0;
+	dbgk_handle *T = nullptr;
+	int rc = dbgk_create(&one, &T);
+	if (rc) return rc;
+	const uint64_t chunk_nodes = 16ull << 20; // 256 MiB of slots at a time when a shard sits on another GPU
+	Node *scratch = nullptr;
+	for (dbgk_handle *S : c->h) {
+		for (uint64_t off = 0; off < S->tslots && rc == DBGK_OK; off += chunk_nodes) {
+			const uint64_t cnt = std::min(chunk_nodes, S->tslots - off);
+			const Node *src = S->table + off;
+			rc = use_device(T);
+			if (rc) break;
+			if (S->device != T->device || c->host_staging) {
+				if (!scratch && hipMalloc(&scratch, chunk_nodes * sizeof(Node)) != hipSuccess) { rc = DBGK_ERR_NOMEM; break; }
+				rc = comm_copy(T, scratch, S, src, cnt * sizeof(Node), T->stream);
+				src = scratch;
+				if (rc) break;
+			}
+			rc = dbgk_merge_nodes(T, reinterpret_cast<const dbgk_node *>(src), cnt); // (empty slots are all-zero entries: they add nothing)
+			if (rc == DBGK_OK) rc = dbgk_sync(T); // the scratch buffer / the shard's memory is read by the kernel just queued
+		}
+		if (rc) break;
+	}
+	if (scratch) {
+		(void)hipSetDevice(T->device);
+		(void)hipFree(scratch);
+	}
+	if (rc == DBGK_OK) rc = dbgk_add_polyA(T, tot.polyA_l_link, tot.polyA_r_link);
+	dbgk_stats st;
+	if (rc == DBGK_OK) rc = dbgk_finalize(T, &st);
+	if (rc == DBGK_OK && st.count != tot.count) {
+		g_last_error = "dbgk_comm_export_host_table_links: the assembled table holds " + std::to_string(st.count) + " nodes, the shards " + std::to_string(tot.count);
+		rc = DBGK_ERR_STATE;
+	}
+	if (rc == DBGK_OK)
+		rc = dbgk_export_host_table_links(T, host_size, array, nul_flag, kmer_freq_cutoff, klink, del_flag, tip_nodes, tip_capacity, n_tips, branch_nodes,
+		                                  branch_capacity, n_branches, stats);
+	dbgk_destroy(T);
+	return rc;
+}
+
 // ---- WIDE communicators: results as 32-byte nodes ----------------------------------------------------------------------
 // all nodes of the job sorted by (kmer_hi, kmer_lo), the key-0 node first; capacity >= stats.count
 extern "C" int dbgk_comm_wide_export_sorted(dbgk_comm *c, dbgk_node32 *out, uint64_t capacity, uint64_t *n_out)

@@ -799,7 +799,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 				free(array), free(nul), free(del);
 				fail(*S, DBGK_ERR_NOMEM, "host table allocation");
 			} else {
-				const bool links = getenv("DBGK_LINKS") && atoi(getenv("DBGK_LINKS")) != 0 && !S->comm;
+				const bool links = getenv("DBGK_LINKS") && atoi(getenv("DBGK_LINKS")) != 0;
 				if (links) { // the consumer's first pass on the device, for exactly this table
 					free(DbgkKmerLinks);
 					DbgkKmerLinks = static_cast<uint16_t *>(malloc(use_size * sizeof(uint16_t)));
@@ -807,10 +807,13 @@ void build_debruijn_graph(vector<string> &reads_files)
 					DbgkBranchNodes.assign(st.count ? st.count : 1, 0);
 					uint64_t nt = 0, nb = 0;
 					const int cutoff = &KmerFreqCutoff ? KmerFreqCutoff : 2;
-					rc = DbgkKmerLinks ? dbgk_export_host_table_links(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul, cutoff, DbgkKmerLinks, del,
-					                                                  DbgkTipNodes.data(), DbgkTipNodes.size(), &nt, DbgkBranchNodes.data(),
-					                                                  DbgkBranchNodes.size(), &nb, NULL)
-					                   : DBGK_ERR_NOMEM;
+					if (!DbgkKmerLinks) rc = DBGK_ERR_NOMEM;
+					else if (S->comm) // several GPU shards: assembled in one table of use_size slots on the first GPU, then the same pass
+						rc = dbgk_comm_export_host_table_links(S->comm, use_size, reinterpret_cast<dbgk_node *>(array), nul, cutoff, DbgkKmerLinks, del,
+						                                       DbgkTipNodes.data(), DbgkTipNodes.size(), &nt, DbgkBranchNodes.data(), DbgkBranchNodes.size(), &nb, NULL);
+					else
+						rc = dbgk_export_host_table_links(S->h, use_size, reinterpret_cast<dbgk_node *>(array), nul, cutoff, DbgkKmerLinks, del,
+						                                  DbgkTipNodes.data(), DbgkTipNodes.size(), &nt, DbgkBranchNodes.data(), DbgkBranchNodes.size(), &nb, NULL);
 					DbgkTipNodes.resize(rc == DBGK_OK ? nt : 0);
 					DbgkBranchNodes.resize(rc == DBGK_OK ? nb : 0);
 					if (rc == DBGK_OK) cerr << "First pass of the contig stage done on the GPU: " << nt << " tip nodes, " << nb << " branching nodes" << endl;

@@ -383,22 +383,52 @@ def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
     return all_sizes, lists
 
 
+def _agree(ok, what, device, group):
+    """every rank learns whether ANY rank failed a local step, so that all of them leave together (a rank that raised alone
+    would leave the others waiting in the next collective): all-reduce (min) of an ok flag, then the same exception everywhere"""
+    flag = torch.tensor([1 if ok is None else 0], dtype=torch.int64, device=device)
+    all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        raise RuntimeError("%s failed on %s" % (what, ("this rank: %s" % ok) if ok is not None else "another rank"))
+
+
 def _hand_offs(g, device, group, wrap, node_bytes):
     """step 4: bucket-overflow observations offered to every rank, the aggregated surplus of heavy hitters broadcast, nodes
     whose probe ran off the end of a shard handed to the next rank (ring).  Overflow observations first: merging them can
-    push further nodes off the end of a shard, so the outgoing lists are read only afterwards."""
+    push further nodes off the end of a shard, so the outgoing lists are read only afterwards.  The ring hand-off is REPEATED
+    until an all-reduce says that nothing moved any more (a node can pass through a shard that is full behind its first slots
+    and leave it again at the far end: dbgk_comm_* does the same); a node still travelling after `world` rounds has been
+    offered to every shard -- the table is full.  Every local failure is turned into an all-reduced flag (_agree): all ranks
+    raise together."""
     on_gpu = torch.device(device).type == "cuda"
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    p_ovf, n_ovf = g.shard_overflow()
+
+    def attempt(fn):
+        try:
+            fn()
+            if on_gpu or hasattr(g, "sync"):
+                g.sync()
+            return None
+        except Exception as e:  # noqa: BLE001 -- reported through _agree on every rank
+            return "%s: %s" % (type(e).__name__, e)
+
+    def fetch(fn, what):
+        """a local read of one of the handle's lists (can fail: a list that overran its capacity) -- agreed on before the collective"""
+        box = {}
+        _agree(attempt(lambda: box.update(v=fn())), what, device, group)
+        return box["v"]
+
+    p_ovf, n_ovf = fetch(g.shard_overflow, "reading the bucket-overflow list")
     ovf_sizes, lists = _gather_lists(p_ovf, n_ovf, node_bytes, device, group, wrap, on_gpu)
     if lists is not None:
-        for src in range(world):
-            if ovf_sizes[src]:
-                g.shard_merge(lists[src].data_ptr(), int(ovf_sizes[src]), is_triple=True)
-        g.sync()
+        def merge_observations():
+            for src in range(world):
+                if ovf_sizes[src]:
+                    g.shard_merge(lists[src].data_ptr(), int(ovf_sizes[src]), is_triple=True)
+        _agree(attempt(merge_observations), "merging the bucket-overflow observations", device, group)
     # the surplus of heavy hitters (beyond a rank's overflow list) sits aggregated in its side table: rare, broadcast whole
-    p_hh, n_hh = g.shard_heavy()
+    p_hh, n_hh = fetch(g.shard_heavy, "reading the heavy-hitter side table")
     sizes = torch.tensor([n_hh], dtype=torch.int64, device=device)
     hh_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     all_gather(hh_sizes, sizes, group=group)
@@ -410,19 +440,25 @@ def _hand_offs(g, device, group, wrap, node_bytes):
             broadcast(buf, src=src, group=group)
             if on_gpu:
                 torch.cuda.synchronize()
-            g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))
-            g.sync()
-    p_out, n_out = g.shard_outgoing()
-    out_sizes, lists = _gather_lists(p_out, n_out, node_bytes, device, group, wrap, on_gpu)
-    handed = int(out_sizes.sum())
-    if lists is not None:
-        prev = (rank - 1) % world
+            _agree(attempt(lambda: g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))), "merging a heavy-hitter side table", device, group)
+    # the ring: what left shard d continues at the first slot of shard d + 1; the outgoing list only grows (it stays valid until
+    # the next reset), so every round ships the entries that were appended since the last one
+    delivered, handed, prev = 0, 0, (rank - 1) % world
+    for rnd in range(world + 1):
+        p_out, n_out = fetch(g.shard_outgoing, "reading the list of nodes that left the shard")
+        fresh = int(n_out) - delivered
+        out_sizes, lists = _gather_lists(int(p_out) + delivered * node_bytes if fresh else p_out, fresh, node_bytes, device, group, wrap, on_gpu)
+        moved = int(out_sizes.sum())   # (the same number on every rank: all of them leave the loop, or fail, together)
+        if moved == 0:
+            break
+        if rnd == world:
+            raise RuntimeError("%d nodes are still looking for a slot after a whole round over all %d shards: the table is full" % (moved, world))
+        handed += moved
+        delivered = int(n_out)
+        err = None
         if out_sizes[prev]:
-            g.shard_merge(lists[prev].data_ptr(), int(out_sizes[prev]), from_previous_shard=True)
-            g.sync()
-            _, n_again = g.shard_outgoing()
-            if n_again != n_out:
-                raise RuntimeError("a handed-over node left the next shard as well: shard (nearly) full")
+            err = attempt(lambda: g.shard_merge(lists[prev].data_ptr(), int(out_sizes[prev]), from_previous_shard=True))
+        _agree(err, "merging the nodes handed over by the previous shard", device, group)
     return int(ovf_sizes.sum()), handed
 
 

@@ -474,6 +474,13 @@ int dbgk_comm_link_stats(dbgk_comm *c, int32_t kmer_freq_cutoff, dbgk_link_stats
 /* the host KmerSet of the whole job (same contract as dbgk_export_host_table): the shards side by side when
  * host_size is the global table size, otherwise every node re-seated on the host                          */
 int dbgk_comm_export_host_table(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
+/* dbgk_export_host_table_links for a communicator: the host table of the whole job AND the consumer's first pass for it (klink,
+ * del_flag, the ascending tip / branch slot lists, DepthStat: contig.cpp:107-181), computed on the device.  The shards' nodes are
+ * first assembled in one table of host_size slots on the first member's device (host_size * 16 bytes must be free there).  Same
+ * arguments, results and (un)pinned parity as dbgk_export_host_table_links.                                                  */
+int dbgk_comm_export_host_table_links(dbgk_comm *c, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag, int32_t kmer_freq_cutoff,
+                                      uint16_t *klink, uint8_t *del_flag, uint64_t *tip_nodes, uint64_t tip_capacity, uint64_t *n_tips,
+                                      uint64_t *branch_nodes, uint64_t branch_capacity, uint64_t *n_branches, dbgk_link_stats *stats);
 /* cfg->engine == DBGK_ENGINE_WIDE (k <= 63, expected_kmers > 0 = what EACH member extracts): n slot-range shards of one table of
  * 32-byte nodes; the reads stream through once (a geometry that needs several passes is refused: drive the handles yourself with
  * dbgk_wide_begin_pass), the record stores are built at dbgk_comm_finalize.  Results of the whole job:                          */

@@ -255,8 +255,8 @@ def test_cli_k_above_32_emits_the_128_bit_graph_PARITY_UNPINNED(tmp_path, k, env
     assert [int(x.split("\t")[1]) for x in rows[1:]] == depth[1:]
 
 
-@pytest.mark.parametrize("name,cutoff", [("mixed150_k31", 2), ("saturate_k31", 5), ("fastq_gz_k31", 0)])
-def test_cli_first_pass_of_the_contig_stage_on_the_gpu_PARITY_UNPINNED(tmp_path, oracle, name, cutoff):
+@pytest.mark.parametrize("name,cutoff,gpus", [("mixed150_k31", 2, ""), ("saturate_k31", 5, ""), ("fastq_gz_k31", 0, ""), ("mixed150_k31", 2, "0,0,0")])
+def test_cli_first_pass_of_the_contig_stage_on_the_gpu_PARITY_UNPINNED(tmp_path, oracle, name, cutoff, gpus):
     """DBGK_LINKS=1: build_debruijn_graph() hands over, with the table, what calculate_kmer_links (contig.cpp:107-181) would
     compute from it -- KmerLink records, del_flag, tip / branch lists in slot order (dbgk_export_host_table_links) -- checked
     against the restatement of those lines applied to the table image the CLI wrote (parity unpinned: contig.cpp needs Boost)"""
@@ -267,6 +267,8 @@ def test_cli_first_pass_of_the_contig_stage_on_the_gpu_PARITY_UNPINNED(tmp_path,
     libf.write_text("\n".join(case_files(case)) + "\n")
     img, lk, prefix = tmp_path / "table.img", tmp_path / "links.txt", tmp_path / "out"
     env = dict(os.environ, DBGK_LINKS="1", DBGK_DUMP_TABLE=str(img), DBGK_DUMP_LINKS=str(lk))
+    if gpus:   # three GPU shards of one table: dbgk_comm_export_host_table_links
+        env["DBGK_GPU_LIST"] = gpus
     cmd = [CLI, "-k", str(p["k"]), "-r", str(p["max_read_len"]), "-f", str(p["fmt"]), "-t", "4", "-i", repr(p["init_hash_size"]),
            "-l", repr(p["load_factor"]), "-e", str(p["max_double"]), "-b", str(p["buffer_num"]), "-D", str(cutoff), "-o", str(prefix), str(libf)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -782,6 +782,38 @@ def test_export_with_the_consumers_first_pass_on_the_device_PARITY_UNPINNED(capi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_shards,staging", [(2, False), (3, True)])
+def test_comm_export_with_the_consumers_first_pass_PARITY_UNPINNED(capi, oracle, n_shards, staging, monkeypatch):
+    """dbgk_comm_export_host_table_links: the table of a communicator AND calculate_kmer_links' first pass for it (contig.cpp:107-181),
+    slot numbers those of the ONE host table: against the restatement applied to the exported table itself, slot for slot, and the
+    node multiset against the oracle (parity of the link records unpinned: contig.cpp needs Boost)"""
+    if staging:
+        monkeypatch.setenv("DBGK_COMM_HOST_STAGING", "1")
+    rng = random.Random(40 + n_shards)
+    reads = rand_reads(rng, 3000, G=20000) + [b"A" * 150] * 300 + [b"T" * 90] * 40
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    for host_size in (capi.find_next_prime_ref(3 * ref.count), size):
+        with capi.Comm(k=31, table_slots=size, devices=[0] * n_shards, expected_kmers=len(bases), max_batch_bases=1 << 18) as c:
+            c.push_reads(bases, offsets)
+            st = c.finalize()
+            assert st.count == ref.count
+            array, flags, klink, dele, tips, branches, ls = c.export_host_table_links(host_size, st.count, cutoff=2)
+        assert oracle.check_host_table(array, flags, host_size, st.count) == 0
+        occ = np.unpackbits(flags)[:host_size].astype(bool)
+        assert np.array_equal(np.sort(array[occ], order="kmer"), ref.nodes)
+        want_rec, want_del, want_tips, want_branches = oracle.kmer_links(array, flags, 2)
+        assert np.array_equal(klink, want_rec) and np.array_equal(dele, want_del)
+        assert np.array_equal(tips, want_tips) and np.array_equal(branches, want_branches)
+        want = oracle.link_stats(array[occ], 2)
+        assert list(ls.depth_stat) == list(want.depth_stat) and (ls.total_nodes, ls.tip_nodes, ls.branch_nodes) == (want.total_nodes, len(tips), len(branches))
+        if host_size == size:
+            break   # (the 67 M-slot host table once is enough)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards,staging", [(2, False), (3, True)])
 def test_comm_resize_across_shards_and_host_staged_copies(capi, oracle, n_shards, staging, monkeypatch):
     """dbgk_comm_resize: the table of a communicator enlarged mid-stream (enlarge_kmerset_parallel, kmerSet.cpp:132-189, for a
     table that lives on several GPUs): every node re-seated into the shard that owns its new home slot, totals and key-0 links

@@ -677,3 +677,96 @@ def test_a_truncated_exchange_fails_loudly_on_every_rank():
         assert p.exitcode == 0
     assert "differ from what was sent" in results[1] and "[0]" in results[1]
     assert "differ from what was sent" in results[0] and "seen by another rank" in results[0]
+
+
+# ---- the ring hand-off protocol and its failure agreement (multigpu._hand_offs) --------------------------------------------
+class _RingGraph:
+    """a scripted shard: node v settles in shard v % world and passes through every other one (it is appended to that shard's
+    outgoing list again), the way a node passes through a shard that is full behind its first slots; `fail_on_merge`: the
+    first merge on this rank raises; `never_settle`: every node passes through every shard (a full table)"""
+
+    def __init__(self, rank, world, start, fail_on_merge=False, never_settle=False):
+        self.rank, self.world = rank, world
+        self.out = np.zeros(64, NODE)
+        self.n_out = 0
+        self.kept = []
+        self.fail, self.never = fail_on_merge, never_settle
+        for v in start:
+            self._leave(v)
+
+    def _leave(self, v):
+        self.out[self.n_out] = (v, 7, 9)
+        self.n_out += 1
+
+    def shard_overflow(self):
+        return 0, 0
+
+    def shard_heavy(self):
+        return 0, 0
+
+    def shard_outgoing(self):
+        return self.out.ctypes.data, self.n_out
+
+    def shard_merge(self, ptr, n, is_triple=False, from_previous_shard=False):
+        assert from_previous_shard and not is_triple
+        if self.fail:
+            raise ValueError("scripted failure on rank %d" % self.rank)
+        got = np.frombuffer((C.c_uint8 * (int(n) * 16)).from_address(int(ptr)), dtype=NODE)
+        for v in got["kmer"].tolist():
+            if not self.never and v % self.world == self.rank:
+                self.kept.append(v)
+            else:
+                self._leave(v)
+
+    def sync(self):
+        pass
+
+
+def _ring_worker(rank, world, port, scenario, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dbg_assembly_amd.multigpu import _hand_offs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start = [rank * 100 + i for i in range(1, 6)]
+    g = _RingGraph(rank, world, start, fail_on_merge=(scenario == "fail" and rank == 1), never_settle=(scenario == "full"))
+    try:
+        n_ovf, handed = _hand_offs(g, "cpu", None, _wrap_host, 16)
+        q.put((rank, "ok", handed, sorted(g.kept)))
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e), []))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["settle", "fail", "full"])
+def test_ring_hand_off_repeats_until_nothing_moves_and_all_ranks_fail_together(scenario):
+    """the hand-off of nodes that ran off the end of a shard: repeated until an all-reduce says nothing moved (a node may pass
+    through several shards); a failure on ONE rank, or nodes that never settle (full table), make EVERY rank raise -- nobody
+    is left waiting in a collective"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if scenario == "settle":
+        assert all(r[1] == "ok" for r in res)
+        everything = sorted(v for r in range(world) for v in [r * 100 + i for i in range(1, 6)])
+        assert sorted(v for r in res for v in r[3]) == everything
+        assert all(v % world == r[0] for r in res for v in r[3])
+        # node v starts as "left shard s": it is delivered to s + 1, s + 2, ... until it reaches shard v % world
+        hops = sum(((v % world - (s + 1)) % world) + 1 for s in range(world) for v in [s * 100 + i for i in range(1, 6)])
+        assert all(r[2] == hops for r in res)
+    else:
+        assert all(r[1] == "raised" for r in res), res
+        if scenario == "fail":
+            assert sum("this rank" in r[2] for r in res) == 1 and sum("another rank" in r[2] for r in res) == 2
+        else:
+            assert all("the table is full" in r[2] for r in res)
