@@ -54,6 +54,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 CONFIGS = {"cfg2": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, table_slots=600_000_000, synth_cfg=2,
                         workload="cfg2: synthetic 10 M x 150 bp reads per GPU (30x of 50 Mb/GPU genome, 0.5% subst, 0.01% N), k=31"),
+           "cfg2t": dict(reads_per_gpu=10_000_000, genome_per_gpu=50_000_000, table_slots=600_000_000, synth_cfg=2, trimmed=True,
+                         workload="cfg2t: cfg2's reads with MIXED lengths -- 30 % of the 10 M reads trimmed to a length uniform in [60, 149] (quality-trimmed "
+                                  "input as debruijn_contig really gets it; dbg_assembly_amd/workloads.py), k=31"),
            "cfg5": dict(reads_per_gpu=75_000_000, genome_per_gpu=375_000_000, table_slots=1_600_000_000, synth_cfg=5, kmer=63, sub_rate=0.001,
                         workload="cfg5 share of one GPU: synthetic 75 M x 150 bp reads (30x of 375 Mb; the stated job is 600 M reads of a 3 Gb "
                                  "genome on 8 GPUs), 0.1% subst, 0.01% N, k=63, 128-bit keys, 32-byte nodes (WIDE engine, PARITY UNPINNED: the "
@@ -71,7 +74,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)   # (the first steps run before the clocks have settled: 14.9 against 14.4 ms with one warm-up step)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg2t", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 (default, the weak-scaling line): BASELINE configs[1] PER GPU -- 10 M x 150 bp reads, 50 Mb of genome "
                          "and 600 M table slots per GPU; cfg3: BASELINE configs[2] split over the GPUs that are there -- 25 M reads, "
                          "125 Mb of genome and 1.075 G slots per GPU, i.e. at N = 8 the stated job: 200 M reads of a 1 Gb genome "
@@ -662,6 +665,18 @@ def run_graph(args, ctx, brief=False):
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0,
                    n_passes=args.passes if wide_sharded else 0)
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
+    if CONFIGS[args.config].get("trimmed"):   # mixed lengths: the reads are trimmed on the host once (setup, untimed) and go back to the device
+        import numpy as np
+        from dbg_assembly_amd import workloads
+        t_bases, t_off = workloads.trim_reads(d_bases.to_host(np.uint8, nb), 150, workloads.trimmed_lengths(rank * n_reads, n_reads, 150))
+        d_bases.free()
+        d_off.free()
+        nb = len(t_bases)
+        d_bases, d_off = g.malloc(nb + 64), g.malloc(t_off.nbytes)
+        d_bases.from_host(t_bases)
+        d_off.from_host(t_off)
+        kpr = float(np.maximum(t_off[1:] - t_off[:-1], args.kmer - 1).sum() - (args.kmer - 1) * n_reads) / n_reads   # mean windows per read
+        del t_bases, t_off
     packed_in = args.input == "packed"
     d_packed = g.pack_bases_device(d_bases.ptr, nb) if packed_in else None  # ... as 2-bit blocks ("packed read blocks")
     g.sync()
@@ -686,14 +701,14 @@ def run_graph(args, ctx, brief=False):
         push(g)
         if debug_mode:  # level-1 timing experiments leave garbage records: never run the later phases on them
             g.sync()
-            return {"stored_kmers": n_reads * kpr, "count": 0}
+            return {"stored_kmers": int(n_reads * kpr), "count": 0}
         if debug_l2:    # level-2 timing experiment: the library refuses to build regions afterwards
             try:
                 g.finalize()
             except capi.DbgkError:
                 pass
             g.sync()
-            return {"stored_kmers": n_reads * kpr, "count": 0}
+            return {"stored_kmers": int(n_reads * kpr), "count": 0}
         if sharded:
             return sharded_finalize(g, device, exchange_chunks=args.exchange_chunks, verify_exchange=state["verify"])
         st = g.finalize()
@@ -823,8 +838,8 @@ def run_graph(args, ctx, brief=False):
     rccl = rccl_record(ctx, args)
     out = None
     if rank == 0:
-        kmers_step = n_reads * kpr
-        base_bytes = (150.0 / kpr) / (4.0 if packed_in else 1.0)   # bases per k-mer as they are read from HBM
+        kmers_step = int(round(n_reads * kpr))
+        base_bytes = (float(nb) / kmers_step) / (4.0 if packed_in else 1.0)   # bases per k-mer as they are read from HBM
         # Per-kernel figures (HIP events on the library's own streams), each kernel with ITS OWN bytes:
         # level 1 reads the bases and writes one 8-byte record per k-mer, level 2 reads and writes every
         # record, the region build reads every record and writes every 16-byte table slot once.
@@ -868,7 +883,7 @@ def run_graph(args, ctx, brief=False):
             "data": "synthetic",
             "config": {"workload": CONFIGS[args.config]["workload"],
                        "input": "reads resident in HBM as 2-bit packed blocks (16 bases per 32-bit word) + 64-bit offsets" if packed_in else "reads resident in HBM as ASCII bytes + 64-bit offsets",
-                       "reads_per_gpu": n_reads, "kmers_per_gpu": n_reads * kpr, "table_slots": size,
+                       "reads_per_gpu": n_reads, "kmers_per_gpu": kmers_step, "bases_per_gpu": nb, "table_slots": size,
                        "nodes": res["count"], "engine": {capi.ENGINE_PARTITION: "partition", capi.ENGINE_WIDE: "wide"}.get(args.engine, "direct"),
                        "parallelism": ("reads sharded by record x%d, k-mers owned by slot range of one global table "
                                        "(all-to-all of level-1 record buckets)" % world) if sharded else

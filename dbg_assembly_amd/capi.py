@@ -28,6 +28,7 @@ NODE32_DTYPE = np.dtype([("kmer_hi", "<u8"), ("kmer_lo", "<u8"), ("l_link", "<u4
 OK, ERR_ARG, ERR_HIP, ERR_TABLE_FULL, ERR_STATE, ERR_NOMEM, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 ENGINE_AUTO, ENGINE_DIRECT, ENGINE_PARTITION, ENGINE_KFREQ, ENGINE_SEEDIDX, ENGINE_WIDE = 0, 1, 2, 3, 4, 5
 FLAG_TRACK_FIRST_SEEN = 1
+FLAG_PREALLOC_STAGING = 2
 
 
 class SynthParams(C.Structure):
@@ -72,7 +73,7 @@ class Timings(C.Structure):
     _fields_ = [("mark_ms", C.c_float), ("insert_ms", C.c_float), ("partition_ms", C.c_float),
                 ("build_ms", C.c_float), ("fixup_ms", C.c_float), ("finalize_ms", C.c_float),
                 ("insert_launches", C.c_uint64), ("l2_build_wall_ms", C.c_float), ("partition_launches", C.c_uint32),
-                ("uniform_launches", C.c_uint32), ("reserved32", C.c_uint32), ("reserved", C.c_uint64 * 1)]
+                ("uniform_launches", C.c_uint32), ("prefix_launches", C.c_uint32), ("reserved", C.c_uint64 * 1)]
 
 
 class DbgkError(RuntimeError):

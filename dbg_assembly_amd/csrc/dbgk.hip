@@ -99,6 +99,17 @@ struct dbgk_handle {
 	// bitmaps for the device-pointer path
 	uint32_t *dev_start = nullptr, *dev_dead = nullptr;
 	uint64_t dev_bits_words = 0;
+	// level 1 for reads of any lengths (k_extract_scatter_prefix): the per-read lane prefix of the current batch, and the
+	// 2-bit form of a batch that came as ASCII.  One set per handle: batches follow each other on one stream.
+	ReadLanes *pf_ent = nullptr;
+	uint32_t *pf_tile_first = nullptr;
+	PrefixTile *pf_tiles = nullptr;
+	unsigned long long *pf_bsum = nullptr;
+	PrefixTotals *pf_tot = nullptr;
+	uint64_t pf_cap_reads = 0, pf_cap_tiles = 0;
+	uint32_t *pf_packed = nullptr;
+	uint64_t pf_packed_words = 0;
+	uint32_t prefix_launches = 0;
 
 	bool finalized = false;
 	uint64_t total_reads = 0;
@@ -322,6 +333,9 @@ static void free_wide_partition(dbgk_handle *h)
 
 static void free_handle(dbgk_handle *h)
 {
+	for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum, (void *)h->pf_tot, (void *)h->pf_packed})
+		if (q) (void)hipFree(q);
+
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	if (h->stream2) (void)hipStreamSynchronize(h->stream2); // region builds of an unfinished ranged finalize
@@ -978,13 +992,15 @@ static int setup_partition(dbgk_handle *h)
 	return DBGK_OK;
 }
 
+static int ensure_slot(dbgk_handle *h, StageSlot &s);
+
 extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 {
 	if (!cfg || !out) return DBGK_ERR_ARG;
 	*out = nullptr;
 	const bool wide = cfg->engine == DBGK_ENGINE_WIDE;
 	if (cfg->kmer_size < 1 || cfg->kmer_size > (wide ? 63 : 32)) return DBGK_ERR_ARG; // 64-bit keys: the reference's "max 31" (+32, main.cpp:100); WIDE: 128-bit keys
-	if (wide && cfg->flags) return DBGK_ERR_ARG;
+	if (wide && (cfg->flags & ~DBGK_FLAG_PREALLOC_STAGING)) return DBGK_ERR_ARG;
 	if (cfg->max_read_len < cfg->kmer_size) return DBGK_ERR_ARG;
 	const bool kfreq = cfg->engine == DBGK_ENGINE_KFREQ;
 	if (kfreq && cfg->kmer_size > 18) return DBGK_ERR_ARG; // 4^18 bytes = 64 GiB
@@ -1102,6 +1118,11 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	}
 	int rc = reset_state(h);
 	if (rc != DBGK_OK) return fail(rc);
+	if (cfg->flags & DBGK_FLAG_PREALLOC_STAGING)
+		for (StageSlot &sl : h->slots) {
+			rc = ensure_slot(h, sl);
+			if (rc != DBGK_OK) return fail(rc);
+		}
 	if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(DBGK_ERR_HIP);
 	*out = h;
 	return DBGK_OK;
@@ -1366,6 +1387,38 @@ static int wide_uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t
 	return 1;
 }
 
+// scratch of the prefix form for a batch of n_reads reads / n_bases bases (grown as needed; the stream is idle when it grows)
+static int ensure_prefix_scratch(dbgk_handle *h, uint64_t n_reads, uint64_t n_bases, bool need_packed)
+{
+	const uint64_t tiles = (n_bases / 15 + n_reads) / kL1Threads + 2; // a read of W windows has at most W / 15 + 1 lanes
+	if (n_reads > h->pf_cap_reads || tiles > h->pf_cap_tiles) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum})
+			if (q) (void)hipFree(q);
+		h->pf_ent = nullptr; h->pf_tile_first = nullptr; h->pf_tiles = nullptr; h->pf_bsum = nullptr;
+		h->pf_cap_reads = h->pf_cap_tiles = 0;
+		const uint64_t cr = std::max(n_reads, h->cap_reads), ct = std::max(tiles, (h->cap_bases / 15 + h->cap_reads) / kL1Threads + 2);
+		const uint64_t blocks = (cr + kPrefixBlock * kPrefixItems - 1) / (kPrefixBlock * kPrefixItems) + 1;
+		if (hipMalloc(&h->pf_ent, cr * sizeof(ReadLanes)) != hipSuccess || hipMalloc(&h->pf_tile_first, (ct + 1) * 4) != hipSuccess ||
+		    hipMalloc(&h->pf_tiles, ct * sizeof(PrefixTile)) != hipSuccess || hipMalloc(&h->pf_bsum, blocks * 8) != hipSuccess)
+			return DBGK_ERR_NOMEM;
+		h->pf_cap_reads = cr;
+		h->pf_cap_tiles = ct;
+	}
+	if (!h->pf_tot && hipMalloc(&h->pf_tot, sizeof(PrefixTotals)) != hipSuccess) return DBGK_ERR_NOMEM;
+	const uint64_t words = (n_bases + 15) / 16 + 16;
+	if (need_packed && words > h->pf_packed_words) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (h->pf_packed) (void)hipFree(h->pf_packed);
+		h->pf_packed = nullptr;
+		h->pf_packed_words = 0;
+		const uint64_t cw = std::max(words, h->cap_bases / 16 + 16);
+		if (hipMalloc(&h->pf_packed, cw * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		h->pf_packed_words = cw;
+	}
+	return DBGK_OK;
+}
+
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
                         int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */,
@@ -1400,8 +1453,26 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		return wrec ? wide_uniform_mode(h, uniform_len, n_reads, n_bases, has_long, WU) : uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15, lin8, lin12);
 	};
 	const bool may_skip_bits = (h->part && !h->seed) || wrec;
-	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) umode = decide_umode();
-	if (may_skip_bits && (umode > 0 || umode < 0)) {
+	// The PREFIX form of level 1 (k_extract_scatter_prefix: every read exactly the lanes its windows need, reads of any lengths,
+	// trimmed ones included) takes what would otherwise go through the flat kernel -- a fifth of whose positions straddle a
+	// read boundary at 150 bases and k = 31 -- and the batches of the ragged form as well; not with many level-1 buckets (the
+	// linear forms), not for reads of more than 4 M windows.  DBGK_L1_PREFIX=0 switches it off (ragged / flat as before).
+	const int prefix_env = getenv("DBGK_L1_PREFIX") ? atoi(getenv("DBGK_L1_PREFIX")) : -1; // (read per batch: tests switch it)
+	bool use_prefix = false;
+	auto prefix_wanted = [&](int um) {
+		static const bool flat_only = getenv("DBGK_L1_FLAT") != nullptr;
+		static const bool dbg = getenv("DBGK_DEBUG_MODE") != nullptr;
+		const int force_lin = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
+		if (!h->part || h->seed || wrec || flat_only || dbg || prefix_env == 0) return false;
+		if (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u)) return false;
+		if (len_max > (uint64_t)kPrefixMaxW || n_bases / 15 + n_reads >= (1ull << 32)) return false;
+		return um == 0 || um == 2; // (measured on cfg2t, level 1 per step: prefix 5.32 ms, ragged 5.72, flat 6.05 + 0.14 of bitmaps: profiles/r04_cfg2t_level1_forms_ab.json)
+	};
+	if (may_skip_bits && has_long >= 0 && uniform_len >= 0) {
+		umode = decide_umode();
+		use_prefix = prefix_wanted(umode);
+	}
+	if (may_skip_bits && (umode > 0 || umode < 0 || use_prefix)) {
 		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases, h->cfg.kmer_size,
 		                   h->cfg.max_read_len, (uint32_t *)nullptr, (uint32_t *)nullptr, h->d_ctr, 1); // statistics only
 	} else {
@@ -1422,7 +1493,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	}
 	if (may_skip_bits && umode < 0) {
 		umode = decide_umode();
-		if (umode == 0) { // the general kernel after all: it needs the bitmaps
+		use_prefix = prefix_wanted(umode);
+		if (umode == 0 && !use_prefix) { // the general kernel after all: it needs the bitmaps
 			rc = mark_bits(0);
 			if (rc) return rc;
 			HIPCHK(hipGetLastError());
@@ -1473,6 +1545,37 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL(k_extract_count<true>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
 		else
 			hipLaunchKernelGGL(k_extract_count<false>, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, rb, reinterpret_cast<uint32_t *>(h->counts));
+	} else if (h->part && use_prefix) {
+		// lane prefix of the batch (three short kernels over the offsets), the batch itself as 2-bit words, then level 1
+		h->prefix_launches++;
+		rc = ensure_prefix_scratch(h, n_reads, n_bases, d_packed == nullptr);
+		if (rc) return rc;
+		if (!d_packed) {
+			hipLaunchKernelGGL(k_pack_bases, dim3(grid_for(h, n_chunks)), dim3(kBlock), 0, h->stream, d_bases, n_bases, h->pf_packed, h->d_ctr);
+			rb.packed = h->pf_packed;
+		}
+		const uint32_t W_max = (uint32_t)std::min<uint64_t>(len_max, (uint64_t)h->cfg.max_read_len) >= (uint32_t)h->cfg.kmer_size
+		                           ? (uint32_t)std::min<uint64_t>(len_max, (uint64_t)h->cfg.max_read_len) - (uint32_t)h->cfg.kmer_size + 1u : 1u;
+		const bool pc15 = (W_max + 14u) / 15u * 15u - W_max < (W_max + 15u) / 16u * 16u - W_max; // 15 or 16 windows per lane: fewer empty slots for a full-length read
+		const uint32_t n_blocks = (uint32_t)((n_reads + kPrefixBlock * kPrefixItems - 1) / (kPrefixBlock * kPrefixItems));
+		const uint32_t tiles_max = (uint32_t)std::min<uint64_t>((n_bases / 15 + n_reads) / kL1Threads + 1, h->pf_cap_tiles);
+		const int wide = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0);
+		const int grid_p = (int)((uint64_t)h->n_cu * l1_wgs_per_cu());
+#define DBGK_LAUNCH_PREFIX(WIDE, CC)                                                                                                              \
+	do {                                                                                                                                          \
+		hipLaunchKernelGGL((k_prefix_count<CC>), dim3(n_blocks), dim3(kPrefixBlock), 0, h->stream, d_offsets, n_reads, (uint32_t)h->cfg.kmer_size,   \
+		                   (uint32_t)h->cfg.max_read_len, h->pf_bsum);                                                                            \
+		hipLaunchKernelGGL(k_prefix_blocks, dim3(1), dim3(kPrefixBlock), 0, h->stream, h->pf_bsum, n_blocks, h->pf_tot);                          \
+		hipLaunchKernelGGL((k_prefix_emit<CC>), dim3(n_blocks), dim3(kPrefixBlock), 0, h->stream, d_offsets, n_reads, (uint32_t)h->cfg.kmer_size,    \
+		                   (uint32_t)h->cfg.max_read_len, h->pf_bsum, h->pf_ent, h->pf_tile_first, h->d_ctr);                                     \
+		hipLaunchKernelGGL((k_prefix_tiles<CC>), dim3((tiles_max + 255) / 256), dim3(256), 0, h->stream, h->pf_ent, h->pf_tile_first, h->pf_tot,    \
+		                   (uint32_t)h->cfg.kmer_size, n_bases, h->pf_tiles);                                                                     \
+		hipLaunchKernelGGL((k_extract_scatter_prefix<WIDE, CC>), dim3(grid_p), dim3(kL1Threads), sizeof(PrefixLds), h->stream, rb, h->pf_ent,       \
+		                   h->pf_tiles, h->pf_tot, h->geom, h->store, h->d_ctr);                                                                  \
+	} while (0)
+		if (pc15) { if (wide == 2) DBGK_LAUNCH_PREFIX(2, 15); else if (wide == 1) DBGK_LAUNCH_PREFIX(1, 15); else DBGK_LAUNCH_PREFIX(0, 15); }
+		else { if (wide == 2) DBGK_LAUNCH_PREFIX(2, 16); else if (wide == 1) DBGK_LAUNCH_PREFIX(1, 16); else DBGK_LAUNCH_PREFIX(0, 16); }
+#undef DBGK_LAUNCH_PREFIX
 	} else if (h->part && umode > 0) {
 		h->uniform_launches++;
 		const int wide = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // (direct blocks: the 64-bit slot path)
@@ -3728,6 +3831,7 @@ extern "C" int dbgk_get_timings(dbgk_handle *h, dbgk_timings *out)
 	out->l2_build_wall_ms = h->phase_ms[PH_L2_BUILD_WALL];
 	out->partition_launches = h->partition_launches;
 	out->uniform_launches = h->uniform_launches;
+	out->prefix_launches = h->prefix_launches;
 	return DBGK_OK;
 }
 
@@ -3738,6 +3842,7 @@ extern "C" int dbgk_reset_timings(dbgk_handle *h)
 	h->insert_launches = 0;
 	h->partition_launches = 0;
 	h->uniform_launches = 0;
+	h->prefix_launches = 0;
 	return DBGK_OK;
 }
 

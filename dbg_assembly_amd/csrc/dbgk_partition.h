@@ -1104,6 +1104,317 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	}
 }
 
+// ---- level 1 for reads of ANY lengths: lanes follow a per-read lane prefix --------------------------------------------------
+// What debruijn_contig is really fed are quality-trimmed, corrected reads of mixed lengths (the reference's own recorded run: mean
+// 243 of 250, test/02.build_contig/Ecoli_corrected_reads.contig.log:437-438).  The equal-length kernel above maps lanes to chunks of
+// VALID windows by arithmetic; its RAGGED form gives every read the lane count of the longest one.  Here read r gets exactly
+// Q_r = ceil(W_r / C) lanes, W_r = max(0, min(len_r, maxReadLen) - k + 1) windows (trimmed reads included), and a short pre-pass
+// turns the offsets into what the tiles need:
+//   k_prefix_count   v_r = (Q_r > 0) << 32 | Q_r summed per block of 4096 reads
+//   k_prefix_blocks  exclusive scan of the block sums (one workgroup), totals
+//   k_prefix_emit    per read with windows: ReadLanes {first base, first lane, windows} into a COMPACT list; tile_first[T] = the entry
+//                    that covers lane 1024 * T
+//   k_prefix_tiles   per tile: the 16-aligned start and the packed words of its byte range, its first entry
+// The level-1 kernel then finds a lane's read with a 1024-bit "an entry starts at this lane" bitmap in LDS (popcount prefix), takes the
+// read's start and windows from two small LDS arrays, and funnels its window out of the tile's packed words exactly like the
+// equal-length kernel.  The input is always 2-bit PACKED (ASCII batches are packed first, k_pack_bases).  A tile whose byte range
+// does not fit the LDS image (reads without a window in between, trimmed tails of long reads) reads its words from global memory.
+struct ReadLanes {
+	uint64_t start;   // first base of the read in the batch
+	uint32_t lane0;   // its first lane (global lane index of the batch)
+	uint32_t W;       // its windows
+};
+struct PrefixTile {
+	uint64_t B0;       // first base of the tile's byte range (a multiple of 16)
+	uint64_t base0;    // start of the tile's first entry: the LDS entries hold starts relative to it
+	uint32_t n_words;  // packed words of the range; 0 = does not fit the LDS image: lanes read global memory
+	uint32_t e0;       // first entry
+	uint32_t cc0;      // chunk of the tile's first lane inside its read (the read may have begun in an earlier tile)
+	uint32_t pad;
+};
+struct PrefixTotals {
+	unsigned long long n_lanes, n_entries;
+};
+constexpr int kPrefixBlock = 1024, kPrefixItems = 4; // reads per workgroup of the pre-pass: 4096
+constexpr uint32_t kPrefixMaxW = (1u << 22) - 2u;    // windows of one read the LDS entry format can say (longer reads: the flat kernel)
+
+__device__ __forceinline__ uint32_t prefix_windows(const uint64_t *__restrict__ offsets, uint64_t r, uint32_t k, uint32_t max_read_len)
+{
+	const uint64_t len = offsets[r + 1] - offsets[r], rl = len > max_read_len ? max_read_len : len;
+	return rl >= k ? (uint32_t)(rl - k + 1u) : 0u;
+}
+
+template <int C>
+__global__ __launch_bounds__(kPrefixBlock) void k_prefix_count(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t k, uint32_t max_read_len,
+                                                               unsigned long long *__restrict__ bsum)
+{
+	__shared__ unsigned long long red[kPrefixBlock / 64];
+	const uint64_t first = ((uint64_t)blockIdx.x * kPrefixBlock + threadIdx.x) * kPrefixItems;
+	unsigned long long v = 0;
+#pragma unroll
+	for (int j = 0; j < kPrefixItems; j++)
+		if (first + j < n_reads) {
+			const uint32_t W = prefix_windows(offsets, first + j, k, max_read_len), Q = (W + (uint32_t)C - 1u) / (uint32_t)C;
+			v += (unsigned long long)Q | ((unsigned long long)(Q ? 1u : 0u) << 32);
+		}
+	const unsigned long long s = block_sum_n<kPrefixBlock>(v, red);
+	if (threadIdx.x == 0) bsum[blockIdx.x] = s;
+}
+
+// exclusive scan of the block sums in place (n_blocks may exceed one workgroup: chunks with a carry); totals
+__global__ __launch_bounds__(kPrefixBlock) void k_prefix_blocks(unsigned long long *__restrict__ bsum, uint32_t n_blocks, PrefixTotals *__restrict__ tot)
+{
+	__shared__ unsigned long long wave_tot[kPrefixBlock / 64];
+	__shared__ unsigned long long carry;
+	const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+	if (t == 0) carry = 0ull;
+	__syncthreads();
+	for (uint32_t base = 0; base < n_blocks; base += kPrefixBlock) {
+		const uint32_t i = base + (uint32_t)t;
+		const unsigned long long v = i < n_blocks ? bsum[i] : 0ull;
+		unsigned long long inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned long long n = __shfl_up(inc, off, 64);
+			if (lane >= off) inc += n;
+		}
+		if (lane == 63) wave_tot[wave] = inc;
+		__syncthreads();
+		unsigned long long before = carry;
+		for (int w = 0; w < wave; w++) before += wave_tot[w];
+		if (i < n_blocks) bsum[i] = before + inc - v;
+		__syncthreads();
+		if (t == kPrefixBlock - 1) carry = before + inc;
+		__syncthreads();
+	}
+	if (t == 0) {
+		tot->n_lanes = carry & 0xFFFFFFFFull;
+		tot->n_entries = carry >> 32;
+	}
+}
+
+template <int C>
+__global__ __launch_bounds__(kPrefixBlock) void k_prefix_emit(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t k, uint32_t max_read_len,
+                                                              const unsigned long long *__restrict__ bsum, ReadLanes *__restrict__ ent,
+                                                              uint32_t *__restrict__ tile_first, Counters *__restrict__ ctr)
+{
+	__shared__ unsigned long long wave_tot[kPrefixBlock / 64];
+	const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+	const uint64_t first = ((uint64_t)blockIdx.x * kPrefixBlock + threadIdx.x) * kPrefixItems;
+	uint32_t W[kPrefixItems];
+	unsigned long long v = 0;
+#pragma unroll
+	for (int j = 0; j < kPrefixItems; j++) {
+		W[j] = first + j < n_reads ? prefix_windows(offsets, first + j, k, max_read_len) : 0u;
+		const uint32_t Q = (W[j] + (uint32_t)C - 1u) / (uint32_t)C;
+		v += (unsigned long long)Q | ((unsigned long long)(Q ? 1u : 0u) << 32);
+	}
+	unsigned long long inc = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const unsigned long long n = __shfl_up(inc, off, 64);
+		if (lane >= off) inc += n;
+	}
+	if (lane == 63) wave_tot[wave] = inc;
+	__syncthreads();
+	unsigned long long run = bsum[blockIdx.x] + inc - v;
+	for (int w = 0; w < wave; w++) run += wave_tot[w];
+	bool too_long = false;
+#pragma unroll
+	for (int j = 0; j < kPrefixItems; j++) {
+		const uint32_t Q = (W[j] + (uint32_t)C - 1u) / (uint32_t)C;
+		if (Q) {
+			const uint32_t lane0 = (uint32_t)run, e = (uint32_t)(run >> 32);
+			ent[e] = ReadLanes{offsets[first + j], lane0, W[j]};
+			too_long = too_long || W[j] > kPrefixMaxW;
+			// the tiles whose first lane belongs to this read
+			for (uint32_t T = (lane0 + (uint32_t)kL1Threads - 1u) / (uint32_t)kL1Threads; (uint64_t)T * kL1Threads < (uint64_t)lane0 + Q; T++) tile_first[T] = e;
+			run += (unsigned long long)Q | (1ull << 32);
+		}
+	}
+	if (too_long) atomicOr(&ctr->error, 4u); // (the host never sends such a batch here: reads of more than 4 M windows take the flat kernel)
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_prefix_tiles(const ReadLanes *__restrict__ ent, const uint32_t *__restrict__ tile_first,
+                                                      const PrefixTotals *__restrict__ tot, uint32_t k, uint64_t n_bases, PrefixTile *__restrict__ tiles)
+{
+	const uint64_t n_lanes = tot->n_lanes, n_entries = tot->n_entries;
+	const uint64_t n_tiles = (n_lanes + kL1Threads - 1) / kL1Threads;
+	const uint64_t T = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (T >= n_tiles) return;
+	const uint32_t e0 = tile_first[T];
+	const ReadLanes E0 = ent[e0];
+	const uint64_t lane_first = T * kL1Threads, lane_last = min((T + 1) * (uint64_t)kL1Threads, n_lanes) - 1u;
+	uint32_t e1 = (uint32_t)n_entries - 1u;
+	if (T + 1 < n_tiles) {
+		e1 = tile_first[T + 1];
+		if ((uint64_t)ent[e1].lane0 > lane_last) e1--;
+	}
+	const ReadLanes E1 = ent[e1];
+	const uint32_t cc0 = (uint32_t)(lane_first - E0.lane0);
+	const uint64_t p_first = E0.start + (uint64_t)C * cc0;
+	PrefixTile M;
+	M.B0 = (p_first ? p_first - 1u : 0u) & ~15ull;
+	M.base0 = E0.start;
+	uint64_t end = E1.start + (uint64_t)C * (uint32_t)(lane_last - E1.lane0) + (uint32_t)C + k + 2u;
+	end = min(end, (n_bases + 15u) & ~15ull);
+	const uint64_t words = end > M.B0 ? (end - M.B0 + 15u) >> 4 : 0u;
+	// (the entries' starts are kept relative to base0 in 32 bits)
+	M.n_words = (words <= (uint64_t)kPkWords - 8u && E1.start - E0.start < (1ull << 32)) ? (uint32_t)words : 0u;
+	M.e0 = e0;
+	M.cc0 = cc0;
+	M.pad = 0u;
+	tiles[T] = M;
+}
+
+struct PrefixLds {
+	ScatterLds s;                  // (s.lbase doubles as the per-entry meta array while a tile is decoded: W << 10 | lane inside the tile)
+	uint32_t pk[kPkWords];
+	uint32_t ent_start[kL1Threads]; // start of the tile's i-th entry, relative to the tile's base0
+	unsigned long long starts[kL1Threads / 64]; // bit l: an entry begins at lane l of the tile
+};
+
+template <int WIDE_D = 0, int C = 16>
+__global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch rb, const ReadLanes *__restrict__ ent, const PrefixTile *__restrict__ tiles,
+                                                                        const PrefixTotals *__restrict__ tot, PartGeom G, PartStore P, Counters *__restrict__ ctr)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	PrefixLds &UL = *reinterpret_cast<PrefixLds *>(lds_raw);
+	ScatterLds &L = UL.s;
+	const uint64_t n_lanes = tot->n_lanes, n_entries = tot->n_entries;
+	const uint64_t n_tiles = (n_lanes + kL1Threads - 1) / kL1Threads;
+	const uint64_t n_words_total = (rb.n_bases + 15u) >> 4;
+	const uint32_t k = (uint32_t)rb.k;
+	const uint64_t head_mask = (k < 32u) ? ((1ull << (2u * k)) - 1ull) : ~0ull;
+	const uint32_t rc_shift = 2u * k - 2u;
+	const uint32_t rel_mask = (1u << G.r) - 1u, q_shift = G.r + 6u;
+
+	struct RawP {
+		uint32_t a, b;       // packed words tid and tid + 1024 of the tile's range
+		uint32_t start_rel;  // the tile's tid-th entry: its start relative to the tile's base0,
+		uint32_t meta;       // its windows << 10 | the lane of the tile it begins at; ~0: no such entry
+	};
+	auto tile_meta = [&](uint64_t tile) {
+		PrefixTile M{};
+		if (tile < n_tiles) M = tiles[tile]; // (uniform address: a scalar load)
+		return M;
+	};
+	auto fetch = [&](uint64_t tile, const PrefixTile &M) {
+		RawP raw;
+		raw.a = raw.b = raw.start_rel = 0u;
+		raw.meta = 0xFFFFFFFFu;
+		if (tile >= n_tiles) return raw;
+		const uint32_t t = fresh_tid();
+		const uint64_t w0 = M.B0 >> 4;
+		if (t < M.n_words && w0 + t < n_words_total) raw.a = rb.packed[w0 + t];
+		if (t + kL1Threads < M.n_words && w0 + t + kL1Threads < n_words_total) raw.b = rb.packed[w0 + t + kL1Threads];
+		if ((uint64_t)M.e0 + t < n_entries) {
+			const ReadLanes E = ent[(uint64_t)M.e0 + t];
+			const uint64_t lane_first = tile * kL1Threads, lane_end = min(lane_first + (uint64_t)kL1Threads, n_lanes);
+			if ((uint64_t)E.lane0 < lane_end) { // (only the tile's first entry can begin before the tile)
+				const uint32_t at = (uint64_t)E.lane0 > lane_first ? (uint32_t)(E.lane0 - lane_first) : 0u;
+				raw.start_rel = (uint32_t)(E.start - M.base0);
+				raw.meta = (E.W << 10) | at;
+			}
+		}
+		return raw;
+	};
+
+	if (fresh_tid() < (uint32_t)(kL1Threads / 64)) UL.starts[fresh_tid()] = 0ull;
+	PrefixTile M = tile_meta(blockIdx.x), M_next = tile_meta((uint64_t)blockIdx.x + gridDim.x);
+	RawP raw = fetch(blockIdx.x, M);
+	lds_barrier();
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		const uint64_t lane_first = tile * kL1Threads, lane_end = min(lane_first + (uint64_t)kL1Threads, n_lanes);
+		if (tid < M.n_words) UL.pk[tid] = raw.a;
+		if (tid + kL1Threads < M.n_words) UL.pk[tid + kL1Threads] = raw.b;
+		// this thread's entry of the tile: where it begins among the tile's lanes, its start and windows
+		if (raw.meta != 0xFFFFFFFFu) {
+			const uint32_t at = raw.meta & 1023u;
+			atomicOr(&UL.starts[at >> 6], 1ull << (at & 63u));
+			UL.ent_start[tid] = raw.start_rel;
+			L.lbase[tid] = raw.meta;
+		}
+		uint32_t bkt[16];
+#pragma unroll
+		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[ScatterLds::kBpt * tid + j] = 0;
+		lds_barrier();
+		// the lane's read: the number of entries that begin at or before this lane
+		const bool live = lane_first + tid < lane_end;
+		uint32_t idx;
+		{
+			const uint32_t lane = tid & 63u, wave = tid >> 6;
+			const unsigned long long mine = UL.starts[wave];
+			uint32_t before = (lane < (uint32_t)(kL1Threads / 64) && lane < wave) ? (uint32_t)__popcll(UL.starts[lane]) : 0u;
+#pragma unroll
+			for (int off = 8; off > 0; off >>= 1) before += __shfl_xor(before, off, 64); // lanes 0..15 hold the per-wave counts: sum over them
+			before = __builtin_amdgcn_readfirstlane(before);
+			idx = before + (uint32_t)__popcll(mine & ((2ull << lane) - 1ull)) - 1u; // (bit 0 of the tile is always set: idx >= 0 for live lanes)
+		}
+		uint64_t p = 0;        // flat position of the lane's first window
+		uint32_t cc = 0, W = 0;
+		if (live) {
+			const uint32_t meta = L.lbase[idx];
+			W = meta >> 10;
+			cc = tid - (meta & 1023u) + (idx == 0u ? M.cc0 : 0u);
+			p = M.base0 + UL.ent_start[idx] + (uint64_t)C * cc;
+		}
+		const bool no_prev = p == 0u;
+		const uint64_t s0 = no_prev ? p : p - 1u;
+		const uint32_t first_w = (uint32_t)C * cc;
+		Chunk16 c;
+		{
+			uint32_t x0, x1, x2, x3, x4;
+			const uint32_t sh = 2u * ((uint32_t)s0 & 15u);
+			if (M.n_words) { // (tile-uniform) the range sits in LDS
+				const uint32_t rel = live ? (uint32_t)(s0 - M.B0) : 0u;
+				const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u);
+				x0 = UL.pk[d]; x1 = UL.pk[d + 1]; x2 = UL.pk[d + 2]; x3 = UL.pk[d + 3]; x4 = UL.pk[d + 4];
+			} else {         // a range too long for the image: every lane reads its five words from global memory
+				const uint64_t wi = live ? s0 >> 4 : 0ull, last = n_words_total ? n_words_total - 1u : 0u;
+				x0 = rb.packed[min(wi, last)]; x1 = rb.packed[min(wi + 1u, last)]; x2 = rb.packed[min(wi + 2u, last)];
+				x3 = rb.packed[min(wi + 3u, last)]; x4 = rb.packed[min(wi + 4u, last)];
+			}
+			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
+			const uint32_t adv = no_prev ? 0u : 2u;
+			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
+			c.lw = no_prev ? (X0 >> 2) : X0;
+			c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
+			c.rc = revcomp_kbit(c.kbit, (int)k);
+			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u);
+			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
+			c.nb = funnel_left(ya, yb, wsh);
+			const uint32_t nv = (live && first_w < W) ? min((uint32_t)C, W - first_w) : 0u;
+			const uint32_t nr = (live && first_w + 1u < W) ? min((uint32_t)C, W - 1u - first_w) : 0u;
+			c.valid = (1u << nv) - 1u;
+			c.has_r = (1u << nr) - 1u;            // the read's last window (after trimming) has no right neighbour
+			c.has_l = cc ? 0xFFFFu : 0xFFFEu;     // its first window no left one
+		}
+		const bool zero_seen = l1_positions<WIDE_D, C, ScatterLds, false>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
+		// next tile: its words and entries travel during this tile's scatter; the meta data of the tile after it as well
+		const uint64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
+		const RawP nxt = fetch(t1, M_next);
+		const PrefixTile M_after = tile_meta(t2);
+		lds_barrier(); // hist complete (as l1_scatter_tail begins) -- and every lane has read starts / ent_start / the meta words in lbase
+		if (tid < (uint32_t)(kL1Threads / 64)) UL.starts[tid] = 0ull; // (for the next tile: set again only after that tile's threads passed the barriers below)
+		{
+			uint64_t rec[16];
+#pragma unroll
+			for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
+			uint32_t my_gbase[ScatterLds::kBpt];
+			const uint32_t sub = blockIdx.x % G.n_sub;
+			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
+			scatter_stage_copy<16, 0>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+		}
+		raw = nxt;
+		M = M_next;
+		M_next = M_after;
+	}
+}
+
 // ---- level 2: split every level-1 bucket into its n2 final buckets -----------------------------
 // Inbox entry e = (s * B + j) * n_sub + x: sub-store x of level-1 bucket j of this shard's slot range
 // as extracted by rank s.  The tile list is flattened OWN-BUCKET-MAJOR, f = (j * n_ranks + s) * n_sub + x,

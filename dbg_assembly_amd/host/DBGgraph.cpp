@@ -692,6 +692,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 		cfg.expected_kmers = std::max<uint64_t>(store, 1024);
 	}
 	if (S->ref_layout) cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
+	cfg.flags |= DBGK_FLAG_PREALLOC_STAGING; // page-locking the staging buffers happens on the creating thread, beside the first file read
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
 	// several GPUs: DBGK_GPUS=N (devices 0..N-1) or DBGK_GPU_LIST=a,b,c (ordinals, repeats allowed)
 	std::vector<int32_t> devices;

@@ -67,13 +67,13 @@ bool for_each_read_in_file(const std::string &path, int format, Callback cb, con
 }
 
 // ---- plain (not compressed) files with several threads ---------------------------------------------------------------------
-// The file is read in windows of 256 MiB into one reusable buffer (2 MiB-aligned, huge pages advised): (1) n_threads threads
+// The file is read in windows of 256 MiB into two buffers used in turn (2 MiB-aligned, huge pages advised): (1) n_threads threads
 // pread() their byte ranges of the window and note the newline positions in them, each with the first character of the line that
 // follows; (2) the calling thread runs the SAME record state machine as above over those notes -- whatever a line begins with is
 // judged in file order, so the result is that of the sequential reader for any input (FASTQ quality lines that start with '@'
 // included) -- and calls cb(pointer into the window, length) for every record; (3) end_of_window() is called before the buffer is
-// reused: the caller copies the sequence bytes it was shown (again with several threads).  A line that straddles two windows is
-// carried over to the front of the buffer.
+// reused: the caller copies / packs the sequence bytes it was shown (again with several threads).  A line that straddles two
+// windows is carried over to the front of the next buffer.  (2) and (3) of window i run while (1) of window i + 1 is under way.
 class ChunkedReadsFile {
 public:
 	~ChunkedReadsFile() { close(); }
@@ -93,9 +93,6 @@ public:
 	void close()
 	{
 		if (fd_ >= 0) ::close(fd_);
-		free(buf_);
-		buf_ = NULL;
-		cap_ = 0;
 		fd_ = -1;
 		size_ = 0;
 	}
@@ -111,33 +108,47 @@ public:
 		const size_t WINDOW = (size_t)256 << 20;
 #endif
 		if (n_threads < 1) n_threads = 1;
-		std::vector<std::vector<uint64_t>> nl((size_t)n_threads); // newline position | first character of the next line << 56
-		std::vector<size_t> slice_end((size_t)n_threads);
-		int state = 0;          // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
-		size_t have = 0;        // bytes of an unfinished line carried over to the front of the buffer
-		size_t file_off = 0;
-		bool ok = true;
-		while (file_off < size_ && !(stop && *stop)) {
-			const size_t take = std::min(WINDOW, size_ - file_off);
-			if (!reserve(have + take)) return false;
-			const size_t per = (take + (size_t)n_threads - 1) / (size_t)n_threads;
+		// TWO windows: while the calling thread runs the record rules over window i and the caller copies / packs its reads
+		// (end_of_window), the reader threads already pread window i + 1 and note its newlines.  What window i + 1 needs of window
+		// i -- the unfinished last line, carried to its front -- is known as soon as window i has been read.
+		struct Window {
+			char *buf = NULL;
+			size_t cap = 0;
+			size_t have = 0, take = 0;                 // carried-over bytes, bytes read from the file
+			std::vector<std::vector<uint64_t>> nl;     // per reader thread: newline position | first character of the next line << 56
+			std::vector<size_t> slice_end;
+			bool ok = true;
+		} win[2];
+		for (Window &W : win) {
+			W.nl.resize((size_t)n_threads);
+			W.slice_end.resize((size_t)n_threads);
+		}
+		auto release = [&]() { for (Window &W : win) free(W.buf); };
+		auto read_window = [&](Window &W, size_t file_off, const char *carry, size_t carry_len) {
+			W.take = std::min(WINDOW, size_ - file_off);
+			W.have = carry_len;
+			W.ok = grow(W.buf, W.cap, W.have + W.take);
+			if (!W.ok) return;
+			if (carry_len) memcpy(W.buf, carry, carry_len);
+			const size_t per = (W.take + (size_t)n_threads - 1) / (size_t)n_threads;
 			std::vector<char> failed((size_t)n_threads, 0);
 			auto work = [&](int t) {
-				std::vector<uint64_t> &out = nl[(size_t)t];
+				std::vector<uint64_t> &out = W.nl[(size_t)t];
 				out.clear();
-				const size_t a = std::min(take, per * (size_t)t), b = std::min(take, a + per);
-				slice_end[(size_t)t] = have + b;
+				const size_t a = std::min(W.take, per * (size_t)t), b = std::min(W.take, a + per);
+				W.slice_end[(size_t)t] = W.have + b;
 				for (size_t done = a; done < b;) { // pread may return less than asked
-					const ssize_t got = pread(fd_, buf_ + have + done, b - done, (off_t)(file_off + done));
+					const ssize_t got = pread(fd_, W.buf + W.have + done, b - done, (off_t)(file_off + done));
 					if (got <= 0) { failed[(size_t)t] = 1; return; }
 					done += (size_t)got;
 				}
 				out.reserve((b - a) / 64 + 16);
-				for (const char *p = buf_ + have + a, *e = buf_ + have + b; p < e;) {
+				// (thread 0 also scans the carried-over bytes: none of them is a newline, but the scan is uniform)
+				for (const char *p = W.buf + W.have + a, *e = W.buf + W.have + b; p < e;) {
 					const char *q = static_cast<const char *>(memchr(p, '\n', (size_t)(e - p)));
 					if (!q) break;
 					const unsigned char next = q + 1 < e ? (unsigned char)q[1] : 0; // (at the slice's end: looked up below, the neighbour is still reading)
-					out.push_back((uint64_t)(q - buf_) | ((uint64_t)next << 56));
+					out.push_back((uint64_t)(q - W.buf) | ((uint64_t)next << 56));
 					p = q + 1;
 				}
 			};
@@ -145,64 +156,78 @@ public:
 			for (int t = 1; t < n_threads; t++) th.emplace_back(work, t);
 			work(0);
 			for (auto &x : th) x.join();
-			for (char f : failed) ok = ok && !f;
-			if (!ok) return false;
-			const size_t end = have + take;
+			for (char f : failed) W.ok = W.ok && !f;
+		};
+		int state = 0;          // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
+		size_t file_off = 0;
+		int cur = 0;
+		if (size_ > 0) read_window(win[0], 0, NULL, 0);
+		while (file_off < size_ && !(stop && *stop)) {
+			Window &W = win[cur];
+			if (!W.ok) return release(), false;
+			const size_t end = W.have + W.take;
+			// the last newline of this window: what follows it is carried over to the next one
+			size_t after_last_nl = 0;
+			for (int t = n_threads - 1; t >= 0; t--)
+				if (!W.nl[(size_t)t].empty()) { after_last_nl = (size_t)(W.nl[(size_t)t].back() & ((1ull << 56) - 1)) + 1; break; }
+			const size_t next_off = file_off + W.take;
+			const bool more = next_off < size_;
+			std::thread ahead;
+			if (more) ahead = std::thread([&, next_off, after_last_nl, end]() { read_window(win[cur ^ 1], next_off, W.buf + after_last_nl, end - after_last_nl); });
 			size_t line_start = 0;
-			char first = buf_[0]; // end >= 1 here
+			char first = W.buf[0]; // end >= 1 here
 			for (int t = 0; t < n_threads && !(stop && *stop); t++)
-				for (uint64_t word : nl[(size_t)t]) {
+				for (uint64_t word : W.nl[(size_t)t]) {
 					if (stop && *stop) break;
 					const size_t pos = (size_t)(word & ((1ull << 56) - 1));
 					const size_t len = pos - line_start;
 					switch (state) { // the record rules of for_each_read_in_file
 						case 0: if (len && first == marker) state = 1; break;
-						case 1: cb(buf_ + line_start, len); state = (format == 1) ? 2 : 0; break;
+						case 1: cb(W.buf + line_start, len); state = (format == 1) ? 2 : 0; break;
 						case 2: state = 3; break;
 						default: state = 0; break;
 					}
 					line_start = pos + 1;
-					first = pos + 1 == slice_end[(size_t)t] ? (pos + 1 < end ? buf_[pos + 1] : 0) : (char)(word >> 56);
+					first = pos + 1 == W.slice_end[(size_t)t] ? (pos + 1 < end ? W.buf[pos + 1] : 0) : (char)(word >> 56);
 				}
-			file_off += take;
-			if (stop && *stop) break;
-			if (file_off >= size_ && line_start < end) { // the file's last line has no newline
+			if (!(stop && *stop) && !more && line_start < end) { // the file's last line has no newline
 				const size_t len = end - line_start;
 				switch (state) {
-					case 0: if (len && buf_[line_start] == marker) state = 1; break;
-					case 1: cb(buf_ + line_start, len); state = (format == 1) ? 2 : 0; break;
+					case 0: if (len && W.buf[line_start] == marker) state = 1; break;
+					case 1: cb(W.buf + line_start, len); state = (format == 1) ? 2 : 0; break;
 					case 2: state = 3; break;
 					default: state = 0; break;
 				}
-				line_start = end;
 			}
-			end_of_window(); // the records shown so far are copied now: the buffer is about to be reused
-			have = end - line_start;
-			if (have) memmove(buf_, buf_ + line_start, have);
+			if (!(stop && *stop)) end_of_window(); // the records shown so far are copied now: this buffer is read into again two windows on
+			if (ahead.joinable()) ahead.join();
+			file_off = next_off;
+			cur ^= 1;
 		}
 		if (!(stop && *stop) && state == 1) { // a header on the very last line
 			cb("", 0);
 			end_of_window();
 		}
+		release();
 		return true;
 	}
 
 private:
-	bool reserve(size_t want)
+	// (2 MiB-aligned, huge pages advised; the content is kept)
+	static bool grow(char *&buf, size_t &cap, size_t want)
 	{
-		if (want <= cap_) return true;
+		if (want <= cap) return true;
 		const size_t c = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
 		void *p = NULL;
 		if (posix_memalign(&p, (size_t)2 << 20, c) != 0) return false;
 		(void)madvise(p, c, MADV_HUGEPAGE);
-		if (buf_) memcpy(p, buf_, cap_);
-		free(buf_);
-		buf_ = static_cast<char *>(p);
-		cap_ = c;
+		if (buf) memcpy(p, buf, cap);
+		free(buf);
+		buf = static_cast<char *>(p);
+		cap = c;
 		return true;
 	}
-	char *buf_ = NULL;
-	size_t cap_ = 0, size_ = 0;
+	size_t size_ = 0;
 	int fd_ = -1;
 };
 

@@ -105,6 +105,10 @@ typedef struct dbgk_config {
  * the reference's single-threaded path first inserts them (DBGgraph.cpp:139-205 at -t 1).  Costs one
  * extra 64-bit atomic per k-mer and 8 bytes per slot.                                            */
 #define DBGK_FLAG_TRACK_FIRST_SEEN 1ull
+/* allocate the two pinned staging buffers (max_batch_bases each + offsets) and their device twins inside dbgk_create instead of on the
+ * first dbgk_push_reads / dbgk_push_acquire: page-locking a few hundred MB costs tens of milliseconds, which a host that creates the
+ * handle on a thread beside its first file read hides this way (host/DBGgraph.cpp)                                               */
+#define DBGK_FLAG_PREALLOC_STAGING 2ull
 
 /* totals after dbgk_finalize (the globals the reference prints, DBGgraph.cpp:410-411, and the
  * KmerSet counters of kmerSet.cpp:331-338) */
@@ -150,7 +154,8 @@ typedef struct dbgk_timings {
 	uint32_t partition_launches; /* launches accumulated into partition_ms (= into build_ms)         */
 	uint32_t uniform_launches;   /* of insert_launches: batches of equal-length reads, which take the
 	                                PARTITION engine's k_extract_scatter_uniform instead of k_extract_scatter */
-	uint32_t reserved32;
+	uint32_t prefix_launches;    /* of insert_launches: batches of mixed-length reads through k_extract_scatter_prefix (every read
+	                                exactly the lanes its windows need; dbgk_partition.h)                                          */
 	uint64_t reserved[1];
 } dbgk_timings;
 
