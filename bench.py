@@ -436,7 +436,7 @@ def run_kfreq(args, ctx, brief=False):
     def step():
         g.reset()
         if packed_in:
-            g.push_reads_packed_device(d_packed.ptr, d_off.ptr, n_reads, nb)
+            g.push_reads_packed_uniform_device(d_packed.ptr, n_reads, 150)
         else:
             g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
         st = g.finalize()
@@ -688,8 +688,12 @@ def run_graph(args, ctx, brief=False):
 
     state = {"verify": True, "packed": packed_in}   # the first step run checksums what every rank sent against what its peers received
 
+    fixed_len = not CONFIGS[args.config].get("trimmed")   # reads of one length travel without offsets (dbgk_push_reads_packed_uniform*)
+
     def push(h):
-        if state["packed"]:
+        if state["packed"] and fixed_len and not os.environ.get("DBGK_BENCH_OFFSETS"):
+            h.push_reads_packed_uniform_device(d_packed.ptr, n_reads, 150)
+        elif state["packed"]:
             h.push_reads_packed_device(d_packed.ptr, d_off.ptr, n_reads, nb)
         else:
             h.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
@@ -818,14 +822,20 @@ def run_graph(args, ctx, brief=False):
         def rec(times, note):
             m = median(times)
             return {"value": n_reads * kpr / m / 1e6, "unit": "M k-mers/s", "ms_per_step": m * 1e3, "reps_ms": [t * 1e3 for t in times], "note": note}
-        t_pp = region(lambda: g.push_reads_packed_ptr(p_words.data_ptr(), p_off.data_ptr(), n_reads, other), H2D_REPS)
+        with_offsets = None
+        if fixed_len:
+            with_offsets = region(lambda: g.push_reads_packed_ptr(p_words.data_ptr(), p_off.data_ptr(), n_reads, other), 3)
+            t_pp = region(lambda: g.push_reads_packed_uniform(p_words.data_ptr(), n_reads, 150, other), H2D_REPS)
+        else:
+            t_pp = region(lambda: g.push_reads_packed_ptr(p_words.data_ptr(), p_off.data_ptr(), n_reads, other), H2D_REPS)
         if gold is not None:
             assert g.digest() == gold["digest"]
         from_h2d = rec(t_pp, "SURVEY 8(d)'s timed region: reset, first host-to-device copy of the 2-bit packed read blocks (page-locked host buffer, "
                              "read by the copy engine directly), level 1 batch by batch while the next batch travels, level 2 + build, counters read back; "
                              "median of %d repetitions" % H2D_REPS)
-        from_h2d["h2d_bytes_per_step"] = int(words.nbytes + h_off.nbytes)
+        from_h2d["h2d_bytes_per_step"] = int(words.nbytes + (0 if fixed_len else h_off.nbytes))
         from_h2d["variants"] = {
+            "packed_pinned_with_offsets": rec(with_offsets, "the same with the 64-bit offsets of the reads travelling too (reads of mixed lengths need them): +80 MB") if with_offsets else None,
             "packed_pageable": rec(region(lambda: g.push_reads_packed(words, h_off, other), 3), "packed words in pageable memory: shifted / copied into the pinned staging buffers by host threads"),
             "ascii_pinned": None, "ascii_pageable": None}
         p_bases = torch.empty(nb, dtype=torch.uint8).pin_memory()
@@ -882,7 +892,8 @@ def run_graph(args, ctx, brief=False):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.kmer <= 32 else "u128",
             "data": "synthetic",
             "config": {"workload": CONFIGS[args.config]["workload"],
-                       "input": "reads resident in HBM as 2-bit packed blocks (16 bases per 32-bit word) + 64-bit offsets" if packed_in else "reads resident in HBM as ASCII bytes + 64-bit offsets",
+                       "input": ("reads resident in HBM as 2-bit packed blocks (16 bases per 32-bit word)" + (", one length: no offsets" if fixed_len else " + 64-bit offsets")) if packed_in
+                                else "reads resident in HBM as ASCII bytes + 64-bit offsets",
                        "reads_per_gpu": n_reads, "kmers_per_gpu": kmers_step, "bases_per_gpu": nb, "table_slots": size,
                        "nodes": res["count"], "engine": {capi.ENGINE_PARTITION: "partition", capi.ENGINE_WIDE: "wide"}.get(args.engine, "direct"),
                        "parallelism": ("reads sharded by record x%d, k-mers owned by slot range of one global table "

@@ -103,6 +103,8 @@ SYMBOLS = [
     ("dbgk_push_commit_packed", _i, [_vp, _u64, _u64]),
     ("dbgk_push_reads_packed_device", _i, [_vp, _vp, _vp, _u64, _u64]),
     ("dbgk_pack_bases_device", _i, [_vp, _vp, _u64, _vp]),
+    ("dbgk_push_reads_packed_uniform", _i, [_vp, _vp, _u64, C.c_uint32, _u64]),
+    ("dbgk_push_reads_packed_uniform_device", _i, [_vp, _vp, _u64, C.c_uint32]),
     ("dbgk_finalize", _i, [_vp, C.POINTER(Stats)]),
     ("dbgk_sync", _i, [_vp]),
     ("dbgk_resize_table", _i, [_vp, _u64]),
@@ -355,6 +357,14 @@ class Graph:
             C.memmove(po.value, rel.ctypes.data, rel.nbytes)
             _chk(lib().dbgk_push_commit_packed(self._h, r1 - r0, other.value), "dbgk_push_commit_packed")
             r0 = r1
+
+    def push_reads_packed_uniform(self, packed, n_reads, read_len, other_bytes=0):
+        """n_reads reads of read_len bases each, packed back to back (host array or host pointer): no offsets"""
+        ptr = packed if isinstance(packed, int) else np.ascontiguousarray(packed, dtype=np.uint32).ctypes.data
+        _chk(lib().dbgk_push_reads_packed_uniform(self._h, ptr, n_reads, read_len, other_bytes), "dbgk_push_reads_packed_uniform")
+
+    def push_reads_packed_uniform_device(self, d_packed, n_reads, read_len):
+        _chk(lib().dbgk_push_reads_packed_uniform_device(self._h, d_packed, n_reads, read_len), "dbgk_push_reads_packed_uniform_device")
 
     def push_reads_packed_device(self, d_packed, d_offsets, n_reads, n_bases):
         _chk(lib().dbgk_push_reads_packed_device(self._h, d_packed, d_offsets, n_reads, n_bases), "dbgk_push_reads_packed_device")

@@ -109,6 +109,8 @@ struct dbgk_handle {
 	uint64_t pf_cap_reads = 0, pf_cap_tiles = 0;
 	uint32_t *pf_packed = nullptr;
 	uint64_t pf_packed_words = 0;
+	uint64_t *uni_offsets = nullptr; // offsets made on the device for a batch that came without (dbgk_push_reads_packed_uniform*) and needs them
+	uint64_t uni_cap = 0;
 	uint32_t prefix_launches = 0;
 
 	bool finalized = false;
@@ -333,7 +335,7 @@ static void free_wide_partition(dbgk_handle *h)
 
 static void free_handle(dbgk_handle *h)
 {
-	for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum, (void *)h->pf_tot, (void *)h->pf_packed})
+	for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum, (void *)h->pf_tot, (void *)h->pf_packed, (void *)h->uni_offsets})
 		if (q) (void)hipFree(q);
 
 	if (!h) return;
@@ -1452,6 +1454,24 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	auto decide_umode = [&]() {
 		return wrec ? wide_uniform_mode(h, uniform_len, n_reads, n_bases, has_long, WU) : uniform_mode(h, uniform_len, len_max, n_reads, n_bases, has_long, U, c15, lin8, lin12);
 	};
+	// A batch of equal-length reads that came WITHOUT offsets (dbgk_push_reads_packed_uniform*): the equal-length level-1 forms of the
+	// PARTITION / WIDE record engines never look at offsets -- the totals are added by a one-thread kernel and nothing else runs in
+	// front of level 1; any other consumer gets the offsets made on the device first.
+	const bool no_offsets = d_offsets == nullptr;
+	auto make_offsets = [&]() -> int {
+		if (n_reads + 1 > h->uni_cap) {
+			HIPCHK(hipStreamSynchronize(h->stream));
+			if (h->uni_offsets) (void)hipFree(h->uni_offsets);
+			h->uni_offsets = nullptr;
+			h->uni_cap = 0;
+			const uint64_t cap = std::max(n_reads + 1, h->cap_reads + 1);
+			if (hipMalloc(&h->uni_offsets, cap * 8) != hipSuccess) return DBGK_ERR_NOMEM;
+			h->uni_cap = cap;
+		}
+		hipLaunchKernelGGL(k_iota_offsets, dim3(grid_for(h, n_reads + 1)), dim3(kBlock), 0, h->stream, h->uni_offsets, n_reads, (uint64_t)uniform_len);
+		d_offsets = h->uni_offsets;
+		return DBGK_OK;
+	};
 	const bool may_skip_bits = (h->part && !h->seed) || wrec;
 	// The PREFIX form of level 1 (k_extract_scatter_prefix: every read exactly the lanes its windows need, reads of any lengths,
 	// trimmed ones included) takes what would otherwise go through the flat kernel -- a fifth of whose positions straddle a
@@ -1472,7 +1492,15 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		umode = decide_umode();
 		use_prefix = prefix_wanted(umode);
 	}
-	if (may_skip_bits && (umode > 0 || umode < 0 || use_prefix)) {
+	if (no_offsets && umode == 1) { // (umode 1 = equal lengths, nothing trimmed: every read has uniform_len - k + 1 windows)
+		const unsigned long long w = uniform_len >= h->cfg.kmer_size ? (unsigned long long)(uniform_len - h->cfg.kmer_size + 1) * n_reads : 0ull;
+		hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, h->stream, h->d_ctr, w, w);
+	} else if (no_offsets) {
+		rc = make_offsets();
+		if (rc) return rc;
+	}
+	if (no_offsets && umode == 1) {
+	} else if (may_skip_bits && (umode > 0 || umode < 0 || use_prefix)) {
 		hipLaunchKernelGGL(k_mark, dim3(grid_for(h, n_reads)), dim3(kBlock), 0, h->stream, d_offsets, n_reads, n_bases, h->cfg.kmer_size,
 		                   h->cfg.max_read_len, (uint32_t *)nullptr, (uint32_t *)nullptr, h->d_ctr, 1); // statistics only
 	} else {
@@ -1570,8 +1598,12 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		                   (uint32_t)h->cfg.max_read_len, h->pf_bsum, h->pf_ent, h->pf_tile_first, h->d_ctr);                                     \
 		hipLaunchKernelGGL((k_prefix_tiles<CC>), dim3((tiles_max + 255) / 256), dim3(256), 0, h->stream, h->pf_ent, h->pf_tile_first, h->pf_tot,    \
 		                   (uint32_t)h->cfg.kmer_size, n_bases, h->pf_tiles);                                                                     \
-		hipLaunchKernelGGL((k_extract_scatter_prefix<WIDE, CC>), dim3(grid_p), dim3(kL1Threads), sizeof(PrefixLds), h->stream, rb, h->pf_ent,       \
-		                   h->pf_tiles, h->pf_tot, h->geom, h->store, h->d_ctr);                                                                  \
+		if (h->cfg.kmer_size >= 17)                                                                                                                 \
+			hipLaunchKernelGGL((k_extract_scatter_prefix<WIDE, CC, true>), dim3(grid_p), dim3(kL1Threads), sizeof(PrefixLds), h->stream, rb, h->pf_ent, \
+			                   h->pf_tiles, h->pf_tot, h->geom, h->store, h->d_ctr);                                                              \
+		else                                                                                                                                      \
+			hipLaunchKernelGGL((k_extract_scatter_prefix<WIDE, CC, false>), dim3(grid_p), dim3(kL1Threads), sizeof(PrefixLds), h->stream, rb, h->pf_ent, \
+			                   h->pf_tiles, h->pf_tot, h->geom, h->store, h->d_ctr);                                                              \
 	} while (0)
 		if (pc15) { if (wide == 2) DBGK_LAUNCH_PREFIX(2, 15); else if (wide == 1) DBGK_LAUNCH_PREFIX(1, 15); else DBGK_LAUNCH_PREFIX(0, 15); }
 		else { if (wide == 2) DBGK_LAUNCH_PREFIX(2, 16); else if (wide == 1) DBGK_LAUNCH_PREFIX(1, 16); else DBGK_LAUNCH_PREFIX(0, 16); }
@@ -1770,7 +1802,7 @@ static int h2d_batch(dbgk_handle *h, StageSlot &s, const char *src, uint64_t nb,
 	if (!serial && !h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 	hipStream_t cs = serial ? h->stream : h->copy_stream;
 	if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, src, nb, hipMemcpyHostToDevice, cs));
-	HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, n_offsets * 8, hipMemcpyHostToDevice, cs));
+	if (n_offsets) HIPCHK(hipMemcpyAsync(s.d_offsets, s.h_offsets, n_offsets * 8, hipMemcpyHostToDevice, cs)); // (0: reads of one length, no offsets travel)
 	if (last_of_pinned_source) { // the caller's buffer is free again once the LAST copy out of it has run: waited for on return
 		if (!h->source_read) HIPCHK(hipEventCreateWithFlags(&h->source_read, hipEventDisableTiming));
 		HIPCHK(hipEventRecord(h->source_read, cs));
@@ -2175,6 +2207,116 @@ extern "C" int dbgk_push_reads_packed_device(dbgk_handle *h, const uint32_t *d_p
 	}
 	rc = launch_batch(h, nullptr, d_offsets, n_reads, n_bases, h->dev_start, h->dev_dead, -1, -1, 0, d_packed);
 	if (rc == DBGK_OK) h->pending_kmers += n_bases;
+	return rc;
+}
+
+// Reads of ONE length (what a sequencer writes before anything trims them), 2 bits per base, back to back: no offsets travel and no
+// statistics pass runs in front of level 1 (launch_batch: no_offsets).  Batches are cut at reads where a word begins.
+extern "C" int dbgk_push_reads_packed_uniform(dbgk_handle *h, const uint32_t *packed, uint64_t n_reads, uint32_t read_len, uint64_t other_bytes)
+{
+	if (!h || (n_reads && read_len && !packed)) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	if (h->seed) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n_reads == 0) return DBGK_OK;
+	if (read_len == 0) { // records without a sequence count as reads (DBGgraph.cpp:274)
+		h->total_reads += n_reads;
+		return DBGK_OK;
+	}
+	const uint64_t L = read_len, K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len;
+	const uint64_t rl = L > max_len ? max_len : L, w_read = rl >= K ? rl - K + 1 : 0ull;
+	uint64_t align_reads = 16; // a batch begins where a word begins: at a multiple of 16 / gcd(L, 16) reads
+	for (uint64_t g = 16; g >= 1; g >>= 1)
+		if (L % g == 0) { align_reads = 16 / g; break; }
+	uint64_t per_batch = h->cap_bases / L;
+	per_batch -= per_batch % align_reads;
+	if (per_batch == 0) return DBGK_ERR_ARG; // reads larger than max_batch_bases
+	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
+	const uint64_t src_words = (n_reads * L + 15) >> 4;
+	const bool pinned_source = device_readable_host(reinterpret_cast<const char *>(packed), src_words * 4);
+	bool source_in_flight = false;
+	struct WaitSource {
+		dbgk_handle *h; bool &on;
+		~WaitSource() { if (on && h->source_read) (void)hipEventSynchronize(h->source_read); }
+	} wait_source{h, source_in_flight};
+	for (uint64_t r0 = 0; r0 < n_reads;) {
+		uint64_t nr = std::min(per_batch, n_reads - r0);
+		if (streaming && h->pending_kmers > 0) {
+			const uint64_t room = h->store_capacity > h->pending_kmers ? h->store_capacity - h->pending_kmers : 0;
+			if (w_read && nr * w_read > room) { // what the record store still takes, in whole alignment groups; else flush first
+				uint64_t fit = room / w_read;
+				fit -= fit % align_reads;
+				if (fit == 0 || !(h->store_capacity >= h->cap_bases && !h->wpart)) {
+					rc = flush_records(h);
+					if (rc) return rc;
+					continue;
+				}
+				nr = std::min(nr, fit);
+			}
+		}
+		StageSlot &s = h->slots[h->next_slot];
+		rc = ensure_slot(h, s);
+		if (rc) return rc;
+		if (s.busy) {
+			HIPCHK(hipEventSynchronize(s.done));
+			s.busy = false;
+		}
+		s.acquired = false;
+		const uint64_t base0 = r0 * L, nb = nr * L, n_words = (nb + 15) >> 4;
+		const uint32_t *src = packed + (base0 >> 4); // (base0 is a multiple of 16)
+		if (!pinned_source) {
+			std::vector<std::thread> copiers;
+			staged_copy(s.h_bases, reinterpret_cast<const char *>(src), n_words * 4, copiers);
+			for (auto &t : copiers) t.join();
+		}
+		rc = h2d_batch(h, s, pinned_source ? reinterpret_cast<const char *>(src) : s.h_bases, n_words * 4, 0, pinned_source);
+		if (rc) return rc;
+		source_in_flight = source_in_flight || pinned_source;
+		rc = launch_batch(h, nullptr, nullptr, nr, nb, s.d_start, s.d_dead, L > max_len ? 1 : 0, (int64_t)L, L, reinterpret_cast<const uint32_t *>(s.d_bases));
+		if (rc) return rc;
+		h->pending_kmers += nr * w_read;
+		HIPCHK(hipEventRecord(s.done, h->stream));
+		s.busy = true;
+		h->next_slot ^= 1;
+		r0 += nr;
+	}
+	h->host_other_bytes += other_bytes;
+	return DBGK_OK;
+}
+
+extern "C" int dbgk_push_reads_packed_uniform_device(dbgk_handle *h, const uint32_t *d_packed, uint64_t n_reads, uint32_t read_len)
+{
+	if (!h || (n_reads && read_len && !d_packed)) return DBGK_ERR_ARG;
+	if ((uintptr_t)d_packed & 15u) return DBGK_ERR_ARG;
+	if (h->finalized) return DBGK_ERR_STATE;
+	if (h->seed) return DBGK_ERR_ARG;
+	int rc = use_device(h);
+	if (rc) return rc;
+	if (n_reads == 0) return DBGK_OK;
+	if (read_len == 0) {
+		h->total_reads += n_reads;
+		return DBGK_OK;
+	}
+	const uint64_t L = read_len, K = (uint64_t)h->cfg.kmer_size, max_len = (uint64_t)h->cfg.max_read_len, n_bases = n_reads * L;
+	const uint64_t rl = L > max_len ? max_len : L, windows = (rl >= K ? rl - K + 1 : 0ull) * n_reads;
+	const uint64_t words = bitmap_words(n_bases);
+	if (words > h->dev_bits_words) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (h->dev_start) (void)hipFree(h->dev_start);
+		if (h->dev_dead) (void)hipFree(h->dev_dead);
+		h->dev_start = h->dev_dead = nullptr;
+		h->dev_bits_words = 0;
+		if (hipMalloc(&h->dev_start, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		if (hipMalloc(&h->dev_dead, words * 4) != hipSuccess) return DBGK_ERR_NOMEM;
+		h->dev_bits_words = words;
+	}
+	if (((h->part && !h->sharded) || (h->wpart && !h->wbuilt)) && h->pending_kmers > 0 && h->pending_kmers + windows > h->store_capacity) {
+		rc = flush_records(h);
+		if (rc) return rc;
+	}
+	rc = launch_batch(h, nullptr, nullptr, n_reads, n_bases, h->dev_start, h->dev_dead, L > max_len ? 1 : 0, (int64_t)L, L, d_packed);
+	if (rc == DBGK_OK) h->pending_kmers += windows; // (exact here: the lengths are known)
 	return rc;
 }
 

@@ -1218,6 +1218,21 @@ __global__ __launch_bounds__(kBlock) void k_count_other_bytes(const char *__rest
 	if (threadIdx.x == 0 && tot) atomicAdd(&ctr->other_bytes, tot);
 }
 
+// reads of ONE length, handed over without offsets (dbgk_push_reads_packed_uniform*): the totals k_mark would have summed up ...
+__global__ void k_add_totals(Counters *__restrict__ ctr, unsigned long long total_kmers, unsigned long long stored_kmers)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		atomicAdd(&ctr->total_kmers, total_kmers);
+		atomicAdd(&ctr->stored_kmers, stored_kmers);
+	}
+}
+// ... and, for the kernels that do navigate by offsets (any engine but the PARTITION engine's equal-length forms), the offsets themselves
+__global__ __launch_bounds__(kBlock) void k_iota_offsets(uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t read_len)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r <= n_reads; r += stride) offsets[r] = r * read_len;
+}
+
 // ASCII -> 2-bit packed on the device (dbgk_pack_bases_device; the host twin is dbgk_pack_bases): one lane per 16 bases
 __global__ __launch_bounds__(kBlock) void k_pack_bases(const char *__restrict__ bases, uint64_t n_bases, uint32_t *__restrict__ packed,
                                                       Counters *__restrict__ ctr)

@@ -580,7 +580,9 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // SPECIAL (regular tiles of the equal-length kernel, k >= 17, every lane's NPOS windows valid): the rolls work on the 32-bit halves
 // -- with 2k > 32 the head mask only touches the high word and the entering complement base only the high word of rc -- and the
 // per-position validity test is gone.
-template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds, bool SPECIAL = false>
+// ROLL32 (k >= 17, any validity pattern -- the prefix form of reads of any lengths): the two savings of SPECIAL that do not depend on
+// every window being valid -- the 32-bit rolls, and the neighbour codes taken after the strand select
+template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds, bool SPECIAL = false, bool ROLL32 = SPECIAL>
 __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
 {
@@ -599,10 +601,11 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		const uint64_t key = rev ? c.rc : c.kbit;
 		// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
 		uint32_t links;
-		if constexpr (SPECIAL) { // the packed words are selected, the two codes extracted once
+		if constexpr (ROLL32) { // the packed words are selected, the two codes extracted once
 			uint32_t wa = rev ? nbc : c.lw, wb = rev ? lwc : c.nb;
 			asm volatile("" : "+v"(wa), "+v"(wb)); // two selects, not a branch
-			links = (((wa >> sh) & 3u) << 3) | ((wb >> sh) & 3u); // (never a KFREQ handle: the host keeps those on the general form)
+			links = (((wa >> sh) & 3u) << 3) | ((wb >> sh) & 3u);
+			if constexpr (!SPECIAL) links = G.kf ? 4u : links; // KFREQ: (lb, rb) = (0, none)  (SPECIAL: never a KFREQ handle, the host keeps those on the general form)
 		} else {
 			uint32_t lf = (left << 3) | right, lr = (((nbc >> sh) & 3u) << 3) | ((lwc >> sh) & 3u);
 			asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
@@ -641,7 +644,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kL1MaxB + (tid & 63u);
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
 		// roll to the next position (DBGgraph.cpp:71-73)
-		if constexpr (SPECIAL) {
+		if constexpr (ROLL32) {
 			const uint32_t klo = (uint32_t)c.kbit, khi = (uint32_t)(c.kbit >> 32);
 			const uint32_t nhi = __builtin_amdgcn_alignbit(khi, klo, 30u) & (uint32_t)(head_mask >> 32), nlo = (klo << 2) | right;
 			c.kbit = ((uint64_t)nhi << 32) | nlo;
@@ -1275,7 +1278,7 @@ struct PrefixLds {
 	unsigned long long starts[kL1Threads / 64]; // bit l: an entry begins at lane l of the tile
 };
 
-template <int WIDE_D = 0, int C = 16>
+template <int WIDE_D = 0, int C = 16, bool K17 = false> // K17: k >= 17 (the 32-bit rolls of l1_positions)
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch rb, const ReadLanes *__restrict__ ent, const PrefixTile *__restrict__ tiles,
                                                                         const PrefixTotals *__restrict__ tot, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
@@ -1392,7 +1395,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 			c.has_r = (1u << nr) - 1u;            // the read's last window (after trimming) has no right neighbour
 			c.has_l = cc ? 0xFFFFu : 0xFFFEu;     // its first window no left one
 		}
-		const bool zero_seen = l1_positions<WIDE_D, C, ScatterLds, false>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
+		const bool zero_seen = l1_positions<WIDE_D, C, ScatterLds, false, K17>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile: its words and entries travel during this tile's scatter; the meta data of the tile after it as well
 		const uint64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;

@@ -220,6 +220,11 @@ int dbgk_push_reads_packed(dbgk_handle *h, const uint32_t *packed, const uint64_
 int dbgk_push_commit_packed(dbgk_handle *h, uint64_t n_reads, uint64_t other_bytes);
 int dbgk_push_reads_packed_device(dbgk_handle *h, const uint32_t *d_packed, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases);
 int dbgk_pack_bases_device(dbgk_handle *h, const char *d_bases, uint64_t n_bases, uint32_t *d_packed);
+/* reads of ONE length (what a sequencer writes, before anything trims them): n_reads reads of read_len bases each, back to back in the
+ * packed format.  No offsets travel (at 150 bases they are a sixth of the packed bytes) and no statistics pass runs in front of
+ * level 1; engines that navigate by offsets get them made on the device.  Otherwise like dbgk_push_reads_packed[_device].      */
+int dbgk_push_reads_packed_uniform(dbgk_handle *h, const uint32_t *packed, uint64_t n_reads, uint32_t read_len, uint64_t other_bytes);
+int dbgk_push_reads_packed_uniform_device(dbgk_handle *h, const uint32_t *d_packed, uint64_t n_reads, uint32_t read_len);
 
 /* same, for reads already resident in device memory of the handle's GPU (both pointers 16-byte
  * aligned, readable through the end of the last read).  Nothing is copied; the buffers must stay

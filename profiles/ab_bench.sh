@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for round in $(seq 1 ${ROUNDS:-3}); do
   for lib in "$@"; do
-    DBGK_LIB=$lib python3 $R/bench.py --steps ${STEPS:-20} --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+    DBGK_LIB=$lib python3 $R/bench.py --steps ${STEPS:-20} --warmup 2 --brief 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read())
 p=j['phases_ms_per_step']

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for round in $(seq 1 ${ROUNDS:-2}); do
   for setting in "$@"; do
     if [ "$setting" = "-" ]; then envs=""; else envs="$setting"; fi
-    env $envs python3 $R/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-h2d 2>/dev/null | python3 -c "
+    env $envs python3 $R/bench.py --steps ${STEPS:-10} --warmup 2 --brief 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read())
 p=j['phases_ms_per_step']

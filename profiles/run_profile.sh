@@ -9,11 +9,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-h2d "$@" > $OUT/kt.log 2>&1 || echo "kt failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 9 --warmup 1 --brief "$@" > $OUT/kt.log 2>&1 || echo "kt failed"
 if [ "${PMC:-1}" = "1" ]; then
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-h2d "$@" > $OUT/pmc_$N.log 2>&1 || echo "pmc $N failed"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $R/bench.py --steps 1 --warmup 0 --brief "$@" > $OUT/pmc_$N.log 2>&1 || echo "pmc $N failed"
 done
 # one summary file: kernel, counter, value, duration_ms
 {
@@ -48,4 +48,4 @@ for r in rows:
 PY
 cat $OUT/kernel_stats.csv | cut -c1-160
 cat $OUT/last_step_timeline.csv | head -60
-[ -f $OUT/pmc_summary.csv ] && cat $OUT/pmc_summary.csv
+if [ -f $OUT/pmc_summary.csv ]; then cat $OUT/pmc_summary.csv; fi

@@ -215,6 +215,68 @@ def test_every_level1_form_takes_packed_batches(capi, oracle, shape, entry):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,k,r", [(150, 31, 250), (64, 31, 250), (100, 17, 250), (150, 31, 100), (20, 31, 250), (97, 32, 97)])
+def test_reads_of_one_length_without_offsets(capi, oracle, L, k, r):
+    """dbgk_push_reads_packed_uniform[_device]: n reads of L bases, no offsets -- every engine (the PARTITION engine's equal-length
+    forms never see offsets; the others get them made on the device), batches cut where a word begins, reads trimmed at -r, reads
+    shorter than k; == the oracle"""
+    rng = random.Random(L * 7 + k)
+    g0 = "".join(rng.choice("ACGT") for _ in range(5000))
+    reads = []
+    for _ in range(2500):
+        s0 = rng.randint(0, len(g0) - L)
+        rd = list(g0[s0:s0 + L])
+        for j in range(L):
+            if rng.random() < 0.01:
+                rd[j] = rng.choice("ACGTNn")
+        reads.append("".join(rd).encode())
+    reads += [b"A" * L] * 40 + [b"T" * L] * 3
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=k, max_read_len=r, init_hash_size=0.001, threads=1)
+    want = ref.nodes.astype(capi.NODE_DTYPE)
+    words, other = capi.pack_bases(bases)
+    n = len(reads)
+    runs = [("partition, host", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "host", 0),
+            ("partition, host, small batches", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "host", 1 << 14),
+            ("partition, device", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), len(bases), "device", 0),
+            ("partition, small store", capi.ENGINE_PARTITION, capi.find_next_prime_ref(PART_SLOTS), 40000, "host", 1 << 14),
+            ("direct, host", capi.ENGINE_DIRECT, 1000003, 0, "host", 1 << 15), ("direct, device", capi.ENGINE_DIRECT, 1000003, 0, "device", 0)]
+    for name, engine, slots, expected, where, batch in runs:
+        with capi.Graph(k=k, table_slots=slots, max_read_len=r, engine=engine, expected_kmers=expected, max_batch_bases=batch) as g:
+            if where == "host":
+                g.push_reads_packed_uniform(words, n, L, other)
+            else:
+                d_w = capi.DeviceBuffer(g, words.nbytes + 64)
+                d_w.from_host(words)
+                g.push_reads_packed_uniform_device(d_w.ptr, n, L)
+                g.sync()
+                d_w.free()
+            st = g.finalize()
+            assert (st.total_reads, st.total_kmers, st.stored_kmers, st.count) == (ref.total_reads, ref.total_kmers, sum(max(0, min(L, r) - k + 1) for _ in reads), ref.count), name
+            assert np.array_equal(g.export_sorted(), want), name
+    if k <= 18:   # the frequency table, both counting paths
+        tabs = []
+        for expected in (0, len(bases)):
+            with capi.Graph(k=k, table_slots=0, max_read_len=r, engine=capi.ENGINE_KFREQ, expected_kmers=expected) as g:
+                g.push_reads_packed_uniform(words, n, L, other)
+                st = g.finalize()
+                tabs.append((int(st.count), int(st.stored_kmers), g.kfreq_counts().tobytes()))
+        with capi.Graph(k=k, table_slots=0, max_read_len=r, engine=capi.ENGINE_KFREQ) as g:
+            g.push_reads(bases, offsets)
+            st = g.finalize()
+            assert tabs[0] == tabs[1] == (int(st.count), int(st.stored_kmers), g.kfreq_counts().tobytes())
+    import wide_checker   # 128-bit keys, atomics and records
+    nodes, total = wide_checker.build(reads, 47 if L >= 47 else k, r)
+    kw = 47 if L >= 47 else k
+    for slots, expected in ((300007, 0), (1 << 26, len(bases))):
+        with capi.Graph(k=kw, table_slots=capi.find_next_prime_ref(slots), max_read_len=r, engine=capi.ENGINE_WIDE, expected_kmers=expected) as g:
+            g.push_reads_packed_uniform(words, n, L, other)
+            st = g.finalize()
+            assert int(st.total_kmers) == total
+            assert np.array_equal(g.wide_export_sorted(), wide_checker.as_sorted_nodes(nodes)), (kw, slots)
+
+
+@pytest.mark.gpu
 def test_seed_index_refuses_packed_batches(capi):
     """its windows are cut at upper-case 'N' (link_scaffold/map_func.cpp:303-324), which two bits cannot carry"""
     with capi.Graph(k=21, table_slots=100003, engine=capi.ENGINE_SEEDIDX) as g:
