@@ -394,18 +394,27 @@ static int zero_table_now(dbgk_handle *h)
 }
 
 // empty the record stores of the PARTITION engine (the table and the counters stay)
-static int clear_record_store(dbgk_handle *h)
+static int clear_record_store(dbgk_handle *h, bool with_counters = false /* also reset the handle's counters (dbgk_reset) */)
 {
 	if (h->chunks_used > 0 && h->stream2) { // region builds on the second stream must not race the memsets
 		HIPCHK(hipEventRecord(h->join_ev, h->stream2));
 		HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev, 0));
 	}
-	HIPCHK(hipMemsetAsync(h->store.cnt1, 0, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4, h->stream));
-	HIPCHK(hipMemsetAsync(h->store.cnt2, 0, (size_t)h->geom.nb_own * h->geom.n2 * 4, h->stream));
-	if (h->three) HIPCHK(hipMemsetAsync(h->cnt_mid, 0, (size_t)h->geom.nb_own * h->fan_mid * 4, h->stream));
-	HIPCHK(hipMemsetAsync(h->store.ovf_n, 0, 16, h->stream));
-	if (h->store.hh) HIPCHK(hipMemsetAsync(h->store.hh, 0, h->store.hh_size * sizeof(Node), h->stream));
-	HIPCHK(hipMemsetAsync(h->store.outgoing_n, 0, 8, h->stream));
+	// the heavy-hitter side table is written only once the overflow list is full: zeroed again only then (read BEFORE ovf_n is cleared)
+	if (h->store.hh)
+		hipLaunchKernelGGL(k_zero_if_greater, dim3(h->n_cu * 4), dim3(kBlock), 0, h->stream, reinterpret_cast<uint4 *>(h->store.hh), h->store.hh_size,
+		                   h->store.ovf_n, (unsigned long long)h->store.ovf_cap);
+	ZeroList z{};
+	int ne = 0;
+	auto add = [&](void *q, size_t bytes) { z.p[ne] = q; z.dwords[ne] = (uint32_t)(bytes / 4); ne++; };
+	add(h->store.cnt1, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 4);
+	add(h->store.cnt2, (size_t)h->geom.nb_own * h->geom.n2 * 4);
+	if (h->three) add(h->cnt_mid, (size_t)h->geom.nb_own * h->fan_mid * 4);
+	add(h->store.ovf_n, 16);
+	add(h->store.outgoing_n, 8);
+	add(h->region_cursor, (kMaxBuildLaunches + 2) * sizeof(unsigned int)); // one work cursor per build launch of the next build, + the exact pass's cursor and count
+	hipLaunchKernelGGL(k_zero_list, dim3(64), dim3(kBlock), 0, h->stream, z, with_counters ? h->d_ctr : (Counters *)nullptr);
+	HIPCHK(hipGetLastError());
 	h->part_built = false;
 	h->exchanged = false;
 	h->part_planned = false;
@@ -703,6 +712,7 @@ static int wide_build_from_records(dbgk_handle *h)
 
 static int reset_state(dbgk_handle *h)
 {
+	bool counters_done = false;
 	// (direct-block form: the build writes every block of the table, also the empty ones -- nothing to zero)
 	if (h->kfreq && !(h->part && h->kf_blocks)) HIPCHK(hipMemsetAsync(h->counts, 0, h->n_counts, h->stream));
 	if (h->wide) {
@@ -730,16 +740,19 @@ static int reset_state(dbgk_handle *h)
 		// if a direct-path write (merge) happens first
 		h->zero_pending = true;
 		h->incr = false;
-		int rc = clear_record_store(h);
+		int rc = clear_record_store(h, true); // (one launch: the stores' control arrays and the counters)
 		if (rc) return rc;
+		counters_done = true;
 	} else {
 		int rc = zero_table_now(h);
 		if (rc) return rc;
 	}
 	if (h->track) HIPCHK(hipMemsetAsync(h->first_pos, 0xFF, h->tslots * 8, h->stream));
 	h->pos_base = 0;
-	HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
-	HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
+	if (!counters_done) {
+		HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(Counters), h->stream));
+		HIPCHK(hipMemsetAsync(&h->d_ctr->polyA_slot, 0xFF, sizeof(unsigned long long), h->stream));
+	}
 	h->finalized = false;
 	h->total_reads = 0;
 	h->host_other_bytes = 0;
@@ -919,6 +932,7 @@ static int setup_partition(dbgk_handle *h)
 	// side table for the surplus of heavy hitters; on a sharded handle it may hold keys of any shard and is
 	// offered to every rank after the build (dbgk_shard_heavy), like the overflow list
 	if (hipMalloc(&P.hh, kHeavyHitterSlots * sizeof(Node)) != hipSuccess) return DBGK_ERR_NOMEM;
+	HIPCHK(hipMemsetAsync(P.hh, 0, kHeavyHitterSlots * sizeof(Node), h->stream)); // once: afterwards it is zeroed again only when it was used (clear_record_store)
 	P.hh_size = kHeavyHitterSlots;
 	P.hh_magic = make_mod_magic(kHeavyHitterSlots);
 	P.inbox = h->sharded ? h->inbox : P.l1;
@@ -1435,7 +1449,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	int rc = span_begin(h, PH_MARK, sp);
 	if (rc) return rc;
 	static_assert(offsetof(Counters, len_max) + sizeof(unsigned long long) - offsetof(Counters, any_dead) == 20, "per-batch fields are contiguous");
-	HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream)); // any_dead, len_min_inv, len_max
+	if (d_offsets) HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream)); // any_dead, len_min_inv, len_max: what k_mark reports per batch
 	// The read-boundary bitmaps are what the general kernels navigate by; the PARTITION engine's level-1 kernel for
 	// (nearly) equal-length reads does without them, so for such a batch only the statistics are taken.  A device
 	// batch tells its shape only after those statistics: the bitmaps follow in a second pass if they are needed.
@@ -1469,6 +1483,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			h->uni_cap = cap;
 		}
 		hipLaunchKernelGGL(k_iota_offsets, dim3(grid_for(h, n_reads + 1)), dim3(kBlock), 0, h->stream, h->uni_offsets, n_reads, (uint64_t)uniform_len);
+		HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream));
 		d_offsets = h->uni_offsets;
 		return DBGK_OK;
 	};
@@ -2486,8 +2501,7 @@ static int part_plan(dbgk_handle *h)
 	}
 	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->geom, h->store, h->tile_prefix);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemsetAsync(h->region_cursor, 0, (kMaxBuildLaunches + 2) * sizeof(unsigned int), h->stream)); // one work cursor per build launch, + the exact pass's cursor and count
-	h->cursors_used = 0;
+	h->cursors_used = 0; // (the work cursors were zeroed with the record stores' control arrays: clear_record_store)
 	int rc = span_begin(h, PH_L2_BUILD_WALL, h->wall_span);
 	if (rc) return rc;
 	h->part_planned = true;
@@ -2557,7 +2571,7 @@ static int build_from_records(dbgk_handle *h)
 	const PartGeom &G = h->geom;
 	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;
 	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
-	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 8; // 1 = level 2, then build
+	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 12; // 1 = level 2, then build (8 .. 16 within noise, 12 and 16 ahead on two boxes: profiles/r04_env_sweep_chunks_l2grid.txt)
 	uint32_t n_chunks = (dbg_l2 || dbg_build || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
 	int rc = part_plan(h);
 	if (rc) return rc;
@@ -2603,7 +2617,7 @@ static int build_from_records(dbgk_handle *h)
 		                   h->tref(), h->d_ctr);
 		// the aggregated surplus of heavy hitters (empty slots are all-zero records and add nothing)
 		hipLaunchKernelGGL(k_merge_nodes, dim3(grid_for(h, h->store.hh_size)), dim3(kBlock), 0, h->stream, h->store.hh, h->store.hh_size,
-		                   h->tref(), h->d_ctr);
+		                   h->tref(), h->d_ctr, (const unsigned long long *)h->store.ovf_n, (unsigned long long)h->store.ovf_cap); // (in use only once the overflow list is full)
 	} else {
 		// spill nodes of this shard's regions stay in the shard unless they run off its end (-> outgoing);
 		// overflow triples may belong to any shard: the caller exchanges them (dbgk_shard_overflow)

@@ -741,9 +741,12 @@ __global__ __launch_bounds__(kBlock) void k_extract_store(ReadBatch rb, uint64_t
 // ---------------------------------------------------------------------------------------------
 
 // merge pre-aggregated nodes: insert-if-absent + per-byte saturating add (multi-GPU merge, rehash)
+// only_if_gt / than: the list is scanned only if *only_if_gt > than (the heavy-hitter side table: in use once the overflow list is full)
 __global__ __launch_bounds__(kBlock) void k_merge_nodes(const Node *__restrict__ in, uint64_t n, TableRef T,
-                                                        Counters *__restrict__ ctr)
+                                                        Counters *__restrict__ ctr, const unsigned long long *__restrict__ only_if_gt = nullptr,
+                                                        unsigned long long than = 0ull)
 {
+	if (only_if_gt && *only_if_gt <= than) return; // (kernel-uniform)
 	__shared__ unsigned long long red[kBlock / 64];
 	unsigned long long n_new = 0, n_conf = 0;
 	bool full = false;
@@ -1216,6 +1219,36 @@ __global__ __launch_bounds__(kBlock) void k_count_other_bytes(const char *__rest
 		for (uint64_t p = n_vec << 4; p < n_bases; p++) n += count_other4((uint32_t)(uint8_t)bases[p] | 0x41414100u);
 	const unsigned long long tot = block_sum(n, red);
 	if (threadIdx.x == 0 && tot) atomicAdd(&ctr->other_bytes, tot);
+}
+
+// The small control arrays of a step (bucket fill counts, list lengths, work cursors, the counters) zeroed by ONE launch: a
+// dozen hipMemsetAsync calls cost ~8 us each on the stream and a few more on the host, per step and per flush.
+struct ZeroList {
+	void *p[8];
+	uint32_t dwords[8];
+};
+__global__ __launch_bounds__(kBlock) void k_zero_list(ZeroList z, Counters *__restrict__ ctr /* may be null: also reset the counters */)
+{
+	const uint32_t stride = gridDim.x * kBlock, t0 = blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll 1
+	for (int e = 0; e < 8; e++) {
+		uint32_t *q = static_cast<uint32_t *>(z.p[e]);
+		for (uint32_t i = t0; i < z.dwords[e]; i += stride) q[i] = 0u;
+	}
+	if (ctr) { // all zero, except polyA_slot = ~0 (no key-0 node placed)
+		uint32_t *q = reinterpret_cast<uint32_t *>(ctr);
+		const uint32_t lo = (uint32_t)(offsetof(Counters, polyA_slot) / 4u);
+		for (uint32_t i = t0; i < (uint32_t)(sizeof(Counters) / 4u); i += stride) q[i] = (i == lo || i == lo + 1u) ? 0xFFFFFFFFu : 0u;
+	}
+}
+// a buffer that is only ever written when a list overflowed (the heavy-hitter side table: used once the overflow list is full) is
+// only then zeroed again -- 64 MiB per step otherwise
+__global__ __launch_bounds__(kBlock) void k_zero_if_greater(uint4 *__restrict__ buf, uint64_t n_vec, const unsigned long long *__restrict__ value,
+                                                            unsigned long long than)
+{
+	if (*value <= than) return; // (kernel-uniform)
+	const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+	for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_vec; i += stride) buf[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // reads of ONE length, handed over without offsets (dbgk_push_reads_packed_uniform*): the totals k_mark would have summed up ...
