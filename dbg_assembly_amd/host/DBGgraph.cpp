@@ -423,6 +423,9 @@ void parse_one_reads_file(string &reads_file)
 			note_read(S, seq, len);
 		}, [&]() { materialize_noted(S); }, &S.stop_file);
 		if (!ok) cerr << "fail to read reads file " << reads_file << endl;
+		if (getenv("DBGK_TIMINGS"))
+			cerr << "Reader (s, calling thread): first window " << chunked.spent[0] << " record rules " << chunked.spent[1] << " copy/pack + hand-over "
+			     << chunked.spent[2] << " waiting for the next window " << chunked.spent[3] << " (" << S.parse_threads << " threads)" << endl;
 		flush_batch(S);
 	} else {
 		if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); }, &S.stop_file)) {

@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -98,9 +99,16 @@ public:
 	}
 	size_t size() const { return size_; }
 
+	// seconds the calling thread spent (measurements: DBGK_TIMINGS): [0] reading the first window, [1] in the record rules + callbacks,
+	// [2] in end_of_window (the caller's copy / pack), [3] waiting for the window read ahead
+	double spent[4] = {0, 0, 0, 0};
+
 	template <class Callback, class EndOfWindow>
 	bool for_each_read(int format, int n_threads, Callback cb, EndOfWindow end_of_window, const bool *stop = nullptr)
 	{
+		auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		double t_mark = now();
+		auto lap = [&](int i) { const double t = now(); spent[i] += t - t_mark; t_mark = t; };
 		const char marker = (format == 1) ? '@' : '>';
 #ifdef DBGK_READS_WINDOW
 		const size_t WINDOW = DBGK_READS_WINDOW; // (tests: windows of a few hundred bytes)
@@ -162,6 +170,7 @@ public:
 		size_t file_off = 0;
 		int cur = 0;
 		if (size_ > 0) read_window(win[0], 0, NULL, 0);
+		lap(0);
 		while (file_off < size_ && !(stop && *stop)) {
 			Window &W = win[cur];
 			if (!W.ok) return release(), false;
@@ -199,8 +208,11 @@ public:
 					default: state = 0; break;
 				}
 			}
+			lap(1);
 			if (!(stop && *stop)) end_of_window(); // the records shown so far are copied now: this buffer is read into again two windows on
+			lap(2);
 			if (ahead.joinable()) ahead.join();
+			lap(3);
 			file_off = next_off;
 			cur ^= 1;
 		}

@@ -30,5 +30,5 @@ for rep in range(3):
     r = subprocess.run([cli, "-k", "31", "-f", "2", "-t", "16", "-i", "0.6", "-o", os.path.join(tmp, "cfg2_cli_out"), libf], env=env,
                        capture_output=True, text=True)
     wall = time.time() - t0
-    lines = [l for l in r.stderr.splitlines() if l.startswith(("Host phases", "GPU phases", "count:", "Wall phases"))]
+    lines = [l for l in r.stderr.splitlines() if l.startswith(("Host phases", "GPU phases", "count:", "Wall phases", "Reader"))]
     print("run %d: rc %d wall %.3f s %s" % (rep, r.returncode, wall, " | ".join(lines)), flush=True)

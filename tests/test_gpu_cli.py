@@ -178,24 +178,34 @@ def test_cli_multi_gpu_path(tmp_path, case, gpus, store):
     assert re.search(r"^array_size:\t%d$" % ref["size"], r.stderr, re.M)
 
 
-@pytest.mark.parametrize("store", [None, "300000000"], ids=["one_build", "four_flush_rounds"])
-def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, oracle, store):
-    """The FULL BASELINE cfg2 workload (10 M x 150 bp reads as a 1.6 GB one-line FASTA file) through the command line:
-    node count, totals and `<prefix>.contig.kmer.freq` (DepthStat rows 1..255) == tests/golden/cfg2_full.json, which the
-    CPU oracle computed at full size.  Second run: a record store of 300 M occurrences, i.e. the input streams through
-    four flush rounds of the PARTITION engine (incremental region builds over the whole 9.6 GB table)."""
+@pytest.fixture(scope="module")
+def cfg2_fasta(tmp_path_factory, oracle):
+    """the FULL BASELINE cfg2 workload as a 1.6 GB one-line FASTA file, written ONCE for the tests that run the command line on it"""
     import ctypes as C
     import json
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg2_full.json")))
-    fa = str(tmp_path / "reads.fa")
+    fa = str(tmp_path_factory.mktemp("cfg2") / "reads.fa")
     PO = oracle.synth_params(gold["genome_len"], 150, cfg=2)
     oracle.lib().orc_synth_write_file(C.byref(PO), 0, gold["n_reads"], os.fsencode(fa), 2, 0)
+    yield gold, fa
+    os.remove(fa)
+
+
+@pytest.mark.parametrize("store", [None, "300000000"], ids=["one_build", "four_flush_rounds"])
+def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, cfg2_fasta, store):
+    """The FULL BASELINE cfg2 workload (10 M x 150 bp reads as a 1.6 GB one-line FASTA file) through the command line:
+    node count, totals and `<prefix>.contig.kmer.freq` (DepthStat rows 1..255) == tests/golden/cfg2_full.json, which the
+    CPU oracle computed at full size.  Second run: a record store of 300 M occurrences, i.e. the input streams through
+    four flush rounds of the PARTITION engine (incremental region builds over the whole 9.6 GB table); it also hands the
+    reads over as ASCII (DBGK_HOST_ASCII=1), the first run 2 bits per base (the default)."""
+    gold, fa = cfg2_fasta
     lib = tmp_path / "reads.lib"
     lib.write_text(fa + "\n")
     prefix = tmp_path / "out"
     env = dict(os.environ, DBGK_TIMINGS="1")
     if store:
         env["DBGK_STORE_KMERS"] = store
+        env["DBGK_HOST_ASCII"] = "1"
     r = subprocess.run([CLI, "-k", "31", "-f", "2", "-i", "0.6", "-t", "16", "-o", str(prefix), str(lib)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -206,7 +216,6 @@ def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, oracle, store):
     assert "engine partition" in log
     rows = open(str(prefix) + ".contig.kmer.freq").read().splitlines()
     assert rows[0] == KMER_FREQ_HEADER and [int(x.split("\t")[1]) for x in rows[1:]] == gold["depth_stat"][1:]
-    os.remove(fa)
 
 
 @pytest.mark.parametrize("k,env", [(63, {}), (33, {"DBGK_WIDE_PASSES": "3"}), (47, {"DBGK_GPU_LIST": "0,0,0"}), (63, {"DBGK_WIDE_DIRECT": "1"})],

@@ -425,7 +425,7 @@ def test_full_size_direct_vs_partition_digest(capi):
 
 
 @pytest.mark.parametrize("L,k", [(100, 31), (130, 31), (110, 17)])
-def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle, L, k):
+def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle, L, k, monkeypatch):
     """RAGGED form of the lane-per-chunk level-1 kernel with a lane count per read (Q) that does not divide
     the 1024 lanes of a tile, and some reads much shorter than C * (Q - 1): a tile can then start in the
     empty tail lanes of a short read, and its byte range must start at the NEXT read (round-1 advisor
@@ -444,15 +444,21 @@ def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[idx]].copy()
     size = capi.find_next_prime_ref(PART_SLOTS)
     res = []
-    for engine in (capi.ENGINE_DIRECT, capi.ENGINE_PARTITION):
+    # (since round 4 such a batch takes the prefix form by default -- exact lane counts per read; DBGK_L1_PREFIX=0 keeps the ragged form,
+    # which stays in the library: both are run)
+    for engine, prefix in ((capi.ENGINE_DIRECT, None), (capi.ENGINE_PARTITION, "0"), (capi.ENGINE_PARTITION, "1")):
+        if prefix is not None:
+            monkeypatch.setenv("DBGK_L1_PREFIX", prefix)
         with capi.Graph(k=k, table_slots=size, engine=engine, expected_kmers=int(offsets[-1]), max_batch_bases=int(offsets[-1]) + 4096) as g:
             g.push_reads(bases, offsets)   # ONE batch: the tiles of interest need many reads in a row
             st = g.finalize()
-            if engine == capi.ENGINE_PARTITION:
+            if prefix == "0":
                 assert g.timings().uniform_launches == 1, "the batch was expected to take the ragged lane-per-chunk kernel"
+            if prefix == "1":
+                assert g.timings().prefix_launches == 1, "the batch was expected to take the prefix form"
             res.append((int(st.count), int(st.stored_kmers), g.digest()))
             nodes = g.export_sorted()
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2]
     ref = oracle.build_graph(files_mem=[(bases, offsets)], k=k, init_hash_size=0.02, threads=1)
     assert res[1][0] == ref.count and np.array_equal(nodes, ref.nodes)
 
