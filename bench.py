@@ -144,8 +144,8 @@ def measured_traffic(args, size, kernel):
         for entry in t.get("workloads", [t]):
             w = entry.get("workload", {})
             per = entry.get("bytes_per_launch", {})
-            if (w.get("reads_per_gpu"), w.get("kmer"), w.get("table_slots"), w.get("engine"), w.get("input", "ascii")) == \
-                    (args.reads_per_gpu, args.kmer, size, args.engine, args.input) and (kernel is None or kernel in per):
+            if (w.get("config", "cfg2"), w.get("reads_per_gpu"), w.get("kmer"), w.get("table_slots"), w.get("engine"), w.get("input", "ascii")) == \
+                    (args.config, args.reads_per_gpu, args.kmer, size, args.engine, args.input) and (kernel is None or kernel in per):
                 best = sum(per.values()) if kernel is None else per[kernel]
     return best
 
@@ -854,7 +854,7 @@ def run_graph(args, ctx, brief=False):
         # level 1 reads the bases and writes one 8-byte record per k-mer, level 2 reads and writes every
         # record, the region build reads every record and writes every 16-byte table slot once.
         l1_name = "k_wide_extract_insert" if args.engine == capi.ENGINE_WIDE else "k_extract_insert" if args.engine != capi.ENGINE_PARTITION else \
-                  ("k_extract_scatter_uniform" if tm.uniform_launches else "k_extract_scatter")  # equal-length reads take the former
+                  ("k_extract_scatter_prefix" if tm.prefix_launches else "k_extract_scatter_uniform" if tm.uniform_launches else "k_extract_scatter")  # mixed lengths / equal lengths / the flat kernel
         l1_ms = tm.insert_ms / args.steps
         l2_ms, build_ms, wall_ms = tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
         slots_local = size // world if sharded else size
@@ -864,7 +864,7 @@ def run_graph(args, ctx, brief=False):
                          "k_build_regions": kmers_step * 8.0 + slots_local * 16.0}
             kernel_ms = {l1_name: l1_ms, "k_scatter_l2": l2_ms, "k_build_regions": build_ms}
         elif wide_records:
-            l1_name = "k_wide_scatter_l1"
+            l1_name = "k_wide_scatter_l1_uniform" if tm.uniform_launches else "k_wide_scatter_l1"
             own_bytes = {l1_name: kmers_step * (base_bytes + 16.0), "k_wide_scatter_l2": kmers_step * 32.0,
                          "k_wide_build_regions": kmers_step * 16.0 + slots_local * 32.0}
             kernel_ms = {l1_name: l1_ms, "k_wide_scatter_l2": l2_ms, "k_wide_build_regions": build_ms}

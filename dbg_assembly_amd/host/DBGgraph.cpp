@@ -147,7 +147,7 @@ struct Session {
 	uint64_t reads_in_block = 0;           // reads since the last full block of the current file
 	bool stop_file = false;                // the reference would have left this file's block loop (-e cap)
 	// host wall clock per phase (DBGK_TIMINGS): device calls made while parsing are timed on their own
-	double t_create = 0, t_parse = 0, t_push = 0, t_count = 0, t_finalize = 0, t_export = 0;
+	double t_create = 0, t_parse = 0, t_push = 0, t_count = 0, t_finalize = 0, t_export = 0, t_pack = 0;
 	// DBGK_LAYOUT=ref: reproduce the reference's -t 1 slot layout (first-seen order replay)
 	bool ref_layout = false;
 	uint64_t pos = 0;                      // bases handed to the device so far (+ pending batch)
@@ -256,6 +256,7 @@ void materialize_noted(Session &S)
 {
 	if (S.noted.empty()) return;
 	acquire_staging(S);
+	Stopwatch sw_pack(S.t_pack);
 	const size_t first = S.offsets.size() - 1 - S.noted.size();
 	S.bases.grow_uninitialized(S.noted_bytes);
 	const int T = std::max(1, std::min(S.parse_threads, (int)(S.noted.size() / 4096 + 1)));
@@ -393,6 +394,48 @@ inline void note_read(Session &S, const char *seq, size_t len)
 	else if (S.offsets.back() >= S.batch_limit) flush_batch(S);
 }
 
+// note_read for a run of records (what one reader thread found in its slice of a file window): the same decisions at the same
+// reads -- a flush when the batch would outgrow the staging buffer, the check after every FULL block of BufferNum reads
+// (DBGgraph.cpp:337-351), a flush when the batch limit is reached -- but between two decisions the bookkeeping is one tight loop
+static_assert(sizeof(ChunkedReadsFile::ReadRef) == sizeof(dbgk_read_ref) && offsetof(ChunkedReadsFile::ReadRef, len) == offsetof(dbgk_read_ref, len),
+              "the reader's record reference is dbgk_read_ref");
+void note_reads(Session &S, const ChunkedReadsFile::ReadRef *recs, size_t n)
+{
+	const uint64_t B = (uint64_t)std::max(BufferNum, 1), K = (uint64_t)KmerSize, R = (uint64_t)maxReadLen;
+	const uint64_t limit = S.batch_limit;
+	size_t i = 0;
+	while (i < n && !S.stop_file) {
+		const size_t base_idx = S.offsets.size();
+		const size_t run = (size_t)std::min<uint64_t>(n - i, B - S.reads_in_block);
+		const uint64_t start = S.offsets.back();
+		uint64_t cur = start, bound = 0;
+		bool flush_before = false, flush_after = false;
+		S.offsets.resize(base_idx + run);
+		uint64_t *off = S.offsets.data() + base_idx;
+		size_t j = 0;
+		for (; j < run; j++) {
+			const uint64_t len = recs[i + j].len;
+			if (S.zero_copy && cur + len > limit + (1u << 16) && base_idx + j > 1) { flush_before = true; break; } // keep the batch inside the staging buffer
+			cur += len;
+			off[j] = cur;
+			const uint64_t rl = len < R ? len : R;
+			bound += rl >= K ? rl - K + 1 : 0;
+			if (cur >= limit) { j++; flush_after = true; break; }
+		}
+		S.offsets.resize(base_idx + j);
+		const dbgk_read_ref *src = reinterpret_cast<const dbgk_read_ref *>(recs + i);
+		S.noted.insert(S.noted.end(), src, src + j);
+		S.noted_bytes += cur - start;
+		S.bound_since += bound;
+		S.pos += cur - start;
+		S.reads_in_block += j;
+		i += j;
+		if (S.reads_in_block == B) end_of_full_block(S);
+		else if (flush_after) flush_batch(S);
+		if (flush_before) flush_batch(S); // (the read that did not fit opens the next batch)
+	}
+}
+
 }  // namespace
 
 void *thread_parseBlock(void *)
@@ -418,14 +461,19 @@ void parse_one_reads_file(string &reads_file)
 	static const bool sequential = getenv("DBGK_PARSE_SEQUENTIAL") != nullptr;
 	if (const char *pt = getenv("DBGK_PARSE_THREADS")) S.parse_threads = std::max(1, atoi(pt));
 	if (!sequential && chunked.open(reads_file)) { // a plain file: windows read, lines found and bytes copied by several threads
-		const bool ok = chunked.for_each_read(Input_file_format, S.parse_threads, [&](const char *seq, size_t len) {
-			if (len >> 32) { S.stop_file = true; return; } // (a 4 GiB line is no read)
+		static const bool per_record = getenv("DBGK_PARSE_PER_RECORD") != nullptr; // (measurements: the record rules and the bookkeeping read by read on the calling thread)
+		const bool ok = per_record ? chunked.for_each_read(Input_file_format, S.parse_threads, [&](const char *seq, size_t len) {
+			if (chunked.too_long) { S.stop_file = true; return; } // (a 4 GiB line is no read)
 			note_read(S, seq, len);
+		}, [&]() { materialize_noted(S); }, &S.stop_file)
+		                           : chunked.for_each_read_bulk(Input_file_format, S.parse_threads, [&](const ChunkedReadsFile::ReadRef *recs, size_t n) {
+			if (chunked.too_long) { S.stop_file = true; return; } // (a 4 GiB line is no read)
+			note_reads(S, recs, n);
 		}, [&]() { materialize_noted(S); }, &S.stop_file);
 		if (!ok) cerr << "fail to read reads file " << reads_file << endl;
 		if (getenv("DBGK_TIMINGS"))
-			cerr << "Reader (s, calling thread): first window " << chunked.spent[0] << " record rules " << chunked.spent[1] << " copy/pack + hand-over "
-			     << chunked.spent[2] << " waiting for the next window " << chunked.spent[3] << " (" << S.parse_threads << " threads)" << endl;
+			cerr << "Reader (s, calling thread): first window " << chunked.spent[0] << " records -> batches " << chunked.spent[1] << " copy/pack + hand-over "
+			     << chunked.spent[2] << " waiting for the next window " << chunked.spent[3] << " (" << S.parse_threads << " threads); of all that, packing / copying the reads into the batches " << S.t_pack << endl;
 		flush_batch(S);
 	} else {
 		if (!for_each_read_in_file(reads_file, Input_file_format, [&](const char *seq, size_t len) { add_read(S, seq, len); }, &S.stop_file)) {

@@ -161,6 +161,7 @@ int main(int argc, char **argv)
 	rc = comm ? dbgk_comm_finalize(comm, &st) : dbgk_finalize(h, &st);
 	if (rc) die("dbgk_finalize", rc);
 	cerr << "reads " << st.total_reads << "  k-mers " << st.stored_kmers << "  distinct canonical k-mers " << st.count << endl;
+	if (st.other_bytes) cerr << "Alert message: " << st.other_bytes << " sequence bytes are none of ACGTNacgtn; they were read as A (like N)" << endl;
 
 	// blocks of 8 Mi k-mers; compressed independently by a small thread pool, written in order
 	const uint64_t total = 1ull << (2 * k);
