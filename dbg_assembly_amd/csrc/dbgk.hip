@@ -10,6 +10,8 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <chrono>
+#include <emmintrin.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1026,6 +1028,12 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 		return DBGK_ERR_ARG;
 	if (seed && (cfg->shard_count || (cfg->flags & DBGK_FLAG_TRACK_FIRST_SEEN))) return DBGK_ERR_ARG;
 
+	// DBGK_TIMINGS: where the time of creating a handle goes (stderr, one line)
+	static const bool lap_wanted = getenv("DBGK_TIMINGS") != nullptr;
+	double laps[6] = {0, 0, 0, 0, 0, 0};
+	auto clock_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double lap_t = clock_s();
+	auto lap = [&](int i) { const double t = clock_s(); laps[i] += t - lap_t; lap_t = t; };
 	int n_dev = 0;
 	hipError_t e = hipGetDeviceCount(&n_dev);
 	if (e != hipSuccess || n_dev <= 0) {
@@ -1033,6 +1041,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 		return DBGK_ERR_HIP;
 	}
 	if (cfg->device_id < 0 || cfg->device_id >= n_dev) return DBGK_ERR_ARG;
+	lap(0);
 
 	dbgk_handle *h = new (std::nothrow) dbgk_handle();
 	if (!h) return DBGK_ERR_NOMEM;
@@ -1093,6 +1102,7 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	h->grid = h->n_cu * 8; // 8 x 256-thread blocks per CU = 32 waves/CU, the residency limit
 
 	if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(DBGK_ERR_HIP);
+	lap(1);
 	if (kfreq) {
 		h->n_counts = 1ull << (2 * cfg->kmer_size);
 		if (h->n_counts < 64) h->n_counts = 64; // whole dwords / 8-byte groups for the scan kernels (k < 3)
@@ -1128,18 +1138,28 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	if (hipHostMalloc(&h->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) return fail(DBGK_ERR_NOMEM);
 	h->cap_bases = cfg->max_batch_bases ? cfg->max_batch_bases : (256ull << 20);
 	h->cap_reads = h->cap_bases / 16 + 1024;
+	lap(2);
 	{
 		const int prc = setup_partition(h);
 		if (prc != DBGK_OK) return fail(prc);
 	}
+	lap(3);
 	int rc = reset_state(h);
 	if (rc != DBGK_OK) return fail(rc);
-	if (cfg->flags & DBGK_FLAG_PREALLOC_STAGING)
-		for (StageSlot &sl : h->slots) {
-			rc = ensure_slot(h, sl);
-			if (rc != DBGK_OK) return fail(rc);
-		}
+	if (lap_wanted && hipStreamSynchronize(h->stream) != hipSuccess) return fail(DBGK_ERR_HIP);
+	lap(4);
+	if (cfg->flags & DBGK_FLAG_PREALLOC_STAGING) { // page-locking is most of it, and two threads lock two buffers in about the time of one
+		int rc1 = DBGK_OK;
+		std::thread second([&]() { rc1 = hipSetDevice(h->device) == hipSuccess ? ensure_slot(h, h->slots[1]) : DBGK_ERR_HIP; });
+		rc = ensure_slot(h, h->slots[0]);
+		second.join();
+		if (rc != DBGK_OK || rc1 != DBGK_OK) return fail(rc != DBGK_OK ? rc : rc1);
+	}
 	if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(DBGK_ERR_HIP);
+	lap(5);
+	if (lap_wanted)
+		fprintf(stderr, "dbgk_create (s): runtime start %.4f device+stream %.4f table %.4f record store %.4f first reset %.4f staging %.4f\n", laps[0], laps[1],
+		        laps[2], laps[3], laps[4], laps[5]);
 	*out = h;
 	return DBGK_OK;
 }
@@ -2803,6 +2823,257 @@ static int d2h_pipelined(dbgk_handle *h, void *dst, const void *d_src, size_t by
 	return DBGK_OK;
 }
 
+// ---- the occupied nodes only ----------------------------------------------------------------------------------------------------
+// A host table at the reference's load (-i: 0.3 - 0.6 of the slots hold a node) is mostly zeros: the copy above moves all of it over
+// the link.  Here the device packs the occupied nodes, in slot order, into one stream (k_compact_nodes), only that stream and the
+// occupancy bits cross the link, and the host threads that used to memcpy() the slices now lay the nodes out at their slots from the
+// bits (zeros in between).  Same bytes in `array` and `nul_flag` as the plain copy (tests/test_gpu_parity.py compares the two).
+constexpr uint32_t kCompactSpan = 4096; // slots per wavefront
+
+__global__ __launch_bounds__(256) void k_flag_block_counts(const uint32_t *__restrict__ flags32, uint64_t n_dwords, uint64_t n_spans,
+                                                           uint32_t *__restrict__ counts)
+{
+	const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+	const uint32_t lane = threadIdx.x & 63u;
+	if (wave >= n_spans) return;
+	uint32_t c = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kCompactSpan / 32 / 64; j++) {
+		const uint64_t d = wave * (kCompactSpan / 32) + j * 64 + lane;
+		if (d < n_dwords) c += (uint32_t)__popc(flags32[d]);
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+	if (lane == 0) counts[wave] = c;
+}
+
+__global__ __launch_bounds__(256) void k_compact_nodes(const Node *__restrict__ nodes, uint64_t size, const Counters *__restrict__ ctr,
+                                                       const uint64_t *__restrict__ span_first, uint64_t n_spans, Node *__restrict__ out)
+{
+	const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+	const uint32_t lane = threadIdx.x & 63u;
+	if (wave >= n_spans) return;
+	const uint64_t polyA_slot = ctr->polyA_slot;
+	uint64_t at = span_first[wave];
+	const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(nodes);
+	ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(out);
+	for (uint32_t it = 0; it < kCompactSpan / 64; it++) {
+		const uint64_t i = wave * kCompactSpan + it * 64 + lane;
+		ulonglong2 nd = make_ulonglong2(0ull, 0ull);
+		bool occ = false;
+		if (i < size) {
+			nd = src[i];
+			occ = nd.x != 0ull || i == polyA_slot; // what k_build_flags_ctr calls occupied
+		}
+		const uint64_t m = __ballot(occ);
+		if (occ) dst[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = nd;
+		at += (uint64_t)__popcll(m);
+	}
+}
+
+// array[0, host_size) and nul_flag[0, host_size / 8 + 1) from the image T whose occupancy bits are d_flags (padded to whole dwords,
+// the padding zero).  DBGK_ERR_STATE: "use the plain copy" (no memory for the stream, or the counts disagree).
+// Page-locked memory: the staging buffers of the handle's batches where they exist -- idle once a table is finalized, and
+// page-locking fresh memory for one copy costs about what the copy costs -- else the handle's own export buffers (d2h_stage).
+static int d2h_compact(dbgk_handle *h, dbgk_node *array, uint8_t *nul_flag, const TableRef &T, const uint8_t *d_flags, uint64_t n_occ)
+{
+	constexpr size_t kSlice = 8ull << 20, kOwnSlice = 32ull << 20; // (d2h_stage holds pieces of 32 MiB: four slices each)
+	constexpr size_t kMinBuffers = 16, kOwnBuffers = 8, kMaxBuffers = 48;
+	static const int n_threads = getenv("DBGK_EXPORT_THREADS") ? std::max(1, atoi(getenv("DBGK_EXPORT_THREADS"))) : 12;
+	const uint64_t size = T.size, n_spans = (size + kCompactSpan - 1) / kCompactSpan, n_flag_bytes = size / 8 + 1;
+	static const bool lap_wanted = getenv("DBGK_TIMINGS") != nullptr;
+	auto clock_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double laps[5] = {0, 0, 0, 0, 0}, lap_t = clock_s();
+	auto lap = [&](int i) { const double t = clock_s(); laps[i] += t - lap_t; lap_t = t; };
+	std::atomic<uint64_t> wait_link_us{0}, wait_host_us{0};
+	Node *d_stream = nullptr;
+	uint32_t *d_counts = nullptr;
+	uint64_t *d_first = nullptr;
+	auto cleanup = [&]() {
+		for (void *p : {(void *)d_stream, (void *)d_counts, (void *)d_first})
+			if (p) (void)hipFree(p);
+	};
+	if (hipMalloc(&d_stream, (n_occ + 1) * sizeof(Node)) != hipSuccess || hipMalloc(&d_counts, n_spans * 4) != hipSuccess ||
+	    hipMalloc(&d_first, n_spans * 8) != hipSuccess) {
+		(void)hipGetLastError();
+		cleanup();
+		return DBGK_ERR_STATE;
+	}
+	// page-locked pieces: [the occupancy bits] + the slices the stream passes through
+	std::vector<char *> bufs;
+	uint8_t *bits_pinned = nullptr;
+	const size_t flag_room = (size_t)((n_flag_bytes + kSlice - 1) / kSlice) * kSlice;
+	for (StageSlot &sl : h->slots) {
+		if (!sl.h_bases || sl.acquired) continue;
+		if (sl.busy && hipEventQuery(sl.done) != hipSuccess) continue; // (a batch still on its way: not after dbgk_finalize)
+		size_t off = 0;
+		if (!bits_pinned && h->cap_bases >= flag_room + kSlice) {
+			bits_pinned = reinterpret_cast<uint8_t *>(sl.h_bases);
+			off = flag_room;
+		}
+		for (; off + kSlice <= h->cap_bases && bufs.size() < kMaxBuffers; off += kSlice) bufs.push_back(sl.h_bases + off);
+	}
+	if (bufs.size() < kMinBuffers) {
+		while (h->d2h_stage.size() < kOwnBuffers) {
+			void *p = nullptr;
+			if (hipHostMalloc(&p, kOwnSlice, hipHostMallocDefault) != hipSuccess) { cleanup(); return DBGK_ERR_NOMEM; }
+			h->d2h_stage.push_back(p);
+		}
+		for (void *p : h->d2h_stage)
+			for (size_t off = 0; off + kSlice <= kOwnSlice && bufs.size() < kMaxBuffers; off += kSlice) bufs.push_back(static_cast<char *>(p) + off);
+	}
+	while (h->d2h_ev.size() < bufs.size()) {
+		hipEvent_t ev = nullptr;
+		if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { cleanup(); return DBGK_ERR_HIP; }
+		h->d2h_ev.push_back(ev);
+	}
+	const size_t n_bufs = bufs.size();
+	lap(0);
+	const unsigned int span_grid = (unsigned int)((n_spans + 3) / 4);
+	hipLaunchKernelGGL(k_flag_block_counts, dim3(span_grid), dim3(256), 0, h->stream, reinterpret_cast<const uint32_t *>(d_flags),
+	                   (n_flag_bytes + 3) / 4, n_spans, d_counts);
+	std::vector<uint32_t> counts(n_spans);
+	std::vector<uint64_t> first(n_spans + 1);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_counts, n_spans * 4, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) { cleanup(); return hip_fail(e, "d2h_compact(counts)", __LINE__); }
+	first[0] = 0;
+	for (uint64_t b = 0; b < n_spans; b++) first[b + 1] = first[b] + counts[b];
+	if (first[n_spans] != n_occ) { // (never: the counters and the bits describe the same table)
+		cleanup();
+		return DBGK_ERR_STATE;
+	}
+	lap(1);
+	e = hipMemcpyAsync(d_first, first.data(), n_spans * 8, hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(bits_pinned ? bits_pinned : nul_flag, d_flags, n_flag_bytes, hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_compact_nodes, dim3(span_grid), dim3(256), 0, h->stream, T.nodes, size, h->d_ctr, d_first, n_spans, d_stream);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream); // the bits are on the host: the threads below read them
+	if (e != hipSuccess) { cleanup(); return hip_fail(e, "d2h_compact(bits)", __LINE__); }
+	lap(2);
+	// slices of the stream small enough that every thread gets several (the zeros between the nodes are written by the thread
+	// whose nodes come next, so the slot ranges follow the ranks)
+	const uint64_t per = std::min<uint64_t>(kSlice / sizeof(Node), std::max<uint64_t>(1u << 16, n_occ / (uint64_t)(4 * n_threads) + 1));
+	const size_t n_slices = (size_t)((n_occ + per - 1) / per);
+	const uint8_t *bits_src = bits_pinned ? bits_pinned : nul_flag;
+	auto occupied = [&](uint64_t slot) { return (bits_src[slot >> 3] >> (7u - (uint32_t)(slot & 7u))) & 1u; };
+	auto slot_of_rank = [&](uint64_t r) -> uint64_t { // the slot of the r-th occupied node (r < n_occ)
+		const uint64_t b = (uint64_t)(std::upper_bound(first.begin(), first.end(), r) - first.begin()) - 1;
+		uint64_t slot = b * kCompactSpan, left = r - first[b];
+		for (;; slot++)
+			if (occupied(slot)) {
+				if (left == 0) return slot;
+				left--;
+			}
+	};
+	if (getenv("DBGK_EXPORT_PROBE")) { // (measurements) the link alone: the same copies with nobody reading the buffers
+		const double t0 = clock_s();
+		for (size_t i = 0; i < n_slices; i++) {
+			const uint64_t r0 = (uint64_t)i * per, r1 = std::min(n_occ, r0 + per);
+			(void)hipMemcpyAsync(bufs[i % n_bufs], d_stream + r0, (size_t)(r1 - r0) * sizeof(Node), hipMemcpyDeviceToHost, h->stream);
+		}
+		(void)hipStreamSynchronize(h->stream);
+		const double t1 = clock_s();
+		fprintf(stderr, "dbgk export probe: %zu copies of %.1f MB back to back %.4f s (%.1f GB/s)\n", n_slices, (double)per * 16e-6, t1 - t0,
+		        (double)n_occ * 16e-9 / (t1 - t0));
+		lap_t = clock_s();
+	}
+	std::vector<std::atomic<int>> issued(n_slices), done(n_slices);
+	for (size_t i = 0; i < n_slices; i++) { issued[i].store(0); done[i].store(0); }
+	std::atomic<int> failed{0};
+	dbgk_node *dst = array;
+	std::vector<std::thread> workers;
+	for (int w = 0; w < n_threads; w++)
+		workers.emplace_back([&, w]() {
+			if (hipSetDevice(h->device) != hipSuccess) { failed.store(1); return; }
+			if (bits_pinned) { // this thread's share of the bits -> the caller's nul_flag
+				const uint64_t chunk = (n_flag_bytes + (uint64_t)n_threads - 1) / (uint64_t)n_threads;
+				const uint64_t a = std::min(n_flag_bytes, chunk * (uint64_t)w), b = std::min(n_flag_bytes, a + chunk);
+				memcpy(nul_flag + a, bits_pinned + a, (size_t)(b - a));
+			}
+			for (size_t i = (size_t)w; i < n_slices; i += (size_t)n_threads) {
+				const uint64_t r0 = (uint64_t)i * per, r1 = std::min(n_occ, r0 + per);
+				uint64_t slot = i == 0 ? 0 : slot_of_rank(r0);
+				const uint64_t slot_end = i + 1 == n_slices ? size : slot_of_rank(r1);
+				while (!issued[i].load(std::memory_order_acquire)) {
+					if (failed.load()) return;
+					std::this_thread::yield();
+				}
+				const size_t b = i % n_bufs;
+				const double t_w = lap_wanted ? clock_s() : 0;
+				if (hipEventSynchronize(h->d2h_ev[b]) != hipSuccess) { failed.store(1); return; }
+				if (lap_wanted) wait_link_us += (uint64_t)((clock_s() - t_w) * 1e6);
+				const dbgk_node *const src0 = reinterpret_cast<const dbgk_node *>(bufs[b]);
+				const dbgk_node *src = src0;
+				const dbgk_node zero{0, 0, 0};
+				for (; slot < slot_end && (slot & 63u); slot++) dst[slot] = occupied(slot) ? *src++ : zero;
+				// 64 slots at a time: zeros and the nodes the bits name (first slot = top bit) are put together in a buffer of one KiB
+				// and leave with non-temporal stores -- the table is written once and not read here: no line is fetched for ownership
+				const bool stream_out = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+				for (; slot + 64 <= slot_end; slot += 64) {
+					uint64_t bits;
+					memcpy(&bits, bits_src + (slot >> 3), 8);
+					bits = __builtin_bswap64(bits);
+					alignas(64) dbgk_node group[64];
+					memset(static_cast<void *>(group), 0, sizeof group);
+					while (bits) {
+						const int j = __builtin_clzll(bits);
+						group[j] = *src++;
+						bits &= ~(0x8000000000000000ull >> j);
+					}
+					if (stream_out) {
+#pragma unroll
+						for (int q = 0; q < 64; q++)
+							_mm_stream_si128(reinterpret_cast<__m128i *>(dst + slot + q), _mm_load_si128(reinterpret_cast<const __m128i *>(group + q)));
+					} else {
+						memcpy(static_cast<void *>(dst + slot), group, sizeof group);
+					}
+				}
+				_mm_sfence();
+				for (; slot < slot_end; slot++) dst[slot] = occupied(slot) ? *src++ : zero;
+				if ((uint64_t)(src - src0) != r1 - r0) failed.store(2); // (never)
+				done[i].store(1, std::memory_order_release);
+			}
+		});
+	int rc = DBGK_OK;
+	for (size_t i = 0; i < n_slices && rc == DBGK_OK; i++) {
+		const double t_w = lap_wanted ? clock_s() : 0;
+		if (i >= n_bufs)
+			while (!done[i - n_bufs].load(std::memory_order_acquire)) { // its buffer is free again
+				if (failed.load()) { rc = DBGK_ERR_HIP; break; }
+				std::this_thread::yield();
+			}
+		if (lap_wanted) wait_host_us += (uint64_t)((clock_s() - t_w) * 1e6);
+		if (rc) break;
+		const size_t b = i % n_bufs;
+		const uint64_t r0 = (uint64_t)i * per, r1 = std::min(n_occ, r0 + per);
+		if (hipMemcpyAsync(bufs[b], d_stream + r0, (size_t)(r1 - r0) * sizeof(Node), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+		    hipEventRecord(h->d2h_ev[b], h->stream) != hipSuccess) {
+			rc = DBGK_ERR_HIP;
+			break;
+		}
+		issued[i].store(1, std::memory_order_release);
+	}
+	if (rc) failed.store(1);
+	for (auto &t : workers) t.join();
+	if (failed.load() && rc == DBGK_OK) rc = DBGK_ERR_HIP;
+	if (rc == DBGK_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = DBGK_ERR_HIP;
+	lap(3);
+	cleanup();
+	lap(4);
+	if (rc) return hip_fail(hipGetLastError(), "d2h_compact", __LINE__);
+	if (lap_wanted)
+		fprintf(stderr, "dbgk export, occupied nodes only (s): buffers %.4f, counts %.4f, stream on the device + bits to the host %.4f, stream to the host and into "
+		        "the slots %.4f (%zu slices of %.1f MB through %zu buffers%s; the %d threads waited %.4f for the link in all, the issuing thread %.4f for a free "
+		        "buffer), release %.4f\n",
+		        laps[0], laps[1], laps[2], laps[3], n_slices, (double)per * 16e-6, n_bufs, bits_pinned ? " of the batch staging" : "", n_threads,
+		        (double)wait_link_us.load() * 1e-6, (double)wait_host_us.load() * 1e-6, laps[4]);
+	return DBGK_OK;
+}
+
 // what the link pass of an export returns (all optional)
 struct LinkOutputs {
 	int32_t cutoff = 0;
@@ -2955,16 +3226,33 @@ static int export_host_table_impl(dbgk_handle *h, uint64_t host_size, dbgk_node 
 		if (hipMemsetAsync(tmp, 0, host_size * sizeof(Node), h->stream) != hipSuccess) { cleanup(); return DBGK_ERR_HIP; }
 		hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, h->size)), dim3(kBlock), 0, h->stream, h->table, h->size, T, h->d_ctr);
 	}
-	if (hipMalloc(&d_flags, host_size / 8 + 1) != hipSuccess) { cleanup(); return DBGK_ERR_NOMEM; }
+	const uint64_t flag_bytes = host_size / 8 + 1, flag_alloc = (flag_bytes + 11) & ~7ull; // whole dwords for k_flag_block_counts
+	if (hipMalloc(&d_flags, flag_alloc) != hipSuccess) { cleanup(); return DBGK_ERR_NOMEM; }
+	if (hipMemsetAsync(d_flags, 0, flag_alloc, h->stream) != hipSuccess) { cleanup(); return DBGK_ERR_HIP; }
 	hipLaunchKernelGGL(k_place_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
 	hipLaunchKernelGGL(k_build_flags_ctr, dim3(grid_for(h, host_size / 8 + 1)), dim3(kBlock), 0, h->stream, T.nodes, T.size,
 	                   h->d_ctr, d_flags);
 	hipError_t e = hipGetLastError();
 	int copy_rc = DBGK_OK;
-	if (e == hipSuccess) copy_rc = d2h_pipelined(h, array, T.nodes, host_size * sizeof(Node));
-	if (e == hipSuccess && copy_rc == DBGK_OK) e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
+	static const bool lap_wanted = getenv("DBGK_TIMINGS") != nullptr;
+	auto clock_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	if (lap_wanted && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	const double t_a = clock_s();
+	// large tables: the occupied nodes only (DBGK_EXPORT_FULL=1: every slot over the link, as before round 4)
+	const bool full_copy = getenv("DBGK_EXPORT_FULL") != nullptr; // (read at every call: the tests compare the two)
+	bool bits_copied = false;
+	if (e == hipSuccess) {
+		copy_rc = DBGK_ERR_STATE;
+		if (!full_copy && host_size * sizeof(Node) >= (getenv("DBGK_EXPORT_COMPACT_MIN") ? strtoull(getenv("DBGK_EXPORT_COMPACT_MIN"), nullptr, 10) : (256ull << 20))) copy_rc = d2h_compact(h, array, nul_flag, T, d_flags, h->h_ctr->n_new + 1);
+		bits_copied = copy_rc == DBGK_OK;
+		if (copy_rc == DBGK_ERR_STATE) copy_rc = d2h_pipelined(h, array, T.nodes, host_size * sizeof(Node));
+	}
+	const double t_b = clock_s();
+	if (e == hipSuccess && copy_rc == DBGK_OK && !bits_copied)
+		e = hipMemcpyAsync(nul_flag, d_flags, host_size / 8 + 1, hipMemcpyDeviceToHost, h->stream);
 	int link_rc = copy_rc;
 	if (e == hipSuccess && LO && copy_rc == DBGK_OK) link_rc = run_link_pass(h, T, *LO); // on the very image that is being copied out
+	if (lap_wanted) fprintf(stderr, "dbgk export (s): node copy %.4f (%.1f GB/s)\n", t_b - t_a, (double)host_size * sizeof(Node) / (t_b - t_a) * 1e-9);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_unplace_polyA, dim3(1), dim3(64), 0, h->stream, T, h->d_ctr);
 		e = hipGetLastError();

@@ -17,6 +17,7 @@
 
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
@@ -148,6 +149,14 @@ struct Session {
 	bool stop_file = false;                // the reference would have left this file's block loop (-e cap)
 	// host wall clock per phase (DBGK_TIMINGS): device calls made while parsing are timed on their own
 	double t_create = 0, t_parse = 0, t_push = 0, t_count = 0, t_finalize = 0, t_export = 0, t_pack = 0;
+	// the host table the consumer gets, allocated at the size -i asks for when the run starts and touched page by page by a few
+	// threads while the reads are parsed (the kernel hands out -- and zeroes -- 16 bytes per slot: 9.6 GB for cfg2; left to the
+	// export, that is most of its time).  Used if the reference's schedule ends at that size, dropped otherwise.
+	KmerNode *early_array = nullptr;
+	uint64_t early_size = 0;
+	std::vector<std::thread> early_threads;
+	std::atomic<bool> early_stop{false};
+	double t_early = 0;
 	// DBGK_LAYOUT=ref: reproduce the reference's -t 1 slot layout (first-seen order replay)
 	bool ref_layout = false;
 	uint64_t pos = 0;                      // bases handed to the device so far (+ pending batch)
@@ -177,6 +186,41 @@ void ensure_created(Session &S)
 		}
 		S.zero_copy = false;
 	}
+}
+
+void start_early_table(Session &S, uint64_t size)
+{
+	static const bool off = getenv("DBGK_NO_EARLY_TABLE") != nullptr;
+	if (off || size * sizeof(KmerNode) < ((size_t)64 << 20)) return;
+	S.early_array = static_cast<KmerNode *>(kmerset_alloc(size * sizeof(KmerNode), false));
+	if (!S.early_array) return;
+	S.early_size = size;
+	const int T = getenv("DBGK_EARLY_THREADS") ? std::max(1, atoi(getenv("DBGK_EARLY_THREADS"))) : 4;
+	const size_t bytes = size * sizeof(KmerNode), per = ((bytes / (size_t)T) + 4095) & ~(size_t)4095;
+	const double t0 = now_s();
+	for (int t = 0; t < T; t++)
+		S.early_threads.emplace_back([&S, t, per, bytes, t0, T]() {
+			volatile char *p = reinterpret_cast<volatile char *>(S.early_array);
+			const size_t a = std::min(bytes, per * (size_t)t), b = std::min(bytes, a + per);
+			for (size_t i = a; i < b && !S.early_stop.load(std::memory_order_relaxed); i += 4096) p[i] = 0; // (fresh pages: zero anyway)
+			if (t == T - 1) S.t_early = now_s() - t0;
+		});
+}
+
+// -> the array if it has `size` slots (all pages present), else NULL (released)
+KmerNode *take_early_table(Session &S, uint64_t size)
+{
+	if (S.early_size != size) S.early_stop.store(true);
+	for (auto &t : S.early_threads) t.join();
+	S.early_threads.clear();
+	KmerNode *a = S.early_array;
+	S.early_array = nullptr;
+	if (a && S.early_size != size) {
+		free(a);
+		a = nullptr;
+	}
+	S.early_size = 0;
+	return a;
 }
 
 void fail(Session &S, int rc, const char *what)
@@ -532,6 +576,7 @@ static void release_session()
 {
 	if (!g_session) return;
 	if (g_session->creator.joinable()) g_session->creator.join();
+	(void)take_early_table(*g_session, 0); // (an early host table nobody took)
 	if (g_session->h) dbgk_destroy(g_session->h);
 	if (g_session->comm) dbgk_comm_destroy(g_session->comm);
 	delete g_session;
@@ -781,6 +826,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 		if (getenv("DBGK_CREATE_SYNC")) ensure_created(*S);
 	}
 
+	if (!S->ref_layout) start_early_table(*S, initial_size);
 	if (S->comm) S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
 	cerr << "The initialization memory used:  " << initHashSize * 16 << " G" << endl;
@@ -844,7 +890,8 @@ void build_debruijn_graph(vector<string> &reads_files)
 			     << " entries the -i/-e settings allow" << endl;
 			fail(*S, DBGK_ERR_TABLE_FULL, "host table");
 		} else {
-			array = static_cast<KmerNode *>(kmerset_alloc(use_size * sizeof(KmerNode), false));
+			array = take_early_table(*S, use_size);
+			if (!array) array = static_cast<KmerNode *>(kmerset_alloc(use_size * sizeof(KmerNode), false));
 			nul = static_cast<uint8_t *>(kmerset_alloc(use_size / 8 + 1, false));
 			del = static_cast<uint8_t *>(kmerset_alloc(use_size / 8 + 1, true));
 			if (!array || !nul || !del) {
@@ -893,7 +940,7 @@ void build_debruijn_graph(vector<string> &reads_files)
 	S->t_export = now_s() - t_export0;
 	if (getenv("DBGK_TIMINGS"))
 		cerr << "Host phases (s): create " << S->t_create << " read+parse " << S->t_parse << " push " << S->t_push << " count/flush " << S->t_count
-		     << " finalize " << S->t_finalize << " host table " << S->t_export << endl;
+		     << " finalize " << S->t_finalize << " host table " << S->t_export << " (its pages touched beside the parse in " << S->t_early << ")" << endl;
 	if (getenv("DBGK_TIMINGS") && S->h) { // device time per phase, summed over the run (HIP events on the library's streams)
 		dbgk_timings tm;
 		if (dbgk_get_timings(S->h, &tm) == DBGK_OK)

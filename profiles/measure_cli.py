@@ -26,9 +26,10 @@ cli = os.path.join(ROOT, "dbg_assembly_amd", "bin", "debruijn_contig")
 env = dict(os.environ, DBGK_TIMINGS="1")
 env.update(extra)
 for rep in range(3):
+    time.sleep(2.0)   # (the driver wipes the ~25 GB of device memory of the run before; a process started at once can wait > 1 s in its first hipMalloc)
     t0 = time.time()
     r = subprocess.run([cli, "-k", "31", "-f", "2", "-t", "16", "-i", "0.6", "-o", os.path.join(tmp, "cfg2_cli_out"), libf], env=env,
                        capture_output=True, text=True)
     wall = time.time() - t0
-    lines = [l for l in r.stderr.splitlines() if l.startswith(("Host phases", "GPU phases", "count:", "Wall phases", "Reader"))]
+    lines = [l for l in r.stderr.splitlines() if l.startswith(("Host phases", "GPU phases", "count:", "Wall phases", "Reader", "dbgk_create", "dbgk export"))]
     print("run %d: rc %d wall %.3f s %s" % (rep, r.returncode, wall, " | ".join(lines)), flush=True)

@@ -787,6 +787,43 @@ def test_export_with_the_consumers_first_pass_on_the_device_PARITY_UNPINNED(capi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_reads,size_hint", [(40_000, 17_000_000), (3, 17_000_000), (400_000, 60_000_000), (200_000, 25_165_857), (60_000, 7_000_000)])
+def test_host_table_through_the_occupied_nodes_only_equals_the_plain_copy(capi, oracle, monkeypatch, n_reads, size_hint):
+    """Large host tables leave the device as the stream of their occupied nodes + the occupancy bits and are laid out at their slots
+    by host threads (d2h_compact, dbgk.hip); DBGK_EXPORT_FULL=1 copies every slot as before.  Same image on the device -> the two
+    must agree byte for byte, in buffers that held garbage before (every slot and every flag byte is written).  Sizes that are no
+    multiple of 64 or 4096, a nearly empty and a well filled table, with and without the link pass."""
+    monkeypatch.setenv("DBGK_EXPORT_COMPACT_MIN", "0")
+    monkeypatch.setenv("DBGK_EXPORT_THREADS", "5")
+    P = oracle.synth_params(300_000, 150, cfg=1)
+    bases, offsets = oracle.synth_reads(P, 0, n_reads)
+    size = capi.find_next_prime_ref(size_hint) if size_hint != 25_165_857 else size_hint   # (an odd non-prime works as well)
+    lib = capi.lib()
+
+    def export(g, links):
+        array = np.full(size * 16, 0xAB, dtype=np.uint8).view(capi.NODE_DTYPE)
+        flags = np.full(size // 8 + 1, 0xCD, dtype=np.uint8)
+        assert len(array) == size
+        if not links:
+            assert lib.dbgk_export_host_table(g._h, size, array.ctypes.data, flags.ctypes.data) == 0
+            return array, flags
+        return g.export_host_table_links(2)[:4]
+
+    with capi.Graph(k=31, table_slots=size, max_read_len=150, engine=1) as g:
+        g.push_reads(bases, offsets)
+        st = g.finalize()
+        for links in (False, True):
+            monkeypatch.delenv("DBGK_EXPORT_FULL", raising=False)
+            got = export(g, links)
+            monkeypatch.setenv("DBGK_EXPORT_FULL", "1")
+            want = export(g, links)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+        assert oracle.check_host_table(got[0], got[1], size, st.count) == 0
+        assert int(np.unpackbits(got[1])[:size].sum()) == st.count
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_shards,staging", [(2, False), (3, True)])
 def test_comm_export_with_the_consumers_first_pass_PARITY_UNPINNED(capi, oracle, n_shards, staging, monkeypatch):
     """dbgk_comm_export_host_table_links: the table of a communicator AND calculate_kmer_links' first pass for it (contig.cpp:107-181),
