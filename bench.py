@@ -537,8 +537,8 @@ def run_kfreq(args, ctx, brief=False):
         # whole table once, nothing zeroes or summarises the table separately
         blocks = k >= 13 and not os.environ.get("DBGK_KFREQ_HASHED")
         bname = "k_kf_build_blocks" if blocks else "k_build_regions(KF)"
-        own = {"k_extract_scatter_uniform": kmers_step * (base_bytes + 8.0), "k_scatter_l2": kmers_step * (10.0 if blocks else 16.0),
-               bname: kmers_step * (2.0 if blocks else 8.0) + (4.0 ** k if blocks else distinct * 1.0)}   # (blocks: level 2 leaves 16-bit records)
+        own = {"k_extract_scatter_uniform": kmers_step * (base_bytes + (4.0 if blocks else 8.0)), "k_scatter_l2": kmers_step * (6.0 if blocks else 16.0),
+               bname: kmers_step * (2.0 if blocks else 8.0) + (4.0 ** k if blocks else distinct * 1.0)}   # (blocks: 32-bit level-1 records, level 2 leaves 16-bit ones)
         ms = {"k_extract_scatter_uniform": l1_ms, "k_scatter_l2": l2_ms, bname: build_ms}
         copy_bw = copy_bandwidth(ctx, g)
         own_total = sum(own.values()) + (0.0 if blocks else 2.0 * 4 ** k)   # hashed form: + zeroing the table at reset and the summary pass over it
@@ -663,7 +663,7 @@ def run_graph(args, ctx, brief=False):
                    expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not os.environ.get("DBGK_WIDE_DIRECT")
                    else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0,
-                   n_passes=args.passes if wide_sharded else 0)
+                   n_passes=args.passes if wide_sharded else 0, max_batch_bases=int(os.environ.get("DBGK_BENCH_BATCH_BASES", "0")))
     d_bases, d_off, nb = g.synth_reads_device(P, rank * n_reads, n_reads)  # inputs resident in HBM before timing
     if CONFIGS[args.config].get("trimmed"):   # mixed lengths: the reads are trimmed on the host once (setup, untimed) and go back to the device
         import numpy as np

@@ -1707,6 +1707,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8, true); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8, true); else DBGK_LAUNCH_UNIFORM8(0, 8, true);
 		} else if (lin8) {
 			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 8, false); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 8, false); else DBGK_LAUNCH_UNIFORM8(0, 8, false);
+		} else if (wide == 2 && h->geom.kf == 2u && !ragged) { // KFREQ, direct blocks: the instantiation without hash, division and neighbour codes
+			if (c15) DBGK_LAUNCH_UNIFORM(3, 15, false); else DBGK_LAUNCH_UNIFORM(3, 16, false);
 		} else if (wide == 2) DBGK_LAUNCH_UNIFORM_W(2);
 		else if (wide == 1) DBGK_LAUNCH_UNIFORM_W(1);
 		else DBGK_LAUNCH_UNIFORM_W(0);

@@ -346,6 +346,33 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
 		if (n == 0) continue;
 		const uint32_t b = wave + kWaves * k;
+		if (G.kf == 2u) {
+			// KFREQ, direct blocks: a level-1 record is (place in the bucket) << 6 | 4 -- 32 bits, its high word zero -- and travels
+			// as 32 bits: half the level-1 store written here and read by level 2 (kSubStores == 1: `out` is the store itself)
+			static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
+			uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * cap + dst;
+			if ((uint64_t)dst + n <= cap) {
+				typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+				for (uint32_t i = 4u * lane; i < n; i += 256u) { // four records per lane and store instruction
+					const uint32_t v0 = (uint32_t)L.stage[src + i];
+					if (i + 3u < n) {
+						const u32x4_a4 v = {v0, (uint32_t)L.stage[src + i + 1u], (uint32_t)L.stage[src + i + 2u], (uint32_t)L.stage[src + i + 3u]};
+						*reinterpret_cast<u32x4_a4 *>(o32 + i) = v;
+					} else {
+						o32[i] = v0;
+						if (i + 1u < n) o32[i + 1u] = (uint32_t)L.stage[src + i + 1u];
+						if (i + 2u < n) o32[i + 2u] = (uint32_t)L.stage[src + i + 2u];
+					}
+				}
+			} else {
+				for (uint32_t i = lane; i < n; i += 64) {
+					const uint64_t rcd = L.stage[src + i];
+					if ((uint64_t)dst + i < cap) o32[i] = (uint32_t)rcd;
+					else push_overflow(P, record_key(rcd, bucket_is_b1 ? b : b1_of_bucket0, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+				}
+			}
+			continue;
+		}
 		uint64_t *o = out + (uint64_t)b * stride * cap + dst;
 		if (DBG == 3) { // timing experiment: same instruction stream, stores land in a 32 KiB window per workgroup (no HBM write traffic)
 			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * stride * cap + dst + i) & 4095ull)] = L.stage[src + i];
@@ -600,8 +627,9 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
 		const uint64_t key = rev ? c.rc : c.kbit;
 		// forward: (left, right); reverse strand: (comp(right), comp(left))  (DBGgraph.cpp:82-97)
-		uint32_t links;
-		if constexpr (ROLL32) { // the packed words are selected, the two codes extracted once
+		uint32_t links = 4u; // (WIDE_D == 3, KFREQ: (lb, rb) = (0, none) and nothing below is needed)
+		if constexpr (WIDE_D == 3) {
+		} else if constexpr (ROLL32) { // the packed words are selected, the two codes extracted once
 			uint32_t wa = rev ? nbc : c.lw, wb = rev ? lwc : c.nb;
 			asm volatile("" : "+v"(wa), "+v"(wb)); // two selects, not a branch
 			links = (((wa >> sh) & 3u) << 3) | ((wb >> sh) & 3u);
@@ -611,7 +639,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 			asm volatile("" : "+v"(lf), "+v"(lr)); // both sides are cheap: a select, not a branch
 			links = G.kf ? 4u : (rev ? lr : lf); // KFREQ: (lb, rb) = (0, none)
 		}
-		if (!SPECIAL || i == 0u || i == (uint32_t)NPOS - 1u) { // (SPECIAL: only a read's first and last window are ever patched below)
+		if (WIDE_D != 3 && (!SPECIAL || i == 0u || i == (uint32_t)NPOS - 1u)) { // (SPECIAL: only a read's first and last window are ever patched below)
 			uint32_t rev_bit = rev ? 1u : 0u;
 			asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
 			rev_mask = SPECIAL ? (rev_mask | (rev_bit << ((uint32_t)NPOS - 1u - i))) : ((rev_mask << 1) | rev_bit);  // position i ends up at bit NPOS - 1 - i
@@ -619,7 +647,12 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 		uint64_t q;
 		uint32_t slot, bucket; // slot: its low 32 bits (r <= 24 of them are recorded); bucket = slot >> r
-		if (WIDE_D == 2) {
+		if constexpr (WIDE_D == 3) { // compiled for KFREQ with direct blocks only: no hash, no division, no neighbour codes
+			const uint64_t s64 = kf_slot_of_key(key, G.kf_mask);
+			q = 0ull;
+			slot = (uint32_t)s64;
+			bucket = (uint32_t)(s64 >> G.r);
+		} else if (WIDE_D == 2) {
 			uint64_t s64;
 			if (G.kf == 2u) { // KFREQ, direct blocks: the slot IS the key, its block index permuted (wave-uniform branch)
 				s64 = kf_slot_of_key(key, G.kf_mask);
@@ -657,7 +690,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	}
 	// windows without a left / right neighbour: that side's code becomes 4 = none
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
-	for (uint32_t fix = (!SPECIAL && G.kf) ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
+	for (uint32_t fix = (WIDE_D == 3 || (!SPECIAL && G.kf)) ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
 		const uint32_t i = (uint32_t)__builtin_ctz(fix);
 		const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
 		uint64_t rec = L.stage[i * kL1Threads + tid];
@@ -744,7 +777,8 @@ __device__ __forceinline__ void l1_scatter_tail_linear(ScatterLdsLin<C> &L, cons
 			const uint32_t b = L.bucket_of[p];
 			const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
 			if (off < G.cap1) {
-				out[(uint64_t)b * G.n_sub * G.cap1 + off] = rcd;
+				if (G.kf == 2u) reinterpret_cast<uint32_t *>(out)[(uint64_t)b * G.cap1 + off] = (uint32_t)rcd; // (32-bit level-1 records, scatter_stage_copy)
+				else out[(uint64_t)b * G.n_sub * G.cap1 + off] = rcd;
 			} else { // the bucket is full: records beyond its capacity go to the overflow list
 				push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
 			}
@@ -1490,6 +1524,15 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records;
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
+	if (G.kf == 2u) { // KFREQ, direct blocks: 32-bit level-1 records (scatter_stage_copy); never all ones -- the low six bits are 4
+		const uint32_t *in32 = reinterpret_cast<const uint32_t *>(P.inbox) + (uint64_t)e * G.cap1;
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const uint64_t i = first + (uint64_t)u * kL2Threads + tid;
+			if (i < filled) rec[u] = (uint64_t)__builtin_nontemporal_load(in32 + i);
+		}
+		return;
+	}
 #pragma unroll
 	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
 		const uint64_t i = first + (uint64_t)u * kL2Threads + tid;

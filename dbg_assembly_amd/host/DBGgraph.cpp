@@ -191,7 +191,8 @@ void ensure_created(Session &S)
 void start_early_table(Session &S, uint64_t size)
 {
 	static const bool off = getenv("DBGK_NO_EARLY_TABLE") != nullptr;
-	if (off || size * sizeof(KmerNode) < ((size_t)64 << 20)) return;
+	const size_t min_bytes = getenv("DBGK_EARLY_TABLE_MIN") ? (size_t)strtoull(getenv("DBGK_EARLY_TABLE_MIN"), NULL, 10) : ((size_t)64 << 20); // (tests: 0)
+	if (off || size * sizeof(KmerNode) < min_bytes) return;
 	S.early_array = static_cast<KmerNode *>(kmerset_alloc(size * sizeof(KmerNode), false));
 	if (!S.early_array) return;
 	S.early_size = size;

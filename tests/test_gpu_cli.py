@@ -65,6 +65,21 @@ def test_cli_matches_reference(tmp_path, oracle, case, engine):
     assert re.search(r"Used tip kmer nodes:\s+%d\t" % st.tip_nodes, log)
 
 
+EARLY_CASES = [c for c in FILE_CASES if "enlarge" in c["name"] or c["name"] in ("mixed150_k31", "polyA_k31", "even_k16", "lengths_k31_r100")]
+
+
+@pytest.mark.parametrize("case", EARLY_CASES, ids=[c["name"] for c in EARLY_CASES])
+def test_cli_early_host_table_and_export_through_occupied_nodes(tmp_path, case):
+    """The two host-table shortcuts of round 4 at sizes the goldens have: the array allocated (and touched) at the size -i asks for
+    when the run starts -- kept when the reference's doubling schedule ends there, dropped when it enlarges (enlarge_* cases) -- and
+    the table leaving the device as occupied nodes + occupancy bits.  Same dump, same final array size as the reference."""
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_EARLY_TABLE_MIN": "0", "DBGK_EXPORT_COMPACT_MIN": "0", "DBGK_EARLY_THREADS": "3"})
+    ref = case["ref"]
+    assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
+    assert re.search(r"^count:\t%d$" % ref["count"], r.stderr, re.M)
+    assert re.search(r"^array_size:\t%d$" % ref["size"], r.stderr, re.M)
+
+
 def test_cli_small_batches_and_device_resize(tmp_path):
     """DIRECT engine: 1 MiB host batches + a tiny initial table force several device-side enlarges"""
     case = [c for c in golden_cases() if c["name"] == "enlarge_b50"][0]

@@ -831,6 +831,7 @@ def test_comm_export_with_the_consumers_first_pass_PARITY_UNPINNED(capi, oracle,
     node multiset against the oracle (parity of the link records unpinned: contig.cpp needs Boost)"""
     if staging:
         monkeypatch.setenv("DBGK_COMM_HOST_STAGING", "1")
+        monkeypatch.setenv("DBGK_EXPORT_COMPACT_MIN", "0")   # the small host table too leaves as occupied nodes + bits (d2h_compact)
     rng = random.Random(40 + n_shards)
     reads = rand_reads(rng, 3000, G=20000) + [b"A" * 150] * 300 + [b"T" * 90] * 40
     rng.shuffle(reads)
