@@ -52,12 +52,16 @@ def pack(reads):
     return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), offsets
 
 
-def table_of(k, expected, bases, offsets, pieces, max_batch):
+def table_of(k, expected, bases, offsets, pieces, max_batch, packed=False):
+    if packed:   # the same reads through the 2-bit entry (dbgk_push_reads_packed)
+        words, _ = capi.pack_bases(bases)
     with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=expected, max_batch_bases=max_batch) as g:
         n = len(offsets) - 1
         cuts = [n * i // pieces for i in range(pieces + 1)]
         for a, b in zip(cuts[:-1], cuts[1:]):
-            if b > a:
+            if b > a and packed and pieces == 1:
+                g.push_reads_packed(words, offsets)
+            elif b > a:
                 g.push_reads(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a])
         st = g.finalize()
         return g.kfreq_counts(), int(st.count), int(st.stored_kmers)
@@ -79,11 +83,21 @@ def main():
         expected = max(1, int(total * rng.choice([4.0, 1.0, 0.4, 0.15, 0.01])))
         pieces = rng.randint(1, 4)
         max_batch = rng.choice([1 << 16, 1 << 20, 1 << 26])
+        # a third of the configurations through the LINEAR level-1 forms (what tables of 4^18 bytes take: 1024 level-1 buckets), a
+        # third through the wave-per-bucket forms whatever the geometry, the rest as the library decides; half of the one-piece
+        # configurations as 2-bit words
+        lin = rng.choice(["1", "0", None])
+        packed = pieces == 1 and rng.random() < 0.5
+        os.environ.pop("DBGK_L1_LINEAR", None)
         want = table_of(k, 0, bases, offsets, 1, 1 << 26)
-        got = table_of(k, expected, bases, offsets, pieces, max_batch)
+        if lin is not None:
+            os.environ["DBGK_L1_LINEAR"] = lin
+        got = table_of(k, expected, bases, offsets, pieces, max_batch, packed)
+        os.environ.pop("DBGK_L1_LINEAR", None)
         ok = got[1:] == want[1:] and np.array_equal(got[0], want[0])
-        print("cfg %3d k=%2d L=%3d %s reads=%5d kmers=%8d expected=%9d pieces=%d batch=2^%d distinct=%8d max=%3d  %s"
-              % (c, k, L, "uniform" if uniform else "ragged ", len(reads), total, expected, pieces, max_batch.bit_length() - 1, want[1], int(want[0].max()),
+        print("cfg %3d k=%2d L=%3d %s reads=%5d kmers=%8d expected=%9d pieces=%d batch=2^%d linear=%s %s distinct=%8d max=%3d  %s"
+              % (c, k, L, "uniform" if uniform else "ragged ", len(reads), total, expected, pieces, max_batch.bit_length() - 1, lin, "packed" if packed else "ascii ",
+                 want[1], int(want[0].max()),
                  "ok" if ok else "MISMATCH"), flush=True)
         bad += 0 if ok else 1
     print("%d configurations, %d mismatches" % (n_cfg, bad))

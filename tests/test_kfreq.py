@@ -95,6 +95,49 @@ def test_kfreq_engine_counts_equal_oracle(oracle, k, expected):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["equal", "ragged", "mixed"])
+@pytest.mark.parametrize("k", [13, 15])
+def test_kfreq_direct_blocks_through_every_level1_form(oracle, monkeypatch, shape, k):
+    """Direct blocks move 32-bit level-1 records (round 4): written by the wave-per-bucket copy-out, by the linear copy-out
+    (DBGK_L1_LINEAR=1: what a table of 4^18 bytes with its 1024 level-1 buckets takes) and read back by level 2.  Reads of one
+    length (the level-1 instantiation compiled for this case), mostly full length (ragged tiles), any length (lane prefix / flat
+    kernel), as ASCII and as 2-bit words: the same 4^k-byte table as the oracle's."""
+    from dbg_assembly_amd import capi
+    rng = random.Random(100 * k + len(shape))
+    genome = "".join(rng.choice("ACGT") for _ in range(30000))
+
+    def read(ln):
+        a = rng.randint(0, len(genome) - ln)
+        r = genome[a:a + ln]
+        return "".join(rng.choice("acgtN") if rng.random() < 0.01 else ch for ch in r).encode()
+
+    if shape == "equal":
+        reads = [read(150) for _ in range(4000)]
+    elif shape == "ragged":
+        reads = [read(150 if rng.random() < 0.9 else rng.randint(100, 150)) for _ in range(4000)]
+    else:
+        reads = [read(rng.choice([0, 5, k - 1, k, 40, 90, 150, 151, 400])) for _ in range(5000)]
+    reads += [b"A" * 150] * 200 + [b"T" * 150] * 30 if shape == "equal" else [b"A" * 90] * 200
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    want = oracle.kfreq_expected_counts([(bases, offsets)], k)
+    words, other = capi.pack_bases(bases)
+    assert other == 0
+    expected = sum(max(0, len(r) - k + 1) for r in reads)
+    for lin in ("0", "1"):
+        monkeypatch.setenv("DBGK_L1_LINEAR", lin)
+        for packed in (False, True):
+            with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=expected) as g:
+                if packed:
+                    g.push_reads_packed(words, offsets)
+                else:
+                    g.push_reads(bases, offsets)
+                st = g.finalize()
+                assert np.array_equal(g.kfreq_counts(), want), (lin, packed)
+                assert st.stored_kmers == expected
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,fmt", [(12, 2), (13, 1)])
 def test_kmerfreq_tool_files_load_like_the_reference(oracle, tmp_path, k, fmt):
     assert os.path.exists(TOOL), "kmerfreq not built"
