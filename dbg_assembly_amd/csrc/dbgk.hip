@@ -991,6 +991,7 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_scatter_l2<1>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<2>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<0, kMaxBuckets, true>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 2048>), sizeof(ScatterLdsL2T<2048>));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 4096>), sizeof(ScatterLdsL2T<4096>));
 #define DBGK_BUILD_ATTR(...) DBGK_LDS_ATTR((k_build_regions<__VA_ARGS__>), sizeof(BuildLds))
@@ -2430,6 +2431,8 @@ static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 		hipLaunchKernelGGL((k_scatter_l2<0, 4096>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<4096>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else if (h->geom.n2 > (uint32_t)kMaxBuckets) // 2^32 .. 2^33 slots
 		hipLaunchKernelGGL((k_scatter_l2<0, 2048>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<2048>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+	else if (h->geom.kf == 2u) // KFREQ, direct blocks: 32-bit level-1 records (n2 <= 1024 always)
+		hipLaunchKernelGGL((k_scatter_l2<0, kMaxBuckets, true>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else
 		hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 }

@@ -283,7 +283,9 @@ __device__ __forceinline__ void scatter_reserve_scan(LDS &L, uint32_t n_buckets,
 // bucket and wave.  The vector-memory pipe costs ~27 clocks per store instruction per CU whatever
 // the number of active lanes (profiles/dbg_modes_l2.sh), which makes the instruction count the cost:
 // level 2 went from 6.3 to 5.3 ms.
-template <int PER_THREAD, int DBG = 0, bool FLAT = false, class LDS>
+// KF32_POSSIBLE: the caller may run for a KFREQ handle with direct blocks (level 1 with the 64-bit slot path, WIDE_D >= 2): only
+// those instantiations carry the 32-bit copy-out
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, class LDS>
 __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
@@ -346,7 +348,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
 		if (n == 0) continue;
 		const uint32_t b = wave + kWaves * k;
-		if (G.kf == 2u) {
+		if (KF32_POSSIBLE && G.kf == 2u) {
 			// KFREQ, direct blocks: a level-1 record is (place in the bucket) << 6 | 4 -- 32 bits, its high word zero -- and travels
 			// as 32 bits: half the level-1 store written here and read by level 2 (kSubStores == 1: `out` is the store itself)
 			static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
@@ -434,7 +436,7 @@ __device__ __forceinline__ void scatter_tile(LDS &L, const uint64_t (&rec)[PER_T
 	}
 	uint32_t my_gbase[LDS::kBpt];
 	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
-	scatter_stage_copy<PER_THREAD, DBG, FLAT>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr);
+	scatter_stage_copy<PER_THREAD, DBG, FLAT, false>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr); // (level 2: FLAT)
 }
 
 // ---- lean extraction for the partition path -----------------------------------------------------
@@ -703,7 +705,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 }
 
 // after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
-template <int DBG>
+template <int DBG, bool KF32_POSSIBLE = true>
 __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
                                                 const uint32_t (&bkt)[16])
 {
@@ -717,7 +719,7 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	uint32_t my_gbase[ScatterLds::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
 	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-	scatter_stage_copy<16, DBG>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 }
 
 // LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
@@ -740,7 +742,7 @@ struct ScatterLdsLin {
 	uint16_t bucket_of[kRecords];
 };
 
-template <int DBG, int C>
+template <int DBG, int C, bool KF32_POSSIBLE = true>
 __device__ __forceinline__ void l1_scatter_tail_linear(ScatterLdsLin<C> &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
                                                        const uint32_t (&bkt)[16])
 {
@@ -777,7 +779,7 @@ __device__ __forceinline__ void l1_scatter_tail_linear(ScatterLdsLin<C> &L, cons
 			const uint32_t b = L.bucket_of[p];
 			const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
 			if (off < G.cap1) {
-				if (G.kf == 2u) reinterpret_cast<uint32_t *>(out)[(uint64_t)b * G.cap1 + off] = (uint32_t)rcd; // (32-bit level-1 records, scatter_stage_copy)
+				if (KF32_POSSIBLE && G.kf == 2u) reinterpret_cast<uint32_t *>(out)[(uint64_t)b * G.cap1 + off] = (uint32_t)rcd; // (32-bit level-1 records, scatter_stage_copy)
 				else out[(uint64_t)b * G.n_sub * G.cap1 + off] = rcd;
 			} else { // the bucket is full: records beyond its capacity go to the overflow list
 				push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter(ReadBatch rb, Pa
 			continue;
 		}
 		const RawChunk nxt = fetch(tile + gridDim.x);
-		l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
+		l1_scatter_tail<DBG, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
 		raw = nxt;
 	}
 }
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_lin(ReadBatch rb
 			c.valid >>= 8;
 			c.has_l >>= 8;
 			c.has_r >>= 8;
-			l1_scatter_tail_linear<0, 8>(L, G, P, ctr, tid, bkt);
+			l1_scatter_tail_linear<0, 8, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
 		}
 		if (zero_any && chunk < n_chunks) { // key-0 side node (DBGgraph.cpp:153-164): rare; redo the chunk on the plain path, rolled
 			LaneWindow w = load_lane_window<HAS_DEAD>(rb, chunk);
@@ -1135,8 +1137,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			continue;
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
-		if constexpr (LIN) l1_scatter_tail_linear<DBG, C>(L, G, P, ctr, tid, bkt);
-		else l1_scatter_tail<DBG>(L, G, P, ctr, tid, bkt);
+		if constexpr (LIN) l1_scatter_tail_linear<DBG, C, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
+		else l1_scatter_tail<DBG, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
 		raw = nxt;
 	}
 }
@@ -1444,7 +1446,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 			uint32_t my_gbase[ScatterLds::kBpt];
 			const uint32_t sub = blockIdx.x % G.n_sub;
 			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-			scatter_stage_copy<16, 0>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+			scatter_stage_copy<16, 0, false, (WIDE_D >= 2)>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 		}
 		raw = nxt;
 		M = M_next;
@@ -1505,12 +1507,19 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 // Persistent workgroups (one per CU) walk the flattened tile list; the records of tile i+1 are
 // loaded into registers before tile i is scattered, so HBM reads, the LDS work and the (undrained)
 // stores of consecutive tiles overlap.
+// KF32: KFREQ with direct blocks, 32-bit level-1 records (an instantiation of its own: the graph kernel keeps its registers).  The
+// records stay 32 bits wide in the registers they are prefetched into -- widened right behind the load, every load waited for its
+// predecessor (one s_waitcnt vmcnt(0) per record: level 2 of cfg4 9.0 instead of 5.0 ms)
+template <bool KF32>
+using L2RecIn = typename std::conditional<KF32, uint32_t, uint64_t>::type;
+
+template <bool KF32 = false>
 __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore &P, const uint32_t *__restrict__ tile_prefix,
-                                             uint32_t g, uint32_t n_tiles, uint64_t (&rec)[16], uint32_t &b1_out)
+                                             uint32_t g, uint32_t n_tiles, L2RecIn<KF32> (&rec)[16], uint32_t &b1_out)
 {
 	b1_out = 0;
 #pragma unroll
-	for (int u = 0; u < 16; u++) rec[u] = ~0ull;
+	for (int u = 0; u < 16; u++) rec[u] = ~(L2RecIn<KF32>)0;
 	if (g >= n_tiles) return;
 	uint32_t lo = 0, hi = G.n_ranks * G.B * G.n_sub; // last flat entry with tile_prefix[f] <= g (empty entries repeat the prefix: take the last)
 	while (hi - lo > 1) {
@@ -1524,12 +1533,12 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records;
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
-	if (G.kf == 2u) { // KFREQ, direct blocks: 32-bit level-1 records (scatter_stage_copy); never all ones -- the low six bits are 4
+	if constexpr (KF32) { // KFREQ, direct blocks: 32-bit level-1 records (scatter_stage_copy); never all ones -- the low six bits are 4
 		const uint32_t *in32 = reinterpret_cast<const uint32_t *>(P.inbox) + (uint64_t)e * G.cap1;
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
 			const uint64_t i = first + (uint64_t)u * kL2Threads + tid;
-			if (i < filled) rec[u] = (uint64_t)__builtin_nontemporal_load(in32 + i);
+			if (i < filled) rec[u] = __builtin_nontemporal_load(in32 + i);
 		}
 		return;
 	}
@@ -1540,8 +1549,11 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	}
 }
 
-template <int DBG = 0, int MAXB = kMaxBuckets>
-__global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
+// (two workgroups of eight waves per CU = four waves per SIMD: at most 128 VGPRs, said to the compiler for the 1024-bucket form -- at
+// 130 it silently halved the occupancy and the pair of level 2 and build went from 9.2 to 12.8 ms; the forms for more buckets have
+// always run one workgroup per CU)
+template <int DBG = 0, int MAXB = kMaxBuckets, bool KF32 = false>
+__global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 256 : 1) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
                                                              Counters *__restrict__ ctr, uint32_t j0, uint32_t j1)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1554,20 +1566,21 @@ __global__ __launch_bounds__(kL2Threads) void k_scatter_l2(PartGeom G, PartStore
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, n_local = gridDim.x >> 3; // gridDim.x is a multiple of 8
 	const uint32_t span = n_tiles - first_tile;
 	const uint32_t lo_tile = first_tile + (uint32_t)(((uint64_t)span * xcd) >> 3), hi_tile = first_tile + (uint32_t)(((uint64_t)span * (xcd + 1u)) >> 3);
-	uint64_t nxt[16];
+	L2RecIn<KF32> nxt[16];
 	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
-	l2_load_tile(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1);
+	l2_load_tile<KF32>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1);
 	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
 		uint64_t rec[16];
 		uint32_t bkt[16];
 		const uint32_t j = nxt_b1;
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
-			rec[u] = nxt[u];
+			if constexpr (KF32) rec[u] = nxt[u] == ~0u ? ~0ull : (uint64_t)nxt[u];
+			else rec[u] = nxt[u];
 			// an all-ones word is never a record: the neighbour fields only take the values 0..4
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits + G.l2_shift)) & (G.n2 - 1u));
 		}
-		l2_load_tile(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
+		l2_load_tile<KF32>(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
 		// (KFREQ, direct blocks: the final buckets hold 16-bit records -- the same index arithmetic on a quarter of the bytes)
 		uint64_t *out = G.kf == 2u ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint16_t *>(P.l2) + (uint64_t)j * G.n2 * G.cap2)
 		                           : P.l2 + (uint64_t)j * G.n2 * G.cap2;
