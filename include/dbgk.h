@@ -264,7 +264,11 @@ int dbgk_store_room(dbgk_handle *h, uint64_t *pending_kmers, uint64_t *capacity_
  * from hash_code(key) % host_size without crossing a clear flag (exist_kmerset kmerSet.cpp:280-302),
  * unused slots are all-zero, and the key-0 node sits on key 0's probe chain.  host_size may differ
  * from table_slots (the table is then re-seated on the device first: the GPU counterpart of
- * enlarge_kmerset_parallel, kmerSet.cpp:132-189).                                                */
+ * enlarge_kmerset_parallel, kmerSet.cpp:132-189).  Every slot of `array` and every byte of `nul_flag`
+ * is written (the buffers need not be zeroed; ordinary pageable memory).  Tables of 256 MiB and more
+ * cross the link as their occupied nodes + the occupancy bits and are laid out at their slots by host
+ * threads (DBGK_EXPORT_THREADS, default 12), through the handle's idle page-locked batch buffers
+ * where it has them: same bytes, a third of the traffic at the reference's load factors.           */
 int dbgk_export_host_table(dbgk_handle *h, uint64_t host_size, dbgk_node *array, uint8_t *nul_flag);
 
 /* dbgk_export_host_table + the WHOLE first pass of the consumer, calculate_kmer_links (DBG_contig/contig.cpp:107-181), computed
