@@ -232,8 +232,9 @@ using ScatterLdsL2 = ScatterLdsL2T<kMaxBuckets>;
 constexpr int kMaxBucketsL2 = 4096;             // largest level-2 fan-out (tables below 2^34 slots)
 
 // exclusive prefix sum of hist[0..kMaxBuckets) into lbase; thread t owns entries LDS::kBpt*t .. LDS::kBpt*t+LDS::kBpt-1
+// returns the number of records ranked in the tile (the sum of the whole histogram)
 template <class LDS>
-__device__ __forceinline__ void scan_hist(LDS &L)
+__device__ __forceinline__ uint32_t scan_hist(LDS &L)
 {
 	const int t = (int)fresh_tid(), lane = t & 63, wave = t >> 6;
 	constexpr int kBpt = LDS::kBpt;
@@ -248,11 +249,16 @@ __device__ __forceinline__ void scan_hist(LDS &L)
 	}
 	if (lane == 63) L.wave_tot[wave] = inc;
 	lds_barrier();
-	uint32_t run = inc - sum;
+	uint32_t run = inc - sum, all = 0;
 #pragma unroll
-	for (int w = 0; w < LDS::kThreads / 64; w++) run += (w < wave) ? L.wave_tot[w] : 0u; // branch-free: a rolled loop gets vectorised into a register hog
+	for (int w = 0; w < LDS::kThreads / 64; w++) { // branch-free: a rolled loop gets vectorised into a register hog
+		const uint32_t wt = L.wave_tot[w];
+		run += (w < wave) ? wt : 0u;
+		all += wt;
+	}
 #pragma unroll
 	for (int j = 0; j < LDS::kBpt; j++) { L.lbase[LDS::kBpt * t + j] = run; run += v[j]; }
+	return all;
 }
 
 // Phases of the workgroup-wide bucket scatter of one tile (<= 16 records per thread).
@@ -260,8 +266,8 @@ __device__ __forceinline__ void scan_hist(LDS &L)
 
 // after every record has been ranked (hist complete): reserve global space, scan
 template <class LDS>
-__device__ __forceinline__ void scatter_reserve_scan(LDS &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[LDS::kBpt],
-                                                     uint32_t stride = 1u) // bucket b counts in cnt[b * stride]
+__device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[LDS::kBpt],
+                                                         uint32_t stride = 1u) // bucket b counts in cnt[b * stride]; returns the records of the tile
 {
 	const int t = (int)fresh_tid();
 	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
@@ -271,8 +277,9 @@ __device__ __forceinline__ void scatter_reserve_scan(LDS &L, uint32_t n_buckets,
 		const uint32_t b = LDS::kBpt * t + j, c = L.hist[b];
 		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], c) : 0u;
 	}
-	scan_hist(L);
+	const uint32_t all = scan_hist(L);
 	lds_barrier();
+	return all;
 }
 
 // bucket-sorted staging of the records, then the coalesced copy-out.  Records beyond a bucket's
@@ -289,9 +296,15 @@ template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = t
 __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
-                                                   const PartStore &P, Counters *ctr, uint32_t stride = 1u) // bucket b lives at out + b * stride * cap
+                                                   const PartStore &P, Counters *ctr, uint32_t stride = 1u, // bucket b lives at out + b * stride * cap
+                                                   uint32_t flat_total = 0u) // FLAT: the records of the tile (scatter_reserve_scan)
 {
 	const int t = (int)fresh_tid();
+	if (FLAT) { // the histogram has been consumed by the scan: every thread clears its own entries for the NEXT tile now, which then
+		// starts ranking without a zeroing pass and its barrier (scatter_tile)
+#pragma unroll
+		for (int j = 0; j < LDS::kBpt; j++) L.hist[LDS::kBpt * t + j] = 0;
+	}
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) {
 		if ((br[u] >> 16) < (uint32_t)LDS::kMaxB) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
@@ -308,7 +321,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 	lds_barrier();
 	if (FLAT) {
 		if (DBG != 2) {
-			const uint32_t total = L.lbase[n_buckets - 1u] + L.hist[n_buckets - 1u];
+			const uint32_t total = flat_total;
 #pragma unroll
 			for (int u = 0; u < PER_THREAD; u++) {
 				const uint32_t p = (uint32_t)u * LDS::kThreads + (uint32_t)t;
@@ -328,7 +341,8 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				}
 			}
 		}
-		lds_barrier(); // stage / hist are reused by the next tile; the global stores keep draining
+		// (no barrier here: the next tile ranks into the histogram cleared above and meets three barriers -- ranks complete, inside
+		// the scan, after the scan -- before it writes lbase, the stage buffer or desc again; the global stores keep draining)
 		return;
 	}
 	// copy-out: wave w takes buckets w, w+16, ...  Lane l fetches the descriptor of the wave's l-th
@@ -420,10 +434,7 @@ __device__ __forceinline__ void scatter_tile(LDS &L, const uint64_t (&rec)[PER_T
                                              uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                              const PartStore &P, Counters *ctr)
 {
-	const int t = (int)fresh_tid();
-#pragma unroll
-	for (int j = 0; j < LDS::kBpt; j++) L.hist[LDS::kBpt * t + j] = 0;
-	lds_barrier();
+	// (the histogram is zero: cleared by the kernel before its first tile and by scatter_stage_copy of the tile before)
 #pragma unroll
 	for (int u = 0; u < PER_THREAD; u++) bkt[u] = (bkt[u] << 16) | ((bkt[u] != 0xFFFFu) ? atomicAdd(&L.hist[bkt[u]], 1u) : 0u);
 	lds_barrier();
@@ -435,8 +446,9 @@ __device__ __forceinline__ void scatter_tile(LDS &L, const uint64_t (&rec)[PER_T
 		return;
 	}
 	uint32_t my_gbase[LDS::kBpt];
-	scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
-	scatter_stage_copy<PER_THREAD, DBG, FLAT, false>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr); // (level 2: FLAT)
+	const uint32_t all = scatter_reserve_scan(L, n_buckets, cnt, my_gbase);
+	static_assert(FLAT, "scatter_tile is level 2's: the flat copy-out clears the histogram for the next tile");
+	scatter_stage_copy<PER_THREAD, DBG, FLAT, false>(L, rec, bkt, my_gbase, n_buckets, out, cap, b1_of_bucket0, bucket_is_b1, G, P, ctr, 1u, all); // (level 2: FLAT)
 }
 
 // ---- lean extraction for the partition path -----------------------------------------------------
@@ -1566,6 +1578,12 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, n_local = gridDim.x >> 3; // gridDim.x is a multiple of 8
 	const uint32_t span = n_tiles - first_tile;
 	const uint32_t lo_tile = first_tile + (uint32_t)(((uint64_t)span * xcd) >> 3), hi_tile = first_tile + (uint32_t)(((uint64_t)span * (xcd + 1u)) >> 3);
+	{ // the histogram starts out zero; every tile clears it for the next one (scatter_stage_copy)
+		const int t = (int)fresh_tid();
+#pragma unroll
+		for (int j = 0; j < ScatterLdsL2T<MAXB>::kBpt; j++) L.hist[ScatterLdsL2T<MAXB>::kBpt * t + j] = 0;
+		lds_barrier();
+	}
 	L2RecIn<KF32> nxt[16];
 	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
 	l2_load_tile<KF32>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1);
