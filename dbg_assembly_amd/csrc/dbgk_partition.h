@@ -631,7 +631,8 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	// first / last window are patched afterwards (rare per lane, so the loop stays lean).
 	// Complemented neighbour codes (3 - x == x ^ 3) for all 16 positions at once:
 	const uint32_t lwc = ~c.lw, nbc = ~c.nb;
-	uint32_t rev_mask = 0, key_min = ~0u;
+	uint32_t rev_mask = 0;
+	bool zero_any = false; // some canonical k-mer of this lane is 0 (the key-0 node is kept apart, DBGgraph.cpp:418)
 #pragma unroll
 	for (uint32_t i = NPOS; i < 16; i++) bkt[i] = (uint32_t)kL1MaxB << 16; // lanes own NPOS positions: the rest never holds a record
 #pragma unroll
@@ -658,7 +659,6 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 			asm volatile("" : "+v"(rev_bit)); // accumulate in a VGPR now instead of parking 16 condition masks in SGPRs
 			rev_mask = SPECIAL ? (rev_mask | (rev_bit << ((uint32_t)NPOS - 1u - i))) : ((rev_mask << 1) | rev_bit);  // position i ends up at bit NPOS - 1 - i
 		}
-		key_min = min(key_min, (uint32_t)key | (uint32_t)(key >> 32)); // 0 <=> some canonical k-mer of this lane is 0
 		uint64_t q;
 		uint32_t slot, bucket; // slot: its low 32 bits (r <= 24 of them are recorded); bucket = slot >> r
 		if constexpr (WIDE_D == 3) { // compiled for KFREQ with direct blocks only: no hash, no division, no neighbour codes
@@ -682,11 +682,13 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		}
 		// only one packed register per position stays live across the tile
 		const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-		const uint32_t rec_lo = (q_lo << q_shift) | ((slot & rel_mask) << 6) | links;
+		// ((q << r | place in the bucket) << 6) | links, as two shift-or instructions (q_shift = r + 6)
+		const uint32_t rec_lo = (((q_lo << (q_shift - 6u)) | (slot & rel_mask)) << 6) | links;
 		const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
 		L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
 		const bool valid = SPECIAL ? true : (bool)((c.valid >> i) & 1u);
 		const bool zero = key == 0ull;
+		zero_any = zero_any || zero; // (the compare is needed below anyway: an OR of condition masks)
 		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
 		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kL1MaxB + (tid & 63u);
 		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
@@ -713,7 +715,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		if (fwd ? nr : nl) rbb = 4u;
 		L.stage[i * kL1Threads + tid] = (rec & ~63ull) | (lb << 3) | rbb;
 	}
-	return key_min == 0u;
+	return zero_any;
 }
 
 // after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
