@@ -27,7 +27,8 @@ algorithmic bytes of the step (33.25 B per k-mer) / ms_per_step aga
 spec peak (`frac`) and against the copy bandwidth measured in the same run (`frac_of_measured`: the best of the runtime's
 DtoD memcpy and the library's own 16-byte-per-lane copy kernels over 2 GiB buffers);
 per kernel: its measured time (HIP events on the library's own streams), its OWN bytes and its PMC
-traffic.  After the timed loop the graph of the last step is checked against the full-size golden
+traffic -- measured in this run at N = 1 (`traffic_source`: two child processes of this bench, one step each, under
+rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE), else taken from the committed profiles/traffic_r*.json.  After the timed loop the graph of the last step is checked against the full-size golden
 record of the CPU oracle (`verified`); `value_from_first_h2d` is SURVEY 8(d)'s region as written -- the same job timed from
 the first host-to-device copy of the packed read blocks (page-locked host buffer) to the final table, median of REPS
 repetitions, with the host packer's own rate next to it (`host_pack`) and the older ASCII / pageable variants; `also`
@@ -115,6 +116,9 @@ def parse_args():
                          "region hands to the device) or ASCII bytes")
     ap.add_argument("--no-also", action="store_true", help="default cfg2 run at N = 1: skip the three-step runs of cfg3 / cfg4 / cfg5")
     ap.add_argument("--brief", action="store_true", help="the timed loop and its check only (no H2D legs, probes, CPU baseline, also-runs)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not measure roofline.traffic in this run (two child processes of this bench under rocprofv3 --pmc, "
+                         "one step each); the committed profiles/traffic_r*.json is used instead")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
@@ -148,6 +152,59 @@ def measured_traffic(args, size, kernel):
                     (args.config, args.reads_per_gpu, args.kmer, size, args.engine, args.input) and (kernel is None or kernel in per):
                 best = sum(per.values()) if kernel is None else per[kernel]
     return best
+
+
+TRAFFIC_KERNELS = ("k_extract_scatter", "k_scatter_l2", "k_build_regions", "k_kf_build_blocks", "k_wide_scatter_l1", "k_wide_scatter_l2",
+                   "k_wide_build_regions", "k_prefix")   # the kernels of a step (k_pack_bases packs the resident input once, before the timed steps)
+
+
+def live_traffic(args):
+    """HBM bytes of ONE step, measured in this run: two child processes of this bench (--steps 1 --warmup 0 --brief, same workload)
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- counters alone, separate passes, the program itself behind `--`,
+    as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes; values are KiB, FETCH_SIZE doubled for these kernels'
+    coalesced streaming reads, WRITE_SIZE as is (the same arithmetic as profiles/make_traffic.py).  -> {kernel: bytes} or None."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    work = tempfile.mkdtemp(prefix="dbgk_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    sums = {"FETCH_SIZE": collections.defaultdict(float), "WRITE_SIZE": collections.defaultdict(float)}
+    try:
+        for counter in sums:
+            out_dir = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "1", "--warmup", "0", "--brief", "--no-live-traffic", "--config", args.config, "--input", args.input,
+                   "--engine", str(args.engine), "--reads-per-gpu", str(args.reads_per_gpu), "--genome-per-gpu", str(args.genome_per_gpu),
+                   "--table-slots", str(args.table_slots), "--kmer", str(args.kmer)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                print("live traffic: the %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:]), file=sys.stderr)
+                return None
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("dbgk::", "")
+                    if any(k.startswith(w) for w in TRAFFIC_KERNELS):
+                        sums[counter]["k_prefix_*" if k.startswith("k_prefix") else k] += float(row["Counter_Value"])
+    except Exception as e:  # noqa: BLE001  (a profiler that is missing or refuses to run must not take the bench line with it)
+        print("live traffic: %s" % e, file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    kernels = sorted(set(sums["FETCH_SIZE"]) | set(sums["WRITE_SIZE"]))
+    if not kernels:
+        return None
+    return {k: 2.0 * sums["FETCH_SIZE"][k] * 1024 + sums["WRITE_SIZE"][k] * 1024 for k in kernels}
 
 
 def cpu_model():
@@ -871,9 +928,12 @@ def run_graph(args, ctx, brief=False):
         else:
             own_bytes = {l1_name: kmers_step * (base_bytes + (32.0 if args.kmer <= 32 else 64.0))}
             kernel_ms = {l1_name: l1_ms}
+        live = None
+        if world == 1 and not multi and not brief and not args.no_live_traffic and args.traffic_bytes is None:
+            live = live_traffic(args)
         kernels = {}
         for kname, ms in kernel_ms.items():
-            traffic = measured_traffic(args, size, kname)
+            traffic = live.get(kname) if live else measured_traffic(args, size, kname)
             kernels[kname] = {"ms_per_step": ms, "own_bytes_per_step": own_bytes[kname],
                               "own_GBs": own_bytes[kname] / (ms * 1e-3) / 1e9 if ms > 0 else None,
                               "pmc_traffic_bytes_per_step": traffic,
@@ -906,7 +966,11 @@ def run_graph(args, ctx, brief=False):
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
                          "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step,
-                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args, size, None),
+                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else (sum(live.values()) if live else measured_traffic(args, size, None)),
+                         "traffic_source": "--traffic-bytes" if args.traffic_bytes is not None else
+                                           ("measured in this run: two child processes of this bench (one step each) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+                                            "KiB, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)" if live else "profiles/traffic_r*.json (committed PMC passes of this workload)"),
+                         "traffic_committed": measured_traffic(args, size, None),
                          "kernels_only_ms": pipeline_ms, "kernels_only_frac": kmers_step * b_alg / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "l2_build_wall_ms": wall_ms, "l2_build_chunks": chunks, "kernels": kernels},
             "phases_ms_per_step": {"mark": tm.mark_ms / args.steps, "insert": tm.insert_ms / args.steps,
