@@ -35,8 +35,14 @@ def run_cli(tmp_path, case, extra_env=None):
     return r, dump, prefix
 
 
-@pytest.mark.parametrize("engine", [2, 1], ids=["partition", "direct"])
-@pytest.mark.parametrize("case", FILE_CASES, ids=[c["name"] for c in FILE_CASES])
+# PARTITION (what the CLI runs) on every case; DIRECT on the cases that exercise the host layer's own logic (block schedule, enlarges,
+# the -e cap, formats, trimming, saturation) -- the DIRECT engine itself meets every golden in tests/test_gpu_parity.py
+DIRECT_CLI_CASES = {"block_b120", "enlarge_b50", "enlarge_b50_t3", "enlarge_cap_e1", "even_k32", "fasta_gz_k31", "fastq_at_quality_k31",
+                    "lengths_k31_r100", "mixed150_k31", "polyA_k31", "saturate_k31", "small_k4"}
+CLI_MATRIX = [(c, 2) for c in FILE_CASES] + [(c, 1) for c in FILE_CASES if c["name"] in DIRECT_CLI_CASES]
+
+
+@pytest.mark.parametrize("case,engine", CLI_MATRIX, ids=["%s-%s" % (c["name"], "partition" if e == 2 else "direct") for c, e in CLI_MATRIX])
 def test_cli_matches_reference(tmp_path, oracle, case, engine):
     """build_debruijn_graph() behind the reference's command line, both engines (PARTITION is what the
     CLI runs by default: records streamed through the record store, regions built in LDS).  Includes the
@@ -65,7 +71,7 @@ def test_cli_matches_reference(tmp_path, oracle, case, engine):
     assert re.search(r"Used tip kmer nodes:\s+%d\t" % st.tip_nodes, log)
 
 
-EARLY_CASES = [c for c in FILE_CASES if "enlarge" in c["name"] or c["name"] in ("mixed150_k31", "polyA_k31", "even_k16", "lengths_k31_r100")]
+EARLY_CASES = [c for c in FILE_CASES if c["name"] in ("enlarge_b50", "enlarge_cap_e1", "mixed150_k31", "polyA_k31", "lengths_k31_r100")]
 
 
 @pytest.mark.parametrize("case", EARLY_CASES, ids=[c["name"] for c in EARLY_CASES])
