@@ -315,7 +315,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 #pragma unroll
 	for (int j = 0; j < LDS::kBpt; j++) {
 		const uint32_t b = LDS::kBpt * t + j;
-		if (FLAT) L.desc[b] = (typename LDS::Desc)my_gbase[j];
+		if (FLAT) L.desc[b] = (typename LDS::Desc)(my_gbase[j] - L.lbase[b]); // global place of staged record p of bucket b = desc[b] + p (modulo 2^32)
 		else L.desc[b] = (typename LDS::Desc)(((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b]);
 	}
 	lds_barrier();
@@ -328,7 +328,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 				if (p >= total) continue;
 				const uint64_t rcd = L.stage[p];
 				const uint32_t b = (uint32_t)(rcd >> (6 + kRegionBits + G.l2_shift)) & (n_buckets - 1u);
-				const uint64_t off = (uint64_t)L.desc[b] + (p - L.lbase[b]);
+				const uint64_t off = (uint32_t)((uint32_t)L.desc[b] + p);
 				if (DBG == 3) {
 					out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * cap + off) & 4095ull)] = rcd;
 				} else if (off < cap) {
@@ -1556,10 +1556,19 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 		}
 		return;
 	}
+	// coalesced, two neighbouring records per lane and load instruction (16 bytes): the memory pipe charges per instruction,
+	// and the order of a tile's records does not matter to the scatter
+	typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 #pragma unroll
-	for (int u = 0; u < 16; u++) { // coalesced: consecutive lanes read consecutive records
-		const uint64_t i = first + (uint64_t)u * kL2Threads + tid;
-		if (i < filled) rec[u] = __builtin_nontemporal_load(in + i);
+	for (int u = 0; u < 16; u += 2) {
+		const uint64_t i = first + (uint64_t)u * kL2Threads + 2u * tid;
+		if (i + 1u < filled) {
+			const u32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(in + i));
+			rec[u] = ((uint64_t)v.y << 32) | v.x;
+			rec[u + 1] = ((uint64_t)v.w << 32) | v.z;
+		} else if (i < filled) {
+			rec[u] = __builtin_nontemporal_load(in + i);
+		}
 	}
 }
 
@@ -1614,12 +1623,14 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 // and fire-and-forget ds_add_u64 instead of the CAS loops 9.7 ms: the kernel is bound by instruction
 // issue in the divergent probe loops, ~1000 VALU + ~1200 SALU per wave per region, not by the
 // counter updates.)
+constexpr int kWalkQ = 64; // entries of a wave's walk queue (one record each): one flush of a full queue keeps every lane busy
 struct BuildLds {
 	unsigned long long ident[kRegionSlots + kSpillSlots]; // (record >> 6) + 1, 0 = empty
 	unsigned long long links[kRegionSlots + kSpillSlots];
 	unsigned long long red[kBuildThreads / 64];
 	uint32_t next_region;
 	uint32_t redo;                 // FAST build: some counter of the current region overflowed its byte, the region goes to the exact pass
+	unsigned long long walkq[kBuildThreads / 64][kWalkQ]; // FAST build: per wave, the records whose home slot holds another key
 };
 
 // Regions the FAST build could not finish (a link counter passed 255, or the region and its spill area were full): rebuilt from
@@ -1666,17 +1677,27 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	// i+1 -- the next 4096 records of this region or the first ones of the next region -- is already
 	// in flight, in the registers the previous batch has just vacated (the kernel must stay inside the
 	// 64 VGPRs that two workgroups per CU allow).
+	// (two neighbouring records per lane and load instruction: the memory pipe charges per instruction; the order of a region's
+	// records does not matter to the insert.  Lane t of a batch holds records base + 2t, 2t + 1, base + 2048 + 2t, 2t + 1.)
+	typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 	auto load_batch = [&](uint32_t f, uint32_t base, uint64_t (&recs)[kBatch]) {
+		static_assert(kBatch == 4, "two pairs of records per thread");
 #pragma unroll
 		for (int u = 0; u < kBatch; u++) recs[u] = ~0ull;
 		if (f == kNone) return;
 		const uint32_t filled = (uint32_t)(P.cnt2[f] < G.cap2 ? P.cnt2[f] : G.cap2);
 		const uint64_t *in = P.l2 + (uint64_t)f * G.cap2; // scalar base + 32-bit lane offset
-		const uint32_t lane_rec = base + fresh_tid();     // opaque: lane addresses are not worth keeping alive across batches
+		const uint32_t lane_rec = base + 2u * fresh_tid(); // opaque: lane addresses are not worth keeping alive across batches
 #pragma unroll
-		for (int u = 0; u < kBatch; u++) {
+		for (int u = 0; u < kBatch; u += 2) {
 			const uint32_t i = (uint32_t)u * kBuildThreads + lane_rec;
-			if (i < filled) recs[u] = __builtin_nontemporal_load(in + i);
+			if (i + 1u < filled) {
+				const u32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(in + i));
+				recs[u] = ((uint64_t)v.y << 32) | v.x;
+				recs[u + 1] = ((uint64_t)v.w << 32) | v.z;
+			} else if (i < filled) {
+				recs[u] = __builtin_nontemporal_load(in + i);
+			}
 		}
 	};
 	auto grab = [&]() { // one region index per workgroup, broadcast through LDS
@@ -1727,6 +1748,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 	uint32_t n_new = 0, n_conf = 0; // per thread: far below 2^32
 	uint32_t n_new_r = 0, n_conf_r = 0; // FAST: of the current region, committed only when the region is emitted
 	bool ovf = false;                   // FAST: this thread saw a counter overflow (or a full region) in the current region
+	uint32_t sat = 0;                   // FAST, lean batches: the largest counter byte this thread bumped in the current region, in bits 31..24
 
 	while (f != kNone) {
 		const uint32_t b1 = G.b_lo + (f >> (G.r - kRegionBits)); // f = LOCAL final bucket == local region index == (slot - slot_lo) >> 12
@@ -1745,90 +1767,88 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			for (int u = 0; u < kBatch; u++) x ^= recs[u];
 			if (x == 0x1234567ull) table[t].kmer = x;
 		} else if constexpr (FAST) {
-			uint32_t idx[kBatch];
+			// The first probe of a record is ONE unconditional compare-swap on its home slot (0 = claimed, its identity = found; the
+			// four of a thread are in flight together).  A record whose home slot holds another key does not walk in its owner lane
+			// -- a loop there runs as long as the busiest lane of the wave needs for all four of its records (a fifth of the records
+			// walk at all), with every register of the four selected by index: measured as the largest cost centre of the kernel --
+			// but is handed to the wave's QUEUE in LDS (ballot + mbcnt give its place); when the four records have been probed (or
+			// the queue would overflow) the wave walks the queued records one per lane, all lanes busy with a loop of a read, a
+			// compare and, on an empty slot, the claiming compare-swap.  Whoever ends a record's probe (owner or walker) bumps its
+			// two neighbour counters with one ds_add_rtn_u64; a plain add cannot saturate, so the returned bytes are folded into
+			// `sat` (the bumped byte moved to the top of a word, maximum over the thread's records of the region): >= 0xFF000000 at
+			// the region's end says a counter that already held 255 was bumped -- the region then emits NOTHING and is rebuilt by
+			// the exact form (kmerSet.cpp:253-273 stops at 255).  A wave without a record u skips that claim and that add (the
+			// tail of a region's last batch; most of the batch in a flush of a streaming build): an LDS atomic costs the same with
+			// 0 lanes as with 64.
+			const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+			unsigned long long *const wq = L.walkq[__builtin_amdgcn_readfirstlane((uint32_t)t >> 6)];
+			const bool whole = region_len == (uint32_t)kRegionSlots; // (all regions but the table's last)
+			auto bump = [&](uint32_t at, uint64_t rec) {
+				const uint32_t sh_l = (uint32_t)rec & 0x38u, sh_r = ((uint32_t)rec << 3) & 0x38u; // 8 * lb, 8 * rb; 32 = no neighbour on that side
+				const uint32_t dl = (uint32_t)(0x01000000ull >> sh_l), dr = (uint32_t)(0x01000000ull >> sh_r); // A in bits 31..24 (kmerSet.cpp:56)
+				const unsigned long long old = atomicAdd(&L.links[at], ((unsigned long long)dr << 32) | dl);
+				const uint32_t bl = (uint32_t)((uint64_t)(uint32_t)old << sh_l), br = (uint32_t)((uint64_t)(uint32_t)(old >> 32) << sh_r);
+				sat = max(sat, max(bl, br));
+			};
+			auto walk_queue = [&](uint32_t n_q) {
+				if (lane < n_q) {
+					const uint64_t rec = wq[lane];
+					const unsigned long long id = (rec >> 6) + 1ull;
+					const uint32_t home = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
+					uint32_t at = home + 1u;
+					bool hit = false, claimed = false;
+					while (!hit && at < (uint32_t)(kRegionSlots + kSpillSlots)) { // ONE exit, no breaks
+						unsigned long long cur = L.ident[at];
+						if (cur == 0ull) {
+							const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
+							claimed = prev == 0ull;
+							cur = claimed ? id : prev;
+						}
+						hit = cur == id;
+						at += hit ? 0u : 1u;
+					}
+					n_conf_r += at - home;
+					n_new_r += (claimed && at < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
+					ovf = ovf || !hit;                                 // region + spill area completely full: the exact pass sends it to the overflow list
+					if (hit) bump(at, rec);
+				}
+			};
 			unsigned long long got[kBatch];
-			bool probing[kBatch];
-			// first probe of all four records: the claims are in flight together.  A wave whose 64 lanes hold no record u at all --
-			// the tail of a region's last batch; most of the batch when a flush of a streaming build brings only a couple of
-			// thousand records per region -- skips that claim and that add: an LDS atomic costs the same with 0 lanes as with 64
-			bool wave_has[kBatch];
-#pragma unroll
-			for (int u = 0; u < kBatch; u++) wave_has[u] = __builtin_amdgcn_ballot_w64(recs[u] != ~0ull) != 0ull;
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
-				idx[u] = (uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u);
 				got[u] = 0ull;
-				// (a lane without a record compares against all-ones, which no slot ever holds: a plain read)
-#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 3
-				got[u] = (recs[u] >> 6) + 1ull; // timing experiment: no claims (results are wrong)
-#else
-				if (wave_has[u]) got[u] = atomicCAS(&L.ident[idx[u]], recs[u] != ~0ull ? 0ull : ~0ull, (recs[u] >> 6) + 1ull);
-#endif
+				if (recs[u] != ~0ull) got[u] = atomicCAS(&L.ident[(uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u)], 0ull, (recs[u] >> 6) + 1ull);
 			}
-			bool any = false;
+			uint32_t n_q = 0; // wave-uniform
+			bool own[kBatch];
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
 				const bool live = recs[u] != ~0ull;
-				const unsigned long long id = (recs[u] >> 6) + 1ull;
-				n_new_r += (live && got[u] == 0ull && idx[u] < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
-				probing[u] = live && got[u] != 0ull && got[u] != id;
-				idx[u] += probing[u] ? 1u : 0u;
-				n_conf_r += probing[u] ? 1u : 0u;
-				any = any || probing[u];
-			}
-			// the records whose home slot holds another key walk on: plain reads, a claim only where a slot is seen empty.  An LDS
-			// instruction costs the same whatever its lane count (profiles/ubench/lds_rate.hip: 2.6 ns per 64-bit read, 8 ns per
-			// 64-bit compare-swap and CU), so the walks of a thread's four records are NOT four loops (each as long as its slowest
-			// lane) but ONE: every lane steps the first of its records that is still walking -- a fifth of the records walk at all,
-			// most lanes have none or one, and the loop ends after as many steps as the busiest lane needs in total.
-			// (One unconditional compare-swap per step instead of the read and the conditional compare-swap: no change, 4.77 against
-			// 4.83 ms alone, 9.16 / 8.85 against 9.09 / 8.83 in the pair -- profiles/r03_walk_cas_ab.txt.)
-			if (any) {
-				uint32_t pend = (probing[0] ? 1u : 0u) | (probing[1] ? 2u : 0u) | (probing[2] ? 4u : 0u) | (probing[3] ? 8u : 0u);
-				while (pend) { // ONE exit, no breaks
-					const uint32_t u = (uint32_t)__builtin_ctz(pend);
-					const uint64_t rc = u == 0u ? recs[0] : (u == 1u ? recs[1] : (u == 2u ? recs[2] : recs[3]));
-					uint32_t at = u == 0u ? idx[0] : (u == 1u ? idx[1] : (u == 2u ? idx[2] : idx[3]));
-					const unsigned long long id = (rc >> 6) + 1ull;
-					unsigned long long cur = L.ident[at];
-					if (cur == 0ull) {
-						const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
-						cur = prev == 0ull ? id : prev;
-						n_new_r += (prev == 0ull && at < region_len) ? 1u : 0u;
-					}
-					const bool hit = cur == id;
-					at += hit ? 0u : 1u;
-					n_conf_r += hit ? 0u : 1u;
-					const bool lost = at >= (uint32_t)(kRegionSlots + kSpillSlots); // region + spill area completely full:
-					ovf = ovf || lost;                                                  // the exact pass sends it to the overflow list
-					at = lost ? 0u : at;
-					idx[0] = u == 0u ? at : idx[0];
-					idx[1] = u == 1u ? at : idx[1];
-					idx[2] = u == 2u ? at : idx[2];
-					idx[3] = u == 3u ? at : idx[3];
-					pend &= (hit || lost) ? ~(1u << u) : ~0u;
+				const uint32_t home = (uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u);
+				const bool fresh = live && got[u] == 0ull, walk = live && !fresh && got[u] != (recs[u] >> 6) + 1ull;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(walk);
+				const uint32_t n_w = (uint32_t)__builtin_popcountll(m);
+				if (n_q + n_w > (uint32_t)kWalkQ) { // (wave-uniform; rare at the load factors the reference allows)
+					walk_queue(n_q);
+					n_q = 0;
+				}
+				if (walk) wq[n_q + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = recs[u];
+				n_q += n_w;
+				n_new_r += (fresh && (whole || home < region_len)) ? 1u : 0u;
+				// the owner's add: issued now, its returned bytes looked at after the walks (four adds in flight)
+				own[u] = live && !walk;
+				if (own[u]) {
+					const uint32_t sh_l = (uint32_t)recs[u] & 0x38u, sh_r = ((uint32_t)recs[u] << 3) & 0x38u;
+					const uint32_t dl = (uint32_t)(0x01000000ull >> sh_l), dr = (uint32_t)(0x01000000ull >> sh_r);
+					got[u] = atomicAdd(&L.links[home], ((unsigned long long)dr << 32) | dl);
 				}
 			}
-			// +1 on the observed neighbour bytes, both dwords with one add; the returned word tells whether a byte was already 255
+			walk_queue(n_q);
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
-				const bool live = recs[u] != ~0ull;
-				const uint32_t lb = (uint32_t)(recs[u] >> 3) & 7u, rb = (uint32_t)recs[u] & 7u;
-				const uint32_t dl = (live && lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (live && rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
-#if defined(DBGK_BUILD_SKIP) && DBGK_BUILD_SKIP == 2
-				got[u] = dl + dr; // timing experiment: no adds (results are wrong)
-#else
-				got[u] = 0ull;
-				if (wave_has[u]) got[u] = atomicAdd(&L.links[idx[u]], ((unsigned long long)dr << 32) | dl);
-#endif
-			}
-#pragma unroll
-			for (int u = 0; u < kBatch; u++) {
-				const bool live = recs[u] != ~0ull;
-				const uint32_t lb = (uint32_t)(recs[u] >> 3) & 7u, rb = (uint32_t)recs[u] & 7u;
-				const uint32_t ml = (live && lb != 4u) ? (0xFFu << (24u - 8u * lb)) : 0u, mr = (live && rb != 4u) ? (0xFFu << (24u - 8u * rb)) : 0u;
-				const uint32_t lo = (uint32_t)got[u], hi = (uint32_t)(got[u] >> 32);
-				ovf = ovf || (ml && (lo & ml) == ml) || (mr && (hi & mr) == mr);
+				const uint32_t sh_l = (uint32_t)recs[u] & 0x38u, sh_r = ((uint32_t)recs[u] << 3) & 0x38u;
+				const uint32_t bl = (uint32_t)((uint64_t)(uint32_t)got[u] << sh_l), br = (uint32_t)((uint64_t)(uint32_t)(got[u] >> 32) << sh_r);
+				sat = own[u] ? max(sat, max(bl, br)) : sat;
 			}
 		} else {
 #pragma unroll
@@ -1878,7 +1898,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		if (last_of_region) {
 			bool redo_region = false;
 			if constexpr (FAST) {
-				if (ovf) L.redo = 1u;
+				if (ovf || sat >= 0xFF000000u) L.redo = 1u;
 				lds_barrier();
 				redo_region = __builtin_amdgcn_readfirstlane(L.redo) != 0u;
 				if (!redo_region) { n_new += n_new_r; n_conf += n_conf_r; }
@@ -1888,6 +1908,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 				}
 				n_new_r = n_conf_r = 0u;
 				ovf = false;
+				sat = 0u;
 			} else {
 				lds_barrier();
 			}
@@ -1896,7 +1917,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 				// image is cleared on the way for the next region.
 				// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
 				// written back into ident[], was measured: no change, 6.78 against 6.69-6.79 ms.)
-				for (uint32_t i = t; i < region_len; i += kBuildThreads) {
+				for (uint32_t i = fresh_tid(); i < region_len; i += kBuildThreads) { // (opaque: the lane's table address is not worth a register across the inserts)
 					const unsigned long long id = L.ident[i];
 					uint64_t key = 0ull, links = 0ull;
 					const bool foreign = INCR && !KF && (id & kForeign);
