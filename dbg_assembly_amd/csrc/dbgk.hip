@@ -884,7 +884,7 @@ static int plan_partition(dbgk_handle *h)
 		h->fan_mid = G.n2 / 64u; // 64
 		uint32_t lg = 0;
 		while ((1u << lg) < h->fan_mid) lg++;
-		const uint64_t cap_mid = (uint64_t)(per_slot * (double)n_ranks * (double)(1ull << (r - lg)) * 1.08) + 8192;
+		const uint64_t cap_mid = ((uint64_t)(per_slot * (double)n_ranks * (double)(1ull << (r - lg)) * 1.08) + 8192 + 15u) & ~15ull;
 		h->g_mid = G;
 		h->g_mid.n2 = h->fan_mid;
 		h->g_mid.l2_shift = 6;      // the low 6 bits of the final-bucket index are left to the final pass

@@ -1529,9 +1529,10 @@ using L2RecIn = typename std::conditional<KF32, uint32_t, uint64_t>::type;
 
 template <bool KF32 = false>
 __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore &P, const uint32_t *__restrict__ tile_prefix,
-                                             uint32_t g, uint32_t n_tiles, L2RecIn<KF32> (&rec)[16], uint32_t &b1_out)
+                                             uint32_t g, uint32_t n_tiles, L2RecIn<KF32> (&rec)[16], uint32_t &b1_out, uint32_t &n_out)
 {
 	b1_out = 0;
+	n_out = 0; // records of the tile (graph records only: the 32-bit KFREQ records are loaded one by one)
 #pragma unroll
 	for (int u = 0; u < 16; u++) rec[u] = ~(L2RecIn<KF32>)0;
 	if (g >= n_tiles) return;
@@ -1561,15 +1562,27 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 #pragma unroll
 	for (int u = 0; u < 16; u += 2) {
+		// (cap1 is a multiple of 16 and i even: record i + 1 lies inside the bucket's storage even when it is not a record -- the
+		// consumer voids it, l2_fix_odd_tail.  ONE guarded load per pair: an else-branch with an 8-byte load made the compiler wait
+		// for every load before issuing the next, level 2 alone 6.1 instead of 4.4 ms)
 		const uint64_t i = first + (uint64_t)u * kL2Threads + 2u * tid;
-		if (i + 1u < filled) {
+		if (i < filled) {
 			const u32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(in + i));
 			rec[u] = ((uint64_t)v.y << 32) | v.x;
 			rec[u + 1] = ((uint64_t)v.w << 32) | v.z;
-		} else if (i < filled) {
-			rec[u] = __builtin_nontemporal_load(in + i);
 		}
 	}
+	n_out = (uint32_t)(filled - first < (uint64_t)kL2Records ? filled - first : (uint64_t)kL2Records);
+}
+
+// a tile with an odd number of records (the last tile of a level-1 bucket, at most): the second half of its last pair is not a record
+__device__ __forceinline__ void l2_fix_odd_tail(uint64_t (&rec)[16], uint32_t n)
+{
+	if (!(n & 1u)) return; // (wave-uniform)
+	const uint32_t tid = fresh_tid();
+#pragma unroll
+	for (int u = 0; u < 16; u += 2)
+		if ((uint32_t)u * kL2Threads + 2u * tid + 1u == n) rec[u + 1] = ~0ull;
 }
 
 // (two workgroups of eight waves per CU = four waves per SIMD: at most 128 VGPRs, said to the compiler for the 1024-bucket form -- at
@@ -1596,12 +1609,13 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 		lds_barrier();
 	}
 	L2RecIn<KF32> nxt[16];
-	uint32_t nxt_b1; // own level-1 bucket index j = b1 - b_lo
-	l2_load_tile<KF32>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1);
+	uint32_t nxt_b1, nxt_n; // own level-1 bucket index j = b1 - b_lo; records of the tile
+	l2_load_tile<KF32>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1, nxt_n);
 	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
 		uint64_t rec[16];
 		uint32_t bkt[16];
 		const uint32_t j = nxt_b1;
+		if constexpr (!KF32) l2_fix_odd_tail(nxt, nxt_n);
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
 			if constexpr (KF32) rec[u] = nxt[u] == ~0u ? ~0ull : (uint64_t)nxt[u];
@@ -1609,7 +1623,7 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 			// an all-ones word is never a record: the neighbour fields only take the values 0..4
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits + G.l2_shift)) & (G.n2 - 1u));
 		}
-		l2_load_tile<KF32>(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1); // in flight during the scatter below
+		l2_load_tile<KF32>(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1, nxt_n); // in flight during the scatter below
 		// (KFREQ, direct blocks: the final buckets hold 16-bit records -- the same index arithmetic on a quarter of the bytes)
 		uint64_t *out = G.kf == 2u ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint16_t *>(P.l2) + (uint64_t)j * G.n2 * G.cap2)
 		                           : P.l2 + (uint64_t)j * G.n2 * G.cap2;
@@ -1690,15 +1704,24 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		const uint32_t lane_rec = base + 2u * fresh_tid(); // opaque: lane addresses are not worth keeping alive across batches
 #pragma unroll
 		for (int u = 0; u < kBatch; u += 2) {
+			// (cap2 is a multiple of 16 and i even: record i + 1 lies inside the bucket's storage even when it is not a record --
+			// the consumer voids it, fix_odd_tail.  ONE guarded load per pair: an else-branch with an 8-byte load made the compiler
+			// wait for every load before issuing the next)
 			const uint32_t i = (uint32_t)u * kBuildThreads + lane_rec;
-			if (i + 1u < filled) {
+			if (i < filled) {
 				const u32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(in + i));
 				recs[u] = ((uint64_t)v.y << 32) | v.x;
 				recs[u + 1] = ((uint64_t)v.w << 32) | v.z;
-			} else if (i < filled) {
-				recs[u] = __builtin_nontemporal_load(in + i);
 			}
 		}
+	};
+	// a region with an odd number of records: the second half of its last pair is not a record
+	auto fix_odd_tail = [&](uint32_t base, uint32_t filled, uint64_t (&recs)[kBatch]) {
+		if (!(filled & 1u) || filled - base > (uint32_t)kBatch * kBuildThreads) return; // (wave-uniform)
+		const uint32_t lane_rec = base + 2u * fresh_tid();
+#pragma unroll
+		for (int u = 0; u < kBatch; u += 2)
+			if ((uint32_t)u * kBuildThreads + lane_rec + 1u == filled) recs[u + 1] = ~0ull;
 	};
 	auto grab = [&]() { // one region index per workgroup, broadcast through LDS
 		if (t == 0) {
@@ -1761,6 +1784,7 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 		const uint32_t f_nxt = last_of_region ? f_after : f, base_nxt = last_of_region ? 0u : base + (uint32_t)kBatch * kBuildThreads;
 		uint64_t nxt[kBatch];
 		load_batch(f_nxt, base_nxt, nxt);
+		fix_odd_tail(base, filled, recs);
 		if (DBG == 1) {
 			uint64_t x = 0;
 #pragma unroll
@@ -1782,35 +1806,33 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			// 0 lanes as with 64.
 			const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 			unsigned long long *const wq = L.walkq[__builtin_amdgcn_readfirstlane((uint32_t)t >> 6)];
-			const bool whole = region_len == (uint32_t)kRegionSlots; // (all regions but the table's last)
-			auto bump = [&](uint32_t at, uint64_t rec) {
-				const uint32_t sh_l = (uint32_t)rec & 0x38u, sh_r = ((uint32_t)rec << 3) & 0x38u; // 8 * lb, 8 * rb; 32 = no neighbour on that side
-				const uint32_t dl = (uint32_t)(0x01000000ull >> sh_l), dr = (uint32_t)(0x01000000ull >> sh_r); // A in bits 31..24 (kmerSet.cpp:56)
-				const unsigned long long old = atomicAdd(&L.links[at], ((unsigned long long)dr << 32) | dl);
-				const uint32_t bl = (uint32_t)((uint64_t)(uint32_t)old << sh_l), br = (uint32_t)((uint64_t)(uint32_t)(old >> 32) << sh_r);
-				sat = max(sat, max(bl, br));
-			};
 			auto walk_queue = [&](uint32_t n_q) {
 				if (lane < n_q) {
 					const uint64_t rec = wq[lane];
 					const unsigned long long id = (rec >> 6) + 1ull;
 					const uint32_t home = (uint32_t)(rec >> 6) & (kRegionSlots - 1u);
-					uint32_t at = home + 1u;
-					bool hit = false, claimed = false;
-					while (!hit && at < (uint32_t)(kRegionSlots + kSpillSlots)) { // ONE exit, no breaks
-						unsigned long long cur = L.ident[at];
+					uint32_t at = home, claim = 0u;
+					unsigned long long cur;
+					do { // ONE exit, no breaks; `at` is the slot just looked at
+						at++;
+						cur = L.ident[at];
 						if (cur == 0ull) {
 							const unsigned long long prev = atomicCAS(&L.ident[at], 0ull, id);
-							claimed = prev == 0ull;
-							cur = claimed ? id : prev;
+							claim = prev == 0ull ? 1u : 0u;
+							cur = prev == 0ull ? id : prev;
 						}
-						hit = cur == id;
-						at += hit ? 0u : 1u;
-					}
+					} while (cur != id && at < (uint32_t)(kRegionSlots + kSpillSlots - 1));
+					const bool hit = cur == id;
 					n_conf_r += at - home;
-					n_new_r += (claimed && at < region_len) ? 1u : 0u; // spilled nodes are counted when they are merged
-					ovf = ovf || !hit;                                 // region + spill area completely full: the exact pass sends it to the overflow list
-					if (hit) bump(at, rec);
+					n_new_r += at < region_len ? claim : 0u; // spilled nodes are counted when they are merged
+					ovf = ovf || !hit;                       // region + spill area completely full: the exact pass sends it to the overflow list
+					if (hit) {
+						const uint32_t sh_l = (uint32_t)rec & 0x38u, sh_r = ((uint32_t)rec << 3) & 0x38u; // 8 * lb, 8 * rb; 32 = no neighbour on that side
+						const uint32_t dl = (uint32_t)(0x01000000ull >> sh_l), dr = (uint32_t)(0x01000000ull >> sh_r); // A in bits 31..24 (kmerSet.cpp:56)
+						const unsigned long long old = atomicAdd(&L.links[at], ((unsigned long long)dr << 32) | dl);
+						const uint32_t bl = (uint32_t)((uint64_t)(uint32_t)old << sh_l), br = (uint32_t)((uint64_t)(uint32_t)(old >> 32) << sh_r);
+						sat = max(sat, max(bl, br));
+					}
 				}
 			};
 			unsigned long long got[kBatch];
@@ -1823,9 +1845,10 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			bool own[kBatch];
 #pragma unroll
 			for (int u = 0; u < kBatch; u++) {
-				const bool live = recs[u] != ~0ull;
 				const uint32_t home = (uint32_t)(recs[u] >> 6) & (kRegionSlots - 1u);
-				const bool fresh = live && got[u] == 0ull, walk = live && !fresh && got[u] != (recs[u] >> 6) + 1ull;
+				// (bitwise: three compares and two scalar ANDs, no short-circuit branches)
+				const bool live = recs[u] != ~0ull, fresh = got[u] == 0ull, same = got[u] == (recs[u] >> 6) + 1ull;
+				const bool walk = live & !fresh & !same;
 				const unsigned long long m = __builtin_amdgcn_ballot_w64(walk);
 				const uint32_t n_w = (uint32_t)__builtin_popcountll(m);
 				if (n_q + n_w > (uint32_t)kWalkQ) { // (wave-uniform; rare at the load factors the reference allows)
@@ -1834,9 +1857,9 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 				}
 				if (walk) wq[n_q + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = recs[u];
 				n_q += n_w;
-				n_new_r += (fresh && (whole || home < region_len)) ? 1u : 0u;
+				n_new_r += (live & fresh & (home < region_len)) ? 1u : 0u;
 				// the owner's add: issued now, its returned bytes looked at after the walks (four adds in flight)
-				own[u] = live && !walk;
+				own[u] = live & !walk;
 				if (own[u]) {
 					const uint32_t sh_l = (uint32_t)recs[u] & 0x38u, sh_r = ((uint32_t)recs[u] << 3) & 0x38u;
 					const uint32_t dl = (uint32_t)(0x01000000ull >> sh_l), dr = (uint32_t)(0x01000000ull >> sh_r);
