@@ -2598,7 +2598,10 @@ static int build_from_records(dbgk_handle *h)
 	const PartGeom &G = h->geom;
 	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;
 	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
-	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 12; // 1 = level 2, then build (8 .. 16 within noise, 12 and 16 ahead on two boxes: profiles/r04_env_sweep_chunks_l2grid.txt)
+	// 1 = level 2, then the build.  Round 5: with the leaner build and 16-byte record loads either kernel alone runs close to what the
+	// memory system gives this traffic (4.1 + 3.7 ms for 2 x 19.2 GB), side by side they only share it: 1 / 2 / 3 / 4 / 6 / 12 chunk pairs ->
+	// 12.86-12.92 / 12.86 / 13.00 / 13.03 / 13.07 / 13.06-13.24 ms per cfg2 step (profiles/r05_build_lean_walk_and_chunks_ab.txt; rounds 2-4: 12)
+	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 1;
 	uint32_t n_chunks = (dbg_l2 || dbg_build || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
 	int rc = part_plan(h);
 	if (rc) return rc;

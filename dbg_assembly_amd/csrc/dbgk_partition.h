@@ -292,12 +292,15 @@ __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buck
 // level 2 went from 6.3 to 5.3 ms.
 // KF32_POSSIBLE: the caller may run for a KFREQ handle with direct blocks (level 1 with the 64-bit slot path, WIDE_D >= 2): only
 // those instantiations carry the 32-bit copy-out
-template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, class LDS>
+// N_SURE > 0 and `sure`: the caller knows that the lane's first N_SURE records all have a bucket (regular level-1 tiles without a
+// zero key); a wave in which every lane says so stages them without a test per record, the lbase reads issued together
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, int N_SURE = 0, class LDS>
 __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                                    const PartStore &P, Counters *ctr, uint32_t stride = 1u, // bucket b lives at out + b * stride * cap
-                                                   uint32_t flat_total = 0u) // FLAT: the records of the tile (scatter_reserve_scan)
+                                                   uint32_t flat_total = 0u, // FLAT: the records of the tile (scatter_reserve_scan)
+                                                   bool sure = false)
 {
 	const int t = (int)fresh_tid();
 	if (FLAT) { // the histogram has been consumed by the scan: every thread clears its own entries for the NEXT tile now, which then
@@ -305,10 +308,23 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 #pragma unroll
 		for (int j = 0; j < LDS::kBpt; j++) L.hist[LDS::kBpt * t + j] = 0;
 	}
+	bool staged = false;
+	if constexpr (N_SURE > 0) {
+		if (__builtin_amdgcn_ballot_w64(!sure) == 0ull) { // (wave-uniform)
+			uint32_t at[N_SURE];
 #pragma unroll
-	for (int u = 0; u < PER_THREAD; u++) {
-		if ((br[u] >> 16) < (uint32_t)LDS::kMaxB) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
-		if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four lbase reads in flight are enough; more costs VGPRs the callers do not have
+			for (int u = 0; u < N_SURE; u++) at[u] = L.lbase[br[u] >> 16];
+#pragma unroll
+			for (int u = 0; u < N_SURE; u++) L.stage[at[u] + (br[u] & 0xFFFFu)] = rec[u];
+			staged = true;
+		}
+	}
+	if (!staged) {
+#pragma unroll
+		for (int u = 0; u < PER_THREAD; u++) {
+			if ((br[u] >> 16) < (uint32_t)LDS::kMaxB) L.stage[L.lbase[br[u] >> 16] + (br[u] & 0xFFFFu)] = rec[u];
+			if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four lbase reads in flight are enough; more costs VGPRs the callers do not have
+		}
 	}
 	// one descriptor per bucket for the copy-out: global offset | records in this tile | first staged index
 	// (FLAT: the global offset alone; lbase is read next to it)
@@ -348,7 +364,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 	// copy-out: wave w takes buckets w, w+16, ...  Lane l fetches the descriptor of the wave's l-th
 	// bucket in ONE LDS read; the loop then broadcasts descriptor k with readlane, so every per-bucket
 	// quantity is scalar and an iteration is an LDS read of the staged run plus one coalesced store.
-	const uint32_t lane = t & 63, wave = t >> 6;
+	const uint32_t lane = t & 63, wave = __builtin_amdgcn_readfirstlane((uint32_t)t >> 6); // (scalar: every per-bucket address below is scalar arithmetic)
 	constexpr uint32_t kWaves = LDS::kThreads / 64;
 	const uint32_t per_wave = (DBG == 2) ? 0u : (n_buckets + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * k < n_buckets
 	const uint32_t mine = wave + kWaves * lane;
@@ -719,9 +735,9 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 }
 
 // after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
-template <int DBG, bool KF32_POSSIBLE = true>
+template <int DBG, bool KF32_POSSIBLE = true, int N_SURE = 0>
 __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
-                                                const uint32_t (&bkt)[16])
+                                                const uint32_t (&bkt)[16], bool sure = false)
 {
 	lds_barrier(); // hist complete
 	// the parked records come back into registers BEFORE the reservation and the scan: the barriers inside the scan then
@@ -733,7 +749,7 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	uint32_t my_gbase[ScatterLds::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
 	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
+	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure);
 }
 
 // LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
@@ -1152,7 +1168,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
 		if constexpr (LIN) l1_scatter_tail_linear<DBG, C, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
-		else l1_scatter_tail<DBG, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
+		else l1_scatter_tail<DBG, (WIDE_D >= 2), (REG ? C : 0)>(L, G, P, ctr, tid, bkt, REG && !zero_seen); // (regular tiles: every window of every lane is valid)
 		raw = nxt;
 	}
 }
