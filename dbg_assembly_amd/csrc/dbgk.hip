@@ -175,6 +175,8 @@ struct dbgk_handle {
 	PartGeom geom;
 	PartStore store;
 	uint32_t *tile_prefix = nullptr; // [n_ranks * B + 1] level-2 tile plan
+	uint32_t *l2_done = nullptr;     // EARLY level 2 (early_l2): records per level-1 bucket that level 2 has taken already; null = not in use
+	uint64_t l2_seen_kmers = 0;      // pending_kmers when the last early level-2 round was launched
 	// THREE-LEVEL partition for tables whose level-1 buckets hold 4096 regions (2^33 slots and more): level 2
 	// runs as two passes of the same kernel -- MID: every level-1 bucket into fan_mid = n2 / 64 mid buckets (store `mid`,
 	// laid out like the level-1 store of a table with r - log2(fan_mid)), FINAL: every mid bucket into its 64 final buckets,
@@ -305,12 +307,13 @@ extern "C" const char *dbgk_strerror(int status)
 static void free_partition_stores(dbgk_handle *h)
 {
 	for (void *p : {(void *)h->store.l1, (void *)h->store.l2, (void *)h->store.cnt1, (void *)h->store.cnt2, (void *)h->store.ovf,
-	                (void *)h->store.spill, (void *)h->store.ovf_n, (void *)h->tile_prefix, (void *)h->store.hh, (void *)h->region_cursor,
+	                (void *)h->store.spill, (void *)h->store.ovf_n, (void *)h->tile_prefix, (void *)h->store.hh, (void *)h->region_cursor, (void *)h->l2_done,
 	                (void *)h->mid, (void *)h->cnt_mid, (void *)h->tile_prefix2,
 	                (void *)h->inbox, (void *)h->inbox_cnt, (void *)h->store.outgoing, (void *)h->store.outgoing_n})
 		if (p) (void)hipFree(p);
 	memset(&h->store, 0, sizeof h->store);
 	h->tile_prefix = nullptr;
+	h->l2_done = nullptr;
 	h->region_cursor = nullptr;
 	h->inbox = nullptr;
 	h->inbox_cnt = nullptr;
@@ -414,6 +417,7 @@ static int clear_record_store(dbgk_handle *h, bool with_counters = false /* also
 	if (h->three) add(h->cnt_mid, (size_t)h->geom.nb_own * h->fan_mid * 4);
 	add(h->store.ovf_n, 16);
 	add(h->store.outgoing_n, 8);
+	if (h->l2_done) add(h->l2_done, (size_t)h->geom.n_ranks * h->geom.B * h->geom.n_sub * 8); // done[] and upto[]
 	add(h->region_cursor, (kMaxBuildLaunches + 2) * sizeof(unsigned int)); // one work cursor per build launch of the next build, + the exact pass's cursor and count
 	hipLaunchKernelGGL(k_zero_list, dim3(64), dim3(kBlock), 0, h->stream, z, with_counters ? h->d_ctr : (Counters *)nullptr);
 	HIPCHK(hipGetLastError());
@@ -423,6 +427,7 @@ static int clear_record_store(dbgk_handle *h, bool with_counters = false /* also
 	h->next_bucket = 0;
 	h->chunks_used = 0;
 	h->pending_kmers = 0;
+	h->l2_seen_kmers = 0;
 	return DBGK_OK;
 }
 
@@ -920,7 +925,8 @@ static int setup_partition(dbgk_handle *h)
 	P.outgoing_cap = 1ull << 16;
 	const size_t n_entries = (size_t)G.n_ranks * G.B * G.n_sub;
 	const size_t l1_bytes = n_entries * G.cap1 * 8, l2_bytes = (size_t)G.nb_own * G.n2 * G.cap2 * (G.kf == 2u ? 2 : 8); // (direct blocks: 16-bit records)
-	bool ok = hipMalloc(&P.l1, l1_bytes) == hipSuccess && hipMalloc(&P.l2, l2_bytes) == hipSuccess &&
+	// (+ 64 bytes: level 2 and the build load their records in pairs, and the second half of a bucket's last pair may lie behind the bucket)
+	bool ok = hipMalloc(&P.l1, l1_bytes + 64) == hipSuccess && hipMalloc(&P.l2, l2_bytes + 64) == hipSuccess &&
 	          hipMalloc(&P.cnt1, n_entries * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.nb_own * G.n2 * 4) == hipSuccess &&
 	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(Node)) == hipSuccess &&
 	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->tile_prefix, (n_entries + 1) * 4) == hipSuccess &&
@@ -928,7 +934,7 @@ static int setup_partition(dbgk_handle *h)
 
 	          hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(Node)) == hipSuccess && hipMalloc(&P.outgoing_n, 8) == hipSuccess;
 	if (ok && h->sharded)
-		ok = hipMalloc(&h->inbox, l1_bytes) == hipSuccess && hipMalloc(&h->inbox_cnt, n_entries * 4) == hipSuccess;
+		ok = hipMalloc(&h->inbox, l1_bytes + 64) == hipSuccess && hipMalloc(&h->inbox_cnt, n_entries * 4) == hipSuccess;
 	if (!ok) {
 		g_last_error = "hipMalloc of the PARTITION record stores failed";
 		return DBGK_ERR_NOMEM;
@@ -941,10 +947,21 @@ static int setup_partition(dbgk_handle *h)
 	P.hh_magic = make_mod_magic(kHeavyHitterSlots);
 	P.inbox = h->sharded ? h->inbox : P.l1;
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
+	// EARLY level 2 (early_l2): a handle that extracts into its own inbox scatters what earlier batches stored while the next
+	// batch is on the link.  Not for shards (their inbox is filled by the exchange), the three-level form, 32-bit KFREQ records
+	const bool no_early = getenv("DBGK_EARLY_L2") && atoi(getenv("DBGK_EARLY_L2")) == 0; // (read per handle: measurements, and the tests compare the two)
+	P.l2_done = P.l2_upto = nullptr;
+	if (!h->sharded && !h->three && G.kf != 2u && !no_early) {
+		if (hipMalloc(&h->l2_done, 2 * n_entries * 4) != hipSuccess) return DBGK_ERR_NOMEM; // done[] and upto[]
+		HIPCHK(hipMemsetAsync(h->l2_done, 0, 2 * n_entries * 4, h->stream));
+		P.l2_done = h->l2_done;
+		P.l2_upto = h->l2_done + n_entries;
+	}
+	h->l2_seen_kmers = 0;
 	h->store_capacity = expected;
 	if (h->three) {
 		const size_t n_mid = (size_t)G.nb_own * h->fan_mid;
-		if (hipMalloc(&h->mid, n_mid * h->g_mid.cap2 * 8) != hipSuccess || hipMalloc(&h->cnt_mid, n_mid * 4) != hipSuccess ||
+		if (hipMalloc(&h->mid, n_mid * h->g_mid.cap2 * 8 + 64) != hipSuccess || hipMalloc(&h->cnt_mid, n_mid * 4) != hipSuccess ||
 		    hipMalloc(&h->tile_prefix2, (n_mid + 1) * 4) != hipSuccess) {
 			g_last_error = "hipMalloc of the mid-level record store failed";
 			return DBGK_ERR_NOMEM;
@@ -1458,6 +1475,8 @@ static int ensure_prefix_scratch(dbgk_handle *h, uint64_t n_reads, uint64_t n_ba
 	return DBGK_OK;
 }
 
+static int early_l2(dbgk_handle *h);
+
 static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint32_t *d_start, uint32_t *d_dead, int has_long /* 0,1 or -1 = ask device */,
                         int64_t uniform_len = -1 /* every read this long; 0 = lengths differ; -1 = ask device */,
@@ -1469,7 +1488,9 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	if (h->seed) has_long = 1; // the dead bitmap carries the 'N' positions
 	const uint64_t words = bitmap_words(n_bases);
 	TimedSpan sp;
-	int rc = span_begin(h, PH_MARK, sp);
+	int rc = early_l2(h); // level 2 of what the batches before this one stored: queued IN FRONT of this batch's level 1, i.e. it runs while
+	if (rc) return rc;    // this batch is still on the link (the level-1 launch below waits for the copy, the level-2 round does not)
+	rc = span_begin(h, PH_MARK, sp);
 	if (rc) return rc;
 	static_assert(offsetof(Counters, len_max) + sizeof(unsigned long long) - offsetof(Counters, any_dead) == 20, "per-batch fields are contiguous");
 	if (d_offsets) HIPCHK(hipMemsetAsync(&h->d_ctr->any_dead, 0, 20, h->stream)); // any_dead, len_min_inv, len_max: what k_mark reports per batch
@@ -1849,6 +1870,10 @@ static int h2d_batch(dbgk_handle *h, StageSlot &s, const char *src, uint64_t nb,
 	}
 	if (!serial) {
 		HIPCHK(hipEventRecord(s.copied, cs));
+		// level 2 of what the batches before this one stored goes onto the compute stream BEFORE that stream is told to wait for this
+		// batch's copy: it runs while the batch is on the link
+		int rc = early_l2(h);
+		if (rc) return rc;
 		HIPCHK(hipStreamWaitEvent(h->stream, s.copied, 0));
 	}
 	return DBGK_OK;
@@ -2272,6 +2297,9 @@ extern "C" int dbgk_push_reads_packed_uniform(dbgk_handle *h, const uint32_t *pa
 	uint64_t per_batch = h->cap_bases / L;
 	per_batch -= per_batch % align_reads;
 	if (per_batch == 0) return DBGK_ERR_ARG; // reads larger than max_batch_bases
+	// (large batches in whole level-1 tiles -- 1024 / Q reads, Q a power of two: no second launch for the reads behind the last whole tile)
+	if (per_batch >= 64 * 1024 && align_reads <= 16) align_reads = 1024;
+	per_batch -= per_batch % align_reads;
 	const bool streaming = (h->part && !h->sharded) || (h->wpart && !h->wbuilt);
 	const uint64_t src_words = (n_reads * L + 15) >> 4;
 	const bool pinned_source = device_readable_host(reinterpret_cast<const char *>(packed), src_words * 4);
@@ -2280,8 +2308,17 @@ extern "C" int dbgk_push_reads_packed_uniform(dbgk_handle *h, const uint32_t *pa
 		dbgk_handle *h; bool &on;
 		~WaitSource() { if (on && h->source_read) (void)hipEventSynchronize(h->source_read); }
 	} wait_source{h, source_in_flight};
+	int ramp = h->pending_kmers == 0 ? 0 : 4; // index into the opening batch sizes of a fresh job (below); 4: full batches
 	for (uint64_t r0 = 0; r0 < n_reads;) {
 		uint64_t nr = std::min(per_batch, n_reads - r0);
+		// the kernels of a batch cannot start before its copy has ended, and they take about 1.5 times as long as the copy: a job of
+		// several batches opens with batches of 1/8, 1/4, 1/2 and 3/4 of the full size, so that the GPU waits for an eighth of a
+		// batch's copy before it has work and hardly again (profiles/r05_h2d_region_timeline.txt)
+		if (ramp < 4 && n_reads > per_batch) {
+			static const uint64_t kEighths[4] = {1, 2, 4, 6};
+			const uint64_t want = per_batch / 8 * kEighths[ramp++];
+			if (want >= align_reads) nr = std::min(nr, want - want % align_reads);
+		}
 		if (streaming && h->pending_kmers > 0) {
 			const uint64_t room = h->store_capacity > h->pending_kmers ? h->store_capacity - h->pending_kmers : 0;
 			if (w_read && nr * w_read > room) { // what the record store still takes, in whole alignment groups; else flush first
@@ -2519,6 +2556,33 @@ static void launch_build_redo(dbgk_handle *h, hipStream_t stream)
 // part_plan: level-2 tile plan for all own buckets (needs every inbox fill count);
 // part_build_range: level 2 + region build of the own buckets [j0, j1), asynchronous, level 2 on
 // `stream`, the build behind it on `stream2`; part_finish: join, spill / overflow fix-ups.
+// EARLY level 2.  Level 2 is an append into the final buckets, so it does not have to wait for the end of the input: every
+// push first queues a level-2 round over the records the batches before it left in the level-1 buckets (tile plan from the fill
+// counts minus what earlier rounds took, P.l2_done), then its own level 1.  A job whose batches come over the link (the reference
+// overlaps reading and parsing the same way, DBGgraph.cpp:233-296) keeps the GPU busy with level 2 while the next batch travels;
+// after the last batch only that batch's level 2 and the region build remain.  A job that is pushed in one piece (bench.py's
+// resident step) is unchanged: its only round runs at dbgk_finalize.  Rounds are only worth their tiles' fixed costs when there
+// is something to scatter: at least kEarlyL2Min occurrences since the last one.
+constexpr uint64_t kEarlyL2Min = 8ull << 20;
+static int early_l2(dbgk_handle *h)
+{
+	if (!h->part || !h->l2_done || h->part_planned || h->part_built) return DBGK_OK;
+	const char *e_min = getenv("DBGK_EARLY_L2_MIN"); // (read per call: the tests ask for a round after every small batch)
+	const uint64_t min_kmers = e_min ? strtoull(e_min, nullptr, 10) : kEarlyL2Min;
+	if (h->pending_kmers < h->l2_seen_kmers + std::max<uint64_t>(min_kmers, 1)) return DBGK_OK;
+	const PartGeom &G = h->geom;
+	static const int l2_grid_env = getenv("DBGK_L2_GRID") ? atoi(getenv("DBGK_L2_GRID")) : 0;
+	const int l2_grid = l2_grid_env >= 8 ? (l2_grid_env & ~7) : h->n_cu;
+	TimedSpan sp;
+	int rc = span_begin(h, PH_PARTITION, sp);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->geom, h->store, h->tile_prefix);
+	launch_l2<0>(h, l2_grid, 0, G.nb_own);
+	HIPCHK(hipGetLastError());
+	h->l2_seen_kmers = h->pending_kmers;
+	return span_end(h, sp);
+}
+
 static int part_plan(dbgk_handle *h)
 {
 	if (h->part_planned) return DBGK_OK;

@@ -133,6 +133,9 @@ struct PartStore {
 	uint32_t *cnt1;               // [n_ranks * B][n_sub] records appended (may exceed cap1: excess went to ovf)
 	const uint64_t *inbox;        // [n_ranks][B][n_sub][cap1]: level-1 buckets of MY slot range from every rank
 	const uint32_t *inbox_cnt;    // [n_ranks * B * n_sub]   (n_ranks == 1: inbox == l1, inbox_cnt == cnt1)
+	uint32_t *l2_done;            // [n_ranks * B * n_sub] or null -- EARLY level 2 (dbgk.hip early_l2: a level-2 round over what the batches so far
+	uint32_t *l2_upto;            // stored, queued in front of every push): the round in flight scatters records [l2_done, l2_upto) of each inbox entry;
+	                              // both written by k_plan_l2 (done <- the last round's upto, upto <- the fill count now)
 	uint64_t *l2;                 // [nb_own * n2][cap2], local final bucket = (b1 - b_lo) * n2 + b2
 	uint32_t *cnt2;               // [nb_own * n2]
 	Node *outgoing;               // nodes that probed past the end of this shard: for the next rank
@@ -1514,7 +1517,13 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 		const uint32_t entry = e < n_entries ? flat_to_entry(G, e, own_j) : 0u;
 		if (e < n_entries && own_j < G.nb_own) {
 			const uint64_t filled = P.inbox_cnt[entry] < G.cap1 ? P.inbox_cnt[entry] : G.cap1;
-			v = (uint32_t)((filled + kL2Records - 1) / kL2Records);
+			uint64_t done = 0;
+			if (P.l2_done) { // EARLY level 2: this round takes what has arrived since the last one
+				done = P.l2_upto[entry];
+				P.l2_done[entry] = (uint32_t)done;
+				P.l2_upto[entry] = (uint32_t)filled;
+			}
+			v = (uint32_t)((filled - done + kL2Records - 1) / kL2Records);
 		}
 		uint32_t inc = v;
 #pragma unroll
@@ -1560,8 +1569,8 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	uint32_t own_j;
 	const uint32_t e = flat_to_entry(G, lo, own_j);
 	b1_out = own_j; // own bucket index j
-	const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
-	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records;
+	const uint64_t filled = P.l2_done ? (uint64_t)P.l2_upto[e] : (P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1); // (EARLY level 2: as planned)
+	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records + (P.l2_done ? P.l2_done[e] : 0u);
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
 	if constexpr (KF32) { // KFREQ, direct blocks: 32-bit level-1 records (scatter_stage_copy); never all ones -- the low six bits are 4
@@ -1954,11 +1963,47 @@ __global__ __launch_bounds__(kBuildThreads, 8) void k_build_regions(PartGeom G, 
 			if (DBG != 1 && DBG != 2 && !redo_region) {
 				// emit the region: slot i of the table <- LDS slot i (key recomputed from (q, home slot)); the LDS
 				// image is cleared on the way for the next region.
-				// (Compacting the ~37 % occupied slots first so that hash_code_inverse runs on full waves, keys
-				// written back into ident[], was measured: no change, 6.78 against 6.69-6.79 ms.)
+				if constexpr (FAST && !KF && !INCR && DBG == 0) {
+					// The keys first, on FULL waves: a wave owns the slots tid + 1024 j, 37 % of them occupied (cfg2), and hash_code_inverse is
+					// ~55 of the ~70 VALU instructions an occupied slot costs below -- executed for every slot of a wave that has one.  So each
+					// wave lists its occupied slots (ballot + mbcnt, 16-bit slot indices in its idle walk queue), turns the identities of
+					// the list into keys with every lane busy (two rounds instead of four) and leaves them in ident[]; the loop below then
+					// only moves slot i to the table.  No barrier: a wave reads and writes its own slots only.
+					// (Round 1 measured a compaction as "no change" when this kernel took 6.7 ms and waited on its LDS round trips; since the
+					// lean insert of round 5 it is three quarters VALU-busy and the emit was half of its instructions.)
+					static_assert(kBuildThreads / 64 * kWalkQ * 8 >= kBuildThreads / 64 * 256 * 2, "a wave's queue holds 256 slot indices");
+					uint16_t *const cq = reinterpret_cast<uint16_t *>(L.walkq[__builtin_amdgcn_readfirstlane((uint32_t)t >> 6)]);
+					uint32_t n_occ = 0; // wave-uniform
+					const uint32_t t0 = fresh_tid();
+#pragma unroll
+					for (uint32_t j = 0; j < (uint32_t)kRegionSlots / kBuildThreads; j++) {
+						const uint32_t i = t0 + j * kBuildThreads;
+						const bool occ = i < region_len && L.ident[i] != 0ull;
+						const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
+						if (occ) cq[n_occ + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+						n_occ += (uint32_t)__builtin_popcountll(m);
+					}
+					for (uint32_t e = t0 & 63u; e < n_occ; e += 64u) {
+						const uint32_t i = cq[e];
+						const uint64_t v = L.ident[i] - 1ull;
+						const uint64_t slot = ((uint64_t)b1 << G.r) | (v & ((1ull << G.r) - 1ull));
+						L.ident[i] = hash_code_inverse((v >> G.r) * G.size + slot); // (never 0: key 0 has no record)
+					}
+				}
 				for (uint32_t i = fresh_tid(); i < region_len; i += kBuildThreads) { // (opaque: the lane's table address is not worth a register across the inserts)
 					const unsigned long long id = L.ident[i];
 					uint64_t key = 0ull, links = 0ull;
+					if constexpr (FAST && !KF && !INCR && DBG == 0) { // ident[] holds the keys already
+						if (id) {
+							key = id;
+							links = L.links[i];
+							L.ident[i] = 0ull;
+							L.links[i] = 0ull;
+						}
+						*reinterpret_cast<uint4 *>(&table[region_base + i]) =
+						    make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)links, (uint32_t)(links >> 32));
+						continue;
+					}
 					const bool foreign = INCR && !KF && (id & kForeign);
 					if (id) {
 						const uint64_t v = id - 1ull;

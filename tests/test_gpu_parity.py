@@ -343,6 +343,46 @@ def test_partition_engine_streams_input_of_unknown_size(capi, oracle, store, exp
     assert np.array_equal(nodes, ref.nodes)
 
 
+@pytest.mark.parametrize("pieces", [2, 6, 40])
+@pytest.mark.parametrize("store_pieces", [0, 3])
+def test_early_level2_rounds_between_the_batches_equal_oracle(capi, oracle, monkeypatch, pieces, store_pieces):
+    """EARLY level 2 (dbgk.hip early_l2): every push first scatters what the batches before it left in the level-1 buckets.  The input
+    comes in 2 / 6 / 40 host batches with a round in front of every batch (DBGK_EARLY_L2_MIN=1), once with all records resident
+    and once through a store that holds three batches (flush rounds in between: the incremental build, the counters of taken
+    records reset with the store); mixed-length reads, poly-A, a heavy repeat.  Nodes, counts and host layout against the oracle;
+    the same input with the rounds switched off (DBGK_EARLY_L2=0) gives the same digest."""
+    rng = random.Random(1000 + pieces)
+    reads = rand_reads(rng, 9000, G=60000) + [b"A" * 150] * 200 + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 300
+    rng.shuffle(reads)
+    bases, offsets = oracle.pack_reads(reads)
+    ref = oracle.build_graph(files_mem=[(bases, offsets)], k=31, init_hash_size=0.001)
+    size = capi.find_next_prime_ref(PART_SLOTS)
+    n = len(reads)
+    per = (n + pieces - 1) // pieces
+    total = int(offsets[-1])
+    store = total if store_pieces == 0 else store_pieces * (total // pieces) + 4096
+    digests = []
+    for early in ("1", "0"):
+        monkeypatch.setenv("DBGK_EARLY_L2", early)
+        monkeypatch.setenv("DBGK_EARLY_L2_MIN", "1")
+        with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=store, max_batch_bases=1 << 20) as g:
+            for a in range(0, n, per):
+                b = min(n, a + per)
+                lo, hi = int(offsets[a]), int(offsets[b])
+                g.push_reads(bases[lo:hi], offsets[a:b + 1] - offsets[a])
+            st = g.finalize()
+            tm = g.timings()
+            nodes = g.export_sorted()
+            digests.append(g.digest())
+            array, flags = g.export_host_table()
+            assert oracle.check_host_table(array, flags, g.table_slots, st.count) == 0
+        assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
+        assert np.array_equal(nodes, ref.nodes)
+        if early == "1" and store_pieces == 0:
+            assert tm.partition_launches >= pieces, "no level-2 round ran between the batches"   # one per batch after the first + the last at finalize
+    assert digests[0] == digests[1] == oracle.nodes_digest(ref.nodes)
+
+
 def test_partition_engine_streaming_device_pushes_equal_one_shot(capi):
     """cfg2-shaped reads pushed from device memory in 8 pieces through a store that holds 3 of them:
     digest and counts equal the one-shot build (records of all pieces resident)."""
