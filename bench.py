@@ -595,7 +595,7 @@ def run_kfreq(args, ctx, brief=False):
         l1_ms, l2_ms, build_ms, wall_ms = tm.insert_ms / args.steps, tm.partition_ms / args.steps, tm.build_ms / args.steps, tm.l2_build_wall_ms / args.steps
         # k >= 13: the build's regions are 64-KiB blocks of the table itself (k_kf_build_blocks): it reads every record and writes the
         # whole table once, nothing zeroes or summarises the table separately
-        blocks = k >= 13 and not os.environ.get("DBGK_KFREQ_HASHED")
+        blocks = k >= 13 and not "kfreq_hashed=1" in os.environ.get("DBGK_TEST_HOOKS", "")
         bname = "k_kf_build_blocks" if blocks else "k_build_regions(KF)"
         own = {"k_extract_scatter_uniform": kmers_step * (base_bytes + (4.0 if blocks else 8.0)), "k_scatter_l2": kmers_step * (6.0 if blocks else 16.0),
                bname: kmers_step * (2.0 if blocks else 8.0) + (4.0 ** k if blocks else distinct * 1.0)}   # (blocks: 32-bit level-1 records, level 2 leaves 16-bit ones)
@@ -720,7 +720,7 @@ def run_graph(args, ctx, brief=False):
     size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
 
     g = capi.Graph(k=args.kmer, table_slots=size, max_read_len=250, device=dev_index, engine=args.engine,
-                   expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not os.environ.get("DBGK_WIDE_DIRECT")
+                   expected_kmers=n_reads * kpr if args.engine in (capi.ENGINE_PARTITION, capi.ENGINE_WIDE) and not "wide_direct=" in os.environ.get("DBGK_TEST_HOOKS", "")
                    else 0,  # exact for fixed-length reads; WIDE: records first, the table in one pass (dbgk_wide_partition.h)
                    shard_count=world if sharded else 0, shard_index=rank if sharded else 0,
                    n_passes=args.passes if wide_sharded else 0, max_batch_bases=int(os.environ.get("DBGK_BENCH_BATCH_BASES", "0")))

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "dbgk.h"
+#include "dbgk_env.h"
 #include "dbgk_kernels.h"
 #include "dbgk_partition.h"
 #include "dbgk_wide_kernels.h"
@@ -264,7 +265,7 @@ static inline uint64_t bitmap_words(uint64_t n_bases) { return (n_bases >> 5) + 
 // 512-thread builds that leave LDS for a workgroup of another kernel)
 static int l1_wgs_per_cu()
 {
-	static const int v = getenv("DBGK_L1_PER_CU") ? std::max(1, atoi(getenv("DBGK_L1_PER_CU"))) : 1024 / kL1Threads;
+	static const int v = DBGK_EXPERIMENT_ENV("DBGK_L1_PER_CU") ? std::max(1, atoi(DBGK_EXPERIMENT_ENV("DBGK_L1_PER_CU"))) : 1024 / kL1Threads;
 	return v;
 }
 
@@ -340,13 +341,12 @@ static void free_wide_partition(dbgk_handle *h)
 
 static void free_handle(dbgk_handle *h)
 {
-	for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum, (void *)h->pf_tot, (void *)h->pf_packed, (void *)h->uni_offsets})
-		if (q) (void)hipFree(q);
-
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	if (h->stream2) (void)hipStreamSynchronize(h->stream2); // region builds of an unfinished ranged finalize
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	for (void *q : {(void *)h->pf_ent, (void *)h->pf_tile_first, (void *)h->pf_tiles, (void *)h->pf_bsum, (void *)h->pf_tot, (void *)h->pf_packed, (void *)h->uni_offsets})
+		if (q) (void)hipFree(q);
 	for (void *p : h->d2h_stage)
 		if (p) (void)hipHostFree(p);
 	for (hipEvent_t e : h->d2h_ev)
@@ -442,7 +442,7 @@ static int clear_record_store(dbgk_handle *h, bool with_counters = false /* also
 static bool plan_wide_partition(dbgk_handle *h, bool *err)
 {
 	*err = false;
-	static const bool off = getenv("DBGK_WIDE_DIRECT") != nullptr; // always the atomic kernels
+	const bool off = dbgk_hook("wide_direct") != nullptr; // always the atomic kernels
 	const uint32_t n_ranks = h->cfg.shard_count > 1 ? h->cfg.shard_count : 1;
 	const bool want_shard = h->cfg.shard_count >= 1;
 	const uint32_t want_passes = (uint32_t)h->cfg.n_passes;
@@ -460,7 +460,7 @@ static bool plan_wide_partition(dbgk_handle *h, bool *err)
 	int qbits = 0;
 	while (qbits < 64 && (qmax >> qbits)) qbits++;
 	uint32_t r = 21;
-	if (const char *e = getenv("DBGK_WIDE_R")) r = (uint32_t)std::max(kWRegionBits + 1, std::min(22, atoi(e)));
+	if (const char *e = DBGK_EXPERIMENT_ENV("DBGK_WIDE_R")) r = (uint32_t)std::max(kWRegionBits + 1, std::min(22, atoi(e)));
 	if (!want_shard && want_passes <= 1)
 		while (r < 22u && ((h->size + (1ull << r) - 1) >> r) > 1024ull) r++; // one pass if the fan-out allows it
 	// passes: at least as many as keep the level-1 fan-out (ranks x buckets of a pass) within 1024
@@ -473,7 +473,7 @@ static bool plan_wide_partition(dbgk_handle *h, bool *err)
 	};
 	// every pass extracts the whole input again: beyond two passes the wider level-1 buckets of r = 22 (half the passes, level 2
 	// fanning out 2048 ways) are the better trade
-	if (!getenv("DBGK_WIDE_R") && r == 21u && passes_at(21u) > 2u && passes_at(22u) < passes_at(21u)) r = 22u;
+	if (!DBGK_EXPERIMENT_ENV("DBGK_WIDE_R") && r == 21u && passes_at(21u) > 2u && passes_at(22u) < passes_at(21u)) r = 22u;
 	while (r > (uint32_t)kWRegionBits + 1u && qbits + (int)r + 6 > 64) r--;
 	const uint64_t n1 = (h->size + (1ull << r) - 1) >> r;
 	if ((1u << (r - kWRegionBits)) > 2048u || qbits + (int)r + 6 > 64 || n1 >= 65536ull) return refuse("no feasible wide record geometry for this table size");
@@ -483,7 +483,14 @@ static bool plan_wide_partition(dbgk_handle *h, bool *err)
 	// Several passes are a PROTOCOL (begin_pass / push everything / end_pass, per pass): a caller who asked for neither shards nor
 	// passes (n_passes == 0, the plain create / push / finalize flow) never gets it -- a table whose fan-out one pass cannot cover
 	// is then built by the atomic kernels, as before the record path existed.  n_passes >= 1 says "I follow the protocol".
-	if (n_passes > 1 && !want_shard && want_passes == 0) return false;
+	if (n_passes > 1 && !want_shard && want_passes == 0) {
+		// (not an error -- the handle works -- but a large performance step: say so where a caller can find it, once on stderr too)
+		g_last_error = "WIDE handle: this table's level-1 fan-out needs several passes over the input and dbgk_config.n_passes is 0 -- "
+		               "built by the atomic kernels; set n_passes (dbgk_wide_pass_info) for the record path";
+		static std::atomic<bool> told{false};
+		if (!told.exchange(true)) fprintf(stderr, "dbgk: %s\n", g_last_error.c_str());
+		return false;
+	}
 	WPartGeom &G = h->wgeom;
 	memset(&G, 0, sizeof G);
 	G.size = h->size;
@@ -825,7 +832,7 @@ static int plan_partition(dbgk_handle *h)
 		if (want == DBGK_ENGINE_AUTO && h->cfg.expected_kmers == 0) return DBGK_OK; // streaming use: total unknown
 	}
 	uint32_t r = 22; // measured on cfg2 (round 2, profiles/r02_r_sweep.txt): r = 20 / 21 / 22 -> 17.3 / 16.5 / 16.3 ms per step
-	if (const char *e = getenv("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(24, atoi(e))); // tuning knob: level-1 bucket = slot >> r
+	if (const char *e = DBGK_EXPERIMENT_ENV("DBGK_PART_R")) r = (uint32_t)std::max(20, std::min(24, atoi(e))); // tuning knob: level-1 bucket = slot >> r
 	while (((h->size + (1ull << r) - 1) >> r) > (uint64_t)kL1MaxB) r++;
 	const uint64_t qmax = ~0ull / h->size;
 	int qbits = 0;
@@ -881,7 +888,7 @@ static int plan_partition(dbgk_handle *h)
 	h->tslots = G.slot_hi - G.slot_lo;
 	h->sharded = want_shard;
 	h->part = true;
-	static const bool no_three = getenv("DBGK_THREE_LEVEL") && atoi(getenv("DBGK_THREE_LEVEL")) == 0; // measurements
+	static const bool no_three = DBGK_EXPERIMENT_ENV("DBGK_THREE_LEVEL") && atoi(DBGK_EXPERIMENT_ENV("DBGK_THREE_LEVEL")) == 0; // measurements
 	// measured with cfg2's 1.2 G records, level 2 alone: n2 = 4096 (8.6 G slots) 17.6 ms in one pass, 9.7 ms in two;
 	// n2 = 2048 (5 G slots) 6.9 ms in one pass, 9.5 in two -- so only the 4096-way fan-out is split
 	h->three = G.n2 > 2048u && !no_three;
@@ -949,7 +956,7 @@ static int setup_partition(dbgk_handle *h)
 	P.inbox_cnt = h->sharded ? h->inbox_cnt : P.cnt1;
 	// EARLY level 2 (early_l2): a handle that extracts into its own inbox scatters what earlier batches stored while the next
 	// batch is on the link.  Not for shards (their inbox is filled by the exchange), the three-level form, 32-bit KFREQ records
-	const bool no_early = getenv("DBGK_EARLY_L2") && atoi(getenv("DBGK_EARLY_L2")) == 0; // (read per handle: measurements, and the tests compare the two)
+	const bool no_early = dbgk_hook("early_l2") && atoi(dbgk_hook("early_l2")) == 0; // (read per handle: measurements, and the tests compare the two)
 	P.l2_done = P.l2_upto = nullptr;
 	if (!h->sharded && !h->three && G.kf != 2u && !no_early) {
 		if (hipMalloc(&h->l2_done, 2 * n_entries * 4) != hipSuccess) return DBGK_ERR_NOMEM; // done[] and upto[]
@@ -982,9 +989,17 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter<true, 0, W>), sizeof(ScatterLds));              \
 	DBGK_LDS_ATTR((k_extract_scatter<false, 0, W>), sizeof(ScatterLds))
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<1, 0, 15, false>), sizeof(UniformLds)); // timing experiments (DBGK_DEBUG_MODE)
+#ifdef DBGK_EXPERIMENTS // timing experiments (DBGK_DEBUG_MODE, results are wrong): not in the product library
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<1, 0, 15, false>), sizeof(UniformLds));
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<2, 0, 15, false>), sizeof(UniformLds));
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<3, 0, 15, false>), sizeof(UniformLds));
+	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_extract_scatter<false, 3>), sizeof(ScatterLds));
+	DBGK_LDS_ATTR((k_scatter_l2<1>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<2>), sizeof(ScatterLdsL2));
+	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
+#endif
 	DBGK_UNIFORM_ATTRS(0);
 	DBGK_UNIFORM_ATTRS(1);
 	DBGK_UNIFORM_ATTRS(2);
@@ -1003,13 +1018,7 @@ static int setup_partition(dbgk_handle *h)
 #undef DBGK_LIN_ATTRS
 #undef DBGK_LIN_ATTRS_U
 #undef DBGK_UNIFORM_ATTRS
-	DBGK_LDS_ATTR((k_extract_scatter<false, 1>), sizeof(ScatterLds));
-	DBGK_LDS_ATTR((k_extract_scatter<false, 2>), sizeof(ScatterLds));
-	DBGK_LDS_ATTR((k_extract_scatter<false, 3>), sizeof(ScatterLds));
 	DBGK_LDS_ATTR((k_scatter_l2<0>), sizeof(ScatterLdsL2));
-	DBGK_LDS_ATTR((k_scatter_l2<1>), sizeof(ScatterLdsL2));
-	DBGK_LDS_ATTR((k_scatter_l2<2>), sizeof(ScatterLdsL2));
-	DBGK_LDS_ATTR((k_scatter_l2<3>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<0, kMaxBuckets, true>), sizeof(ScatterLdsL2));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 2048>), sizeof(ScatterLdsL2T<2048>));
 	DBGK_LDS_ATTR((k_scatter_l2<0, 4096>), sizeof(ScatterLdsL2T<4096>));
@@ -1018,8 +1027,10 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_BUILD_ATTR(0, false, false, true);  DBGK_BUILD_ATTR(0, true, false, true);  DBGK_BUILD_ATTR(0, false, true, true);  DBGK_BUILD_ATTR(0, true, true, true);
 	DBGK_BUILD_ATTR(0, false, false, false, true); DBGK_BUILD_ATTR(0, true, false, false, true); DBGK_BUILD_ATTR(0, false, true, false, true);
 	DBGK_BUILD_ATTR(0, true, true, false, true);
+#ifdef DBGK_EXPERIMENTS
 	DBGK_BUILD_ATTR(1, false, false, false); DBGK_BUILD_ATTR(2, false, false, false); DBGK_BUILD_ATTR(3, false, false, false);
 	DBGK_BUILD_ATTR(1, false, false, true);  DBGK_BUILD_ATTR(2, false, false, true);  DBGK_BUILD_ATTR(3, false, false, true);
+#endif
 #undef DBGK_BUILD_ATTR
 	DBGK_LDS_ATTR((k_kf_build_blocks<false, true>), sizeof(KfBlockLds));
 	DBGK_LDS_ATTR((k_kf_build_blocks<true, true>), sizeof(KfBlockLds));
@@ -1076,11 +1087,11 @@ extern "C" int dbgk_create(const dbgk_config *cfg, dbgk_handle **out)
 	// hash_code(key) % size like graph records and aggregated per key in LDS; `size` is only the modulus
 	// (no node table exists), chosen so that the LDS regions stay about half empty even if every second
 	// occurrence were a new key.  Without expected_kmers: direct atomics on the byte table.
-	static const bool kf_direct = getenv("DBGK_KFREQ_DIRECT") != nullptr;
+	static const bool kf_direct = DBGK_EXPERIMENT_ENV("DBGK_KFREQ_DIRECT") != nullptr;
 	const bool kf_part = kfreq && cfg->expected_kmers > 0 && cfg->shard_count == 0 && !kf_direct;
 	// k >= 13 (a table of 2^26 bytes and more): the direct-block form -- regions ARE 64-KiB blocks of the table
 	// (dbgk_partition.h, kf_slot_of_key); smaller k (or DBGK_KFREQ_HASHED=1, measurements): the hashed form
-	static const bool kf_hashed = getenv("DBGK_KFREQ_HASHED") && atoi(getenv("DBGK_KFREQ_HASHED"));
+	const bool kf_hashed = dbgk_hook("kfreq_hashed") && atoi(dbgk_hook("kfreq_hashed"));
 	h->kf_blocks = kf_part && cfg->kmer_size >= 13 && !kf_hashed;
 	if (h->kf_blocks) {
 		h->size = 1ull << (2 * cfg->kmer_size);
@@ -1370,8 +1381,8 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
                         UniformGeom &U, bool &c15, bool &lin, bool &lin12)
 {
 	lin = lin12 = false;
-	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
-	static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
+	static const bool off = DBGK_EXPERIMENT_ENV("DBGK_L1_FLAT") != nullptr; // force the general kernel
+	static const int dbg_mode = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE")) : 0;
 	if (off || has_long || n_reads == 0) return 0;
 	if (dbg_mode && (uniform_len != 150 || h->cfg.kmer_size != 31 || h->geom.size >= (1ull << 31))) return 0; // debug builds: cfg2's shape only
 	const uint64_t L = uniform_len > 0 ? (uint64_t)uniform_len : len_max, k = (uint64_t)h->cfg.kmer_size;
@@ -1405,11 +1416,11 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	// form, 12 (or 8) windows per lane.  Measured on cfg2's reads, level 1 in ms, wave-per-bucket / linear with 8 / with 12
 	// windows: n1 = 143: 5.57 / 6.76 / 6.05, 573: 8.13 / 7.57 / 6.81, 1023: 10.61 / 7.76 / 6.99 (287: 6.34 / 6.77 / -).
 	// DBGK_L1_LINEAR=0/1 forces the choice.
-	const int force = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1; // (read per batch: tests switch it)
+	const int force = dbgk_hook("l1_linear") ? atoi(dbgk_hook("l1_linear")) : -1; // (read per batch: tests switch it)
 	// 12 or 8 windows per lane, whichever leaves fewer empty slots at the end of a read (W = 120: both none -> 12)
 	const uint64_t q12 = (W + 11u) / 12u, q8 = (W + 7u) / 8u;
 	lin12 = q12 * 12u - W <= q8 * 8u - W;
-	if (const char *e = getenv("DBGK_L1_LINEAR_C")) lin12 = atoi(e) == 12; // measurements
+	if (const char *e = DBGK_EXPERIMENT_ENV("DBGK_L1_LINEAR_C")) lin12 = atoi(e) == 12; // measurements
 	const uint64_t QL = lin12 ? q12 : q8, CL = lin12 ? 12 : 8;
 	bool fits = QL < 2048 && n_reads * QL < (1ull << 32) && ((uint64_t)kL1Threads / QL + 2) * L + 96 <= (uint64_t)kPkWords * 16;
 	if (mode == 2) fits = fits && (double)(n_reads * QL * CL) <= 0.93 * (double)n_bases;
@@ -1426,7 +1437,7 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 // WIDE record path: can this batch take the equal-length level-1 kernel (k_wide_scatter_l1_uniform)?
 static int wide_uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t n_reads, uint64_t n_bases, int has_long, WUniformGeom &U)
 {
-	static const bool off = getenv("DBGK_L1_FLAT") != nullptr; // force the general kernel
+	static const bool off = DBGK_EXPERIMENT_ENV("DBGK_L1_FLAT") != nullptr; // force the general kernel
 	if (off || has_long || n_reads == 0 || uniform_len <= 0) return 0;
 	const uint64_t L = (uint64_t)uniform_len, k = (uint64_t)h->cfg.kmer_size;
 	if (L > (uint64_t)h->cfg.max_read_len || L < k || L >= (1ull << 24) || n_bases != n_reads * L) return 0;
@@ -1536,12 +1547,12 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	// trimmed ones included) takes what would otherwise go through the flat kernel -- a fifth of whose positions straddle a
 	// read boundary at 150 bases and k = 31 -- and the batches of the ragged form as well; not with many level-1 buckets (the
 	// linear forms), not for reads of more than 4 M windows.  DBGK_L1_PREFIX=0 switches it off (ragged / flat as before).
-	const int prefix_env = getenv("DBGK_L1_PREFIX") ? atoi(getenv("DBGK_L1_PREFIX")) : -1; // (read per batch: tests switch it)
+	const int prefix_env = dbgk_hook("l1_prefix") ? atoi(dbgk_hook("l1_prefix")) : -1; // (read per batch: tests switch it)
 	bool use_prefix = false;
 	auto prefix_wanted = [&](int um) {
-		static const bool flat_only = getenv("DBGK_L1_FLAT") != nullptr;
-		static const bool dbg = getenv("DBGK_DEBUG_MODE") != nullptr;
-		const int force_lin = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
+		static const bool flat_only = DBGK_EXPERIMENT_ENV("DBGK_L1_FLAT") != nullptr;
+		static const bool dbg = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") != nullptr;
+		const int force_lin = dbgk_hook("l1_linear") ? atoi(dbgk_hook("l1_linear")) : -1;
 		if (!h->part || h->seed || wrec || flat_only || dbg || prefix_env == 0) return false;
 		if (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u)) return false;
 		if (len_max > (uint64_t)kPrefixMaxW || n_bases / 15 + n_reads >= (1ull << 32)) return false;
@@ -1684,8 +1695,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 #define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-		static const int dbg_mode_u = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
-		static const bool no_reg = getenv("DBGK_L1_NO_REG") != nullptr; // A/B: the general form everywhere
+		static const int dbg_mode_u = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE")) : 0;
+		static const bool no_reg = DBGK_EXPERIMENT_ENV("DBGK_L1_NO_REG") != nullptr; // A/B: the general form everywhere
 		bool rest_only = false;
 		if (!dbg_mode_u && !no_reg && umode == 1 && !lin8 && U.tile_blocks) {
 			// regular tiles: kL1Threads / Q whole reads each, from a 16-byte boundary; the reads behind the last whole tile
@@ -1717,12 +1728,15 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		const uint64_t n_tiles_rest = (U.n_lanes + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(std::max<uint64_t>(n_tiles_rest, 1), (uint64_t)h->n_cu * l1_wgs_per_cu());
 		if (rest_only) {
-		} else if (dbg_mode_u == 1)   // timing experiments on cfg2's shape (C = 15, equal lengths, size < 2^31): results are wrong
+		}
+#ifdef DBGK_EXPERIMENTS
+		else if (dbg_mode_u == 1)   // timing experiments on cfg2's shape (C = 15, equal lengths, size < 2^31): results are wrong
 			hipLaunchKernelGGL((k_extract_scatter_uniform<1, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode_u == 2)
 			hipLaunchKernelGGL((k_extract_scatter_uniform<2, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode_u == 3)
 			hipLaunchKernelGGL((k_extract_scatter_uniform<3, 0, 15, false>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);
+#endif
 		else if (lin8 && lin12 && ragged) {
 			if (wide == 2) DBGK_LAUNCH_UNIFORM8(2, 12, true); else if (wide == 1) DBGK_LAUNCH_UNIFORM8(1, 12, true); else DBGK_LAUNCH_UNIFORM8(0, 12, true);
 		} else if (lin8 && lin12) {
@@ -1742,9 +1756,9 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;
 		const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu()); // 140 KiB of LDS: one workgroup per CU
-		static const int dbg_mode = getenv("DBGK_DEBUG_MODE") ? atoi(getenv("DBGK_DEBUG_MODE")) : 0;
+		static const int dbg_mode = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE")) : 0;
 		const int wide_d = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
-		const int force_lin = getenv("DBGK_L1_LINEAR") ? atoi(getenv("DBGK_L1_LINEAR")) : -1;
+		const int force_lin = dbgk_hook("l1_linear") ? atoi(dbgk_hook("l1_linear")) : -1;
 		if (!dbg_mode && (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u))) { // many level-1 buckets: the linear form
 #define DBGK_LAUNCH_FLAT_LIN(DEAD, WD)                                                                                                       \
 	hipLaunchKernelGGL((k_extract_scatter_lin<DEAD, WD>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLdsLin<8>), h->stream, rb, h->geom, h->store, \
@@ -1763,12 +1777,14 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 			hipLaunchKernelGGL((k_extract_scatter<true, 0, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (wide_d)
 			hipLaunchKernelGGL((k_extract_scatter<false, 0, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+#ifdef DBGK_EXPERIMENTS
 		else if (dbg_mode == 1)
 			hipLaunchKernelGGL((k_extract_scatter<false, 1>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode == 2)
 			hipLaunchKernelGGL((k_extract_scatter<false, 2>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else if (dbg_mode == 3)
 			hipLaunchKernelGGL((k_extract_scatter<false, 3>), dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
+#endif
 		else if (has_long)
 			hipLaunchKernelGGL(k_extract_scatter<true>, dim3(grid), dim3(kL1Threads), sizeof(ScatterLds), h->stream, rb, h->geom, h->store, h->d_ctr);
 		else
@@ -1820,7 +1836,7 @@ static void staged_copy(char *dst, const char *src, size_t n, std::vector<std::t
 // bounds the pageable path (~30 GB/s against the link's 57), does not happen.
 static bool device_readable_host(const char *p, size_t n)
 {
-	static const bool off = getenv("DBGK_NO_PINNED_SOURCE") && atoi(getenv("DBGK_NO_PINNED_SOURCE"));
+	static const bool off = DBGK_EXPERIMENT_ENV("DBGK_NO_PINNED_SOURCE") && atoi(DBGK_EXPERIMENT_ENV("DBGK_NO_PINNED_SOURCE"));
 	if (off || !p || !n) return false;
 	void *dev[2] = {nullptr, nullptr};
 	int i = 0;
@@ -1859,7 +1875,7 @@ static int ensure_slot(dbgk_handle *h, StageSlot &s)
 // first batch) instead of queueing behind them.  The slot's device buffers are free: the caller has waited for s.done.
 static int h2d_batch(dbgk_handle *h, StageSlot &s, const char *src, uint64_t nb, uint64_t n_offsets, bool last_of_pinned_source)
 {
-	static const bool serial = getenv("DBGK_COPY_ON_COMPUTE_STREAM") && atoi(getenv("DBGK_COPY_ON_COMPUTE_STREAM")); // measurements
+	static const bool serial = DBGK_EXPERIMENT_ENV("DBGK_COPY_ON_COMPUTE_STREAM") && atoi(DBGK_EXPERIMENT_ENV("DBGK_COPY_ON_COMPUTE_STREAM")); // measurements
 	if (!serial && !h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 	hipStream_t cs = serial ? h->stream : h->copy_stream;
 	if (nb) HIPCHK(hipMemcpyAsync(s.d_bases, src, nb, hipMemcpyHostToDevice, cs));
@@ -2485,14 +2501,14 @@ static RedoList redo_list(dbgk_handle *h)
 // left to the exact pass) unless DBGK_BUILD_EXACT=1 asks for the saturating CAS loops everywhere
 static bool build_fast()
 {
-	static const bool exact = getenv("DBGK_BUILD_EXACT") && atoi(getenv("DBGK_BUILD_EXACT")) != 0;
+	const bool exact = dbgk_hook("build_exact") && atoi(dbgk_hook("build_exact")) != 0;
 	return !exact;
 }
 
 template <int DBG>
 static void launch_build(dbgk_handle *h, hipStream_t stream, uint32_t first_region, uint32_t n_regions, unsigned int *cursor)
 {
-	static const int per_cu = getenv("DBGK_BUILD_PER_CU") ? std::max(1, atoi(getenv("DBGK_BUILD_PER_CU"))) : 2; // tuning knob
+	static const int per_cu = DBGK_EXPERIMENT_ENV("DBGK_BUILD_PER_CU") ? std::max(1, atoi(DBGK_EXPERIMENT_ENV("DBGK_BUILD_PER_CU"))) : 2; // tuning knob
 	const uint32_t grid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * (uint32_t)per_cu); // persistent: two 66-KiB workgroups fit a CU
 	const RedoList redo = redo_list(h);
 	if (h->geom.kf == 2u) { // KFREQ, direct blocks
@@ -2567,11 +2583,11 @@ constexpr uint64_t kEarlyL2Min = 8ull << 20;
 static int early_l2(dbgk_handle *h)
 {
 	if (!h->part || !h->l2_done || h->part_planned || h->part_built) return DBGK_OK;
-	const char *e_min = getenv("DBGK_EARLY_L2_MIN"); // (read per call: the tests ask for a round after every small batch)
+	const char *e_min = dbgk_hook("early_l2_min"); // (read per call: the tests ask for a round after every small batch)
 	const uint64_t min_kmers = e_min ? strtoull(e_min, nullptr, 10) : kEarlyL2Min;
 	if (h->pending_kmers < h->l2_seen_kmers + std::max<uint64_t>(min_kmers, 1)) return DBGK_OK;
 	const PartGeom &G = h->geom;
-	static const int l2_grid_env = getenv("DBGK_L2_GRID") ? atoi(getenv("DBGK_L2_GRID")) : 0;
+	static const int l2_grid_env = DBGK_EXPERIMENT_ENV("DBGK_L2_GRID") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_L2_GRID")) : 0;
 	const int l2_grid = l2_grid_env >= 8 ? (l2_grid_env & ~7) : h->n_cu;
 	TimedSpan sp;
 	int rc = span_begin(h, PH_PARTITION, sp);
@@ -2604,19 +2620,21 @@ static int part_plan(dbgk_handle *h)
 static int part_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1, bool two_streams)
 {
 	const PartGeom &G = h->geom;
-	static const int l2_grid_env = getenv("DBGK_L2_GRID") ? atoi(getenv("DBGK_L2_GRID")) : 0; // tuning knob: level-2 workgroups (multiple of 8)
+	static const int l2_grid_env = DBGK_EXPERIMENT_ENV("DBGK_L2_GRID") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_L2_GRID")) : 0; // tuning knob: level-2 workgroups (multiple of 8)
 	const int l2_grid = l2_grid_env >= 8 ? (l2_grid_env & ~7) : h->n_cu;
-	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;       // timing experiments, results are wrong
-	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
+	static const int dbg_l2 = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_L2") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_L2")) : 0;       // timing experiments, results are wrong
+	static const int dbg_build = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_BUILD") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_BUILD")) : 0;
 	if (j0 >= j1) return DBGK_OK;
 	hipStream_t bstream = two_streams ? h->stream2 : h->stream;
 	TimedSpan sp;
 	int rc = span_begin(h, PH_PARTITION, sp);
 	if (rc) return rc;
 	switch (dbg_l2) {
+#ifdef DBGK_EXPERIMENTS
 		case 1: launch_l2<1>(h, l2_grid, j0, j1); break;
 		case 2: launch_l2<2>(h, l2_grid, j0, j1); break;
 		case 3: launch_l2<3>(h, l2_grid, j0, j1); break;
+#endif
 		default: launch_l2<0>(h, l2_grid, j0, j1); break;
 	}
 	HIPCHK(hipGetLastError());
@@ -2644,9 +2662,11 @@ static int part_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1, bool two_s
 	}
 	unsigned int *cursor = h->region_cursor + h->cursors_used++;
 	switch (dbg_build) {
+#ifdef DBGK_EXPERIMENTS
 		case 1: launch_build<1>(h, bstream, r0, r1 - r0, cursor); break;
 		case 2: launch_build<2>(h, bstream, r0, r1 - r0, cursor); break;
 		case 3: launch_build<3>(h, bstream, r0, r1 - r0, cursor); break;
+#endif
 		default: launch_build<0>(h, bstream, r0, r1 - r0, cursor); break;
 	}
 	HIPCHK(hipGetLastError());
@@ -2660,13 +2680,13 @@ static int part_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1, bool two_s
 static int build_from_records(dbgk_handle *h)
 {
 	const PartGeom &G = h->geom;
-	static const int dbg_l2 = getenv("DBGK_DEBUG_L2") ? atoi(getenv("DBGK_DEBUG_L2")) : 0;
-	static const int dbg_build = getenv("DBGK_DEBUG_BUILD") ? atoi(getenv("DBGK_DEBUG_BUILD")) : 0;
+	static const int dbg_l2 = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_L2") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_L2")) : 0;
+	static const int dbg_build = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_BUILD") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_BUILD")) : 0;
 	// 1 = level 2, then the build.  Round 5: with the leaner build and 16-byte record loads either kernel alone runs close to what the
 	// memory system gives this traffic (4.1 + 3.7 ms for 2 x 19.2 GB), side by side they only share it: 1 / 2 / 3 / 4 / 6 / 12 chunk pairs ->
 	// 12.86-12.92 / 12.86 / 13.00 / 13.03 / 13.07 / 13.06-13.24 ms per cfg2 step (profiles/r05_build_lean_walk_and_chunks_ab.txt; rounds 2-4: 12)
-	static const int want_chunks = getenv("DBGK_OVERLAP_CHUNKS") ? atoi(getenv("DBGK_OVERLAP_CHUNKS")) : 1;
-	uint32_t n_chunks = (dbg_l2 || dbg_build || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
+	static const int want_chunks = DBGK_EXPERIMENT_ENV("DBGK_OVERLAP_CHUNKS") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_OVERLAP_CHUNKS")) : 1;
+	uint32_t n_chunks = ((dbg_l2 | dbg_build) != 0 || want_chunks < 1) ? 1u : (uint32_t)want_chunks;
 	int rc = part_plan(h);
 	if (rc) return rc;
 	// whatever the caller has not built by ranges yet (dbgk_shard_build_range): all of it, normally
@@ -2686,7 +2706,7 @@ static int build_from_records(dbgk_handle *h)
 	rc = span_end(h, h->wall_span);
 	if (rc) return rc;
 	h->part_planned = false;
-	if (dbg_l2 || dbg_build) {
+	if ((dbg_l2 | dbg_build) != 0) {
 		g_last_error = "DBGK_DEBUG_L2 / DBGK_DEBUG_BUILD set: timing experiment, no valid table was built";
 		return DBGK_ERR_STATE;
 	}
@@ -2839,7 +2859,7 @@ static int d2h_pipelined(dbgk_handle *h, void *dst, const void *d_src, size_t by
 	constexpr size_t kSlice = 32ull << 20;
 	constexpr int kBuffers = 8;
 	static const int n_threads = getenv("DBGK_EXPORT_THREADS") ? std::max(1, atoi(getenv("DBGK_EXPORT_THREADS"))) : 6;
-	if (bytes < 8 * kSlice || getenv("DBGK_EXPORT_PLAIN")) {
+	if (bytes < 8 * kSlice || DBGK_EXPERIMENT_ENV("DBGK_EXPORT_PLAIN")) {
 		HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
 		HIPCHK(hipStreamSynchronize(h->stream));
 		return DBGK_OK;
@@ -3043,7 +3063,7 @@ static int d2h_compact(dbgk_handle *h, dbgk_node *array, uint8_t *nul_flag, cons
 				left--;
 			}
 	};
-	if (getenv("DBGK_EXPORT_PROBE")) { // (measurements) the link alone: the same copies with nobody reading the buffers
+	if (DBGK_EXPERIMENT_ENV("DBGK_EXPORT_PROBE")) { // (measurements) the link alone: the same copies with nobody reading the buffers
 		const double t0 = clock_s();
 		for (size_t i = 0; i < n_slices; i++) {
 			const uint64_t r0 = (uint64_t)i * per, r1 = std::min(n_occ, r0 + per);
@@ -3313,11 +3333,11 @@ static int export_host_table_impl(dbgk_handle *h, uint64_t host_size, dbgk_node 
 	if (lap_wanted && e == hipSuccess) e = hipStreamSynchronize(h->stream);
 	const double t_a = clock_s();
 	// large tables: the occupied nodes only (DBGK_EXPORT_FULL=1: every slot over the link, as before round 4)
-	const bool full_copy = getenv("DBGK_EXPORT_FULL") != nullptr; // (read at every call: the tests compare the two)
+	const bool full_copy = dbgk_hook("export_full") != nullptr; // (read at every call: the tests compare the two)
 	bool bits_copied = false;
 	if (e == hipSuccess) {
 		copy_rc = DBGK_ERR_STATE;
-		if (!full_copy && host_size * sizeof(Node) >= (getenv("DBGK_EXPORT_COMPACT_MIN") ? strtoull(getenv("DBGK_EXPORT_COMPACT_MIN"), nullptr, 10) : (256ull << 20))) copy_rc = d2h_compact(h, array, nul_flag, T, d_flags, h->h_ctr->n_new + 1);
+		if (!full_copy && host_size * sizeof(Node) >= (dbgk_hook("export_compact_min") ? strtoull(dbgk_hook("export_compact_min"), nullptr, 10) : (256ull << 20))) copy_rc = d2h_compact(h, array, nul_flag, T, d_flags, h->h_ctr->n_new + 1);
 		bits_copied = copy_rc == DBGK_OK;
 		if (copy_rc == DBGK_ERR_STATE) copy_rc = d2h_pipelined(h, array, T.nodes, host_size * sizeof(Node));
 	}

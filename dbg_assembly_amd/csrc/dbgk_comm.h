@@ -710,7 +710,7 @@ static int comm_push_impl(dbgk_comm *c, const char *bases, const uint32_t *packe
 	// A large batch is cut into one piece per member and the pieces are handed over by as many host threads at once (each member
 	// has its own pinned staging buffers, stream and PCIe link): one thread copying batch after batch tops out near 30 GB/s whatever
 	// the number of GPUs.  Small batches go to one member, round robin.
-	static const bool serial = getenv("DBGK_COMM_SERIAL_PUSH") != nullptr;
+	static const bool serial = DBGK_EXPERIMENT_ENV("DBGK_COMM_SERIAL_PUSH") != nullptr;
 	const uint64_t bytes = offsets[n_reads] - offsets[0];
 	if (!serial && n > 1 && n_reads >= 4ull * n && bytes >= (8ull << 20)) {
 		uint64_t worst = 0;
@@ -784,7 +784,7 @@ static int comm_kfreq_finalize(dbgk_comm *c)
 		c->kf_distinct = c->h[0]->kf_distinct;
 		return DBGK_OK;
 	}
-	const uint64_t kStage = getenv("DBGK_COMM_KFREQ_STAGE_MB") ? (uint64_t)std::max(1, atoi(getenv("DBGK_COMM_KFREQ_STAGE_MB"))) << 20 : 256ull << 20;
+	const uint64_t kStage = dbgk_hook("comm_kfreq_stage_mb") ? (uint64_t)std::max(1, atoi(dbgk_hook("comm_kfreq_stage_mb"))) << 20 : 256ull << 20;
 	struct Owner {
 		uint8_t *stage[2] = {nullptr, nullptr};
 		hipEvent_t arrived[2] = {nullptr, nullptr}, merged[2] = {nullptr, nullptr};

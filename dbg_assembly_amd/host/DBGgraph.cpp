@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "dbgk.h"
+#include "dbgk_env.h"
 #include "reads_io.h"
 
 // ---- the reference's globals (DBGgraph.cpp:10-34), same names and defaults -------------------
@@ -190,13 +191,13 @@ void ensure_created(Session &S)
 
 void start_early_table(Session &S, uint64_t size)
 {
-	static const bool off = getenv("DBGK_NO_EARLY_TABLE") != nullptr;
-	const size_t min_bytes = getenv("DBGK_EARLY_TABLE_MIN") ? (size_t)strtoull(getenv("DBGK_EARLY_TABLE_MIN"), NULL, 10) : ((size_t)64 << 20); // (tests: 0)
+	static const bool off = DBGK_EXPERIMENT_ENV("DBGK_NO_EARLY_TABLE") != nullptr;
+	const size_t min_bytes = dbgk_hook("early_table_min") ? (size_t)strtoull(dbgk_hook("early_table_min"), NULL, 10) : ((size_t)64 << 20); // (tests: 0)
 	if (off || size * sizeof(KmerNode) < min_bytes) return;
 	S.early_array = static_cast<KmerNode *>(kmerset_alloc(size * sizeof(KmerNode), false));
 	if (!S.early_array) return;
 	S.early_size = size;
-	const int T = getenv("DBGK_EARLY_THREADS") ? std::max(1, atoi(getenv("DBGK_EARLY_THREADS"))) : 4;
+	const int T = dbgk_hook("early_threads") ? std::max(1, atoi(dbgk_hook("early_threads"))) : 4;
 	const size_t bytes = size * sizeof(KmerNode), per = ((bytes / (size_t)T) + 4095) & ~(size_t)4095;
 	const double t0 = now_s();
 	for (int t = 0; t < T; t++)
@@ -503,10 +504,10 @@ void parse_one_reads_file(string &reads_file)
 	S.stop_file = false;
 	S.reads_in_block = 0;
 	ChunkedReadsFile chunked;
-	static const bool sequential = getenv("DBGK_PARSE_SEQUENTIAL") != nullptr;
+	const bool sequential = dbgk_hook("parse_sequential") != nullptr;
 	if (const char *pt = getenv("DBGK_PARSE_THREADS")) S.parse_threads = std::max(1, atoi(pt));
 	if (!sequential && chunked.open(reads_file)) { // a plain file: windows read, lines found and bytes copied by several threads
-		static const bool per_record = getenv("DBGK_PARSE_PER_RECORD") != nullptr; // (measurements: the record rules and the bookkeeping read by read on the calling thread)
+		static const bool per_record = DBGK_EXPERIMENT_ENV("DBGK_PARSE_PER_RECORD") != nullptr; // (measurements: the record rules and the bookkeeping read by read on the calling thread)
 		const bool ok = per_record ? chunked.for_each_read(Input_file_format, S.parse_threads, [&](const char *seq, size_t len) {
 			if (chunked.too_long) { S.stop_file = true; return; } // (a 4 GiB line is no read)
 			note_read(S, seq, len);
@@ -516,6 +517,7 @@ void parse_one_reads_file(string &reads_file)
 			note_reads(S, recs, n);
 		}, [&]() { materialize_noted(S); }, &S.stop_file);
 		if (!ok) cerr << "fail to read reads file " << reads_file << endl;
+		if (chunked.too_long) cerr << "Alert: a sequence line of 4 GiB or more in " << reads_file << ": the rest of this file is not read" << endl;
 		if (getenv("DBGK_TIMINGS"))
 			cerr << "Reader (s, calling thread): first window " << chunked.spent[0] << " records -> batches " << chunked.spent[1] << " copy/pack + hand-over "
 			     << chunked.spent[2] << " waiting for the next window " << chunked.spent[3] << " (" << S.parse_threads << " threads); of all that, packing / copying the reads into the batches " << S.t_pack << endl;
@@ -622,7 +624,7 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 	cfg.table_slots = initial_size;
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
 	const uint64_t bound = input_size_bound(reads_files);
-	const bool records = bound > 0 && initial_size >= kPartitionMinSlots && initial_size <= kPartitionMaxSlots && !getenv("DBGK_WIDE_DIRECT");
+	const bool records = bound > 0 && initial_size >= kPartitionMinSlots && initial_size <= kPartitionMaxSlots && !dbgk_hook("wide_direct");
 	cfg.expected_kmers = records ? bound : 0; // unknown input size (compressed files): fused extract + atomic insert
 	if (records) cfg.n_passes = 1; // this caller follows the pass protocol: as many passes over the input files as the geometry needs
 	if (records && getenv("DBGK_WIDE_PASSES")) cfg.n_passes = (uint64_t)std::max(1, atoi(getenv("DBGK_WIDE_PASSES"))); // more passes than the geometry needs (small devices, tests)
@@ -647,7 +649,7 @@ static void build_debruijn_graph_wide(vector<string> &reads_files, Session *S, u
 		rc = dbgk_create(&cfg, &S->h);
 		if (rc != DBGK_OK) fail(*S, rc, "dbgk_create");
 		else if (dbgk_wide_pass_info(S->h, &n_passes, NULL) != DBGK_OK) n_passes = 1;
-		S->zero_copy = rc == DBGK_OK && !getenv("DBGK_NO_ZERO_COPY");
+		S->zero_copy = rc == DBGK_OK && !dbgk_hook("no_zero_copy");
 	}
 	S->t_create = double(clock() - time_start) / CLOCKS_PER_SEC;
 	cerr << "Hash initialization array size:  " << initHashSize << " G" << endl;
@@ -752,7 +754,6 @@ void build_debruijn_graph(vector<string> &reads_files)
 	S->offsets.assign(1, 0);
 	S->ref_size = initial_size;
 	S->ref_max = (uint64_t)((float)initial_size * clamped_load_factor());   // kmerSet.cpp:114
-	if (const char *mb = getenv("DBGK_BATCH_MB")) S->batch_limit = std::max<uint64_t>(1, strtoull(mb, NULL, 10)) << 20;
 	if (const char *bb = getenv("DBGK_BATCH_BYTES")) S->batch_limit = std::max<uint64_t>(1024, strtoull(bb, NULL, 10)); // tests: many small batches
 	S->bases.reserve(S->batch_limit + (1u << 16));
 	S->packed = !getenv("DBGK_HOST_ASCII");
@@ -789,7 +790,6 @@ void build_debruijn_graph(vector<string> &reads_files)
 		cfg.expected_kmers = std::max<uint64_t>(store, 1024);
 	}
 	if (S->ref_layout) cfg.flags |= DBGK_FLAG_TRACK_FIRST_SEEN;
-	cfg.flags |= DBGK_FLAG_PREALLOC_STAGING; // page-locking the staging buffers happens on the creating thread, beside the first file read
 	cfg.max_batch_bases = S->batch_limit + (1u << 16);
 	// several GPUs: DBGK_GPUS=N (devices 0..N-1) or DBGK_GPU_LIST=a,b,c (ordinals, repeats allowed)
 	std::vector<int32_t> devices;
@@ -817,14 +817,17 @@ void build_debruijn_graph(vector<string> &reads_files)
 		// the handle (device table, record stores, streams: ~0.1 s) is made on a thread of its own while the first window of the
 		// first file is being read; whoever needs it first waits for it (ensure_created)
 		rc = DBGK_OK;
-		S->zero_copy = !getenv("DBGK_NO_ZERO_COPY"); // batches are parsed straight into the pinned staging buffers
+		S->zero_copy = !dbgk_hook("no_zero_copy"); // batches are parsed straight into the pinned staging buffers
 		const double t0c = now_s();
+		// (only here: page-locking the staging buffers happens on the creating thread, beside the first file read.  A communicator
+		// creates its handles on the calling thread and a fresh set at every resize: there the buffers are made when first used)
+		cfg.flags |= DBGK_FLAG_PREALLOC_STAGING;
 		S->creator = std::thread([S, cfg, t0c]() {
 			S->create_rc = dbgk_create(&cfg, &S->h);
 			if (S->create_rc != DBGK_OK) S->create_err = dbgk_last_error();
 			S->t_create = now_s() - t0c;
 		});
-		if (getenv("DBGK_CREATE_SYNC")) ensure_created(*S);
+		if (DBGK_EXPERIMENT_ENV("DBGK_CREATE_SYNC")) ensure_created(*S);
 	}
 
 	if (!S->ref_layout) start_early_table(*S, initial_size);

@@ -78,5 +78,9 @@ int write_links_dump(const string &path);   // text dump of the three artefacts 
 extern uint16_t *DbgkKmerLinks;
 extern vector<uint64_t> DbgkTipNodes;
 extern vector<uint64_t> DbgkBranchNodes;
+// build_debruijn_graph() keeps its GPU handle (table, record stores, pinned staging buffers) alive for write_kmer_freq_file /
+// DBGK_LINKS users that follow; a program that embeds libdbgasm_host.so and goes on living gives it back with this
+// (debruijn_contig itself leaves through _exit: the process ends faster than the teardown runs)
+void dbgk_host_release_session();
 
 #endif

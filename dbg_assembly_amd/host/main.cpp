@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "DBGgraph.h"
+#include "dbgk_env.h"
 
 // parameters of the contig stage: parsed for command-line compatibility (main.cpp:177-189) and
 // handed to the contig stage when it is linked in (it defines the same globals; these are weak).
@@ -67,7 +68,7 @@ static void usage()
 	     << "   Version: 1.0 (gfx950)\n" << endl;
 	print_options(cout, true);
 	cout << "   -h          this help" << endl << endl
-	     << "   environment: DBGK_DEVICE=<gpu ordinal>  DBGK_BATCH_MB=<host batch size>  DBGK_DUMP=<file: sorted node dump>" << endl
+	     << "   environment: DBGK_DEVICE=<gpu ordinal>  DBGK_BATCH_BYTES=<host batch size>  DBGK_DUMP=<file: sorted node dump>" << endl
 	     << "                DBGK_ENGINE=1|2   1 = global-atomic insert, 2 = partitioned records + LDS-built table regions (default)" << endl
 	     << "                DBGK_STORE_KMERS=<n>  k-mer occurrences the partitioned engine holds before merging them into the table" << endl
 	     << "                DBGK_LAYOUT=ref   lay the hash table out slot for slot like `debruijn_contig -t 1` of the reference" << endl
@@ -87,7 +88,7 @@ static void leave(int code)
 	cout.flush();
 	cerr.flush();
 	fflush(NULL);
-	if (getenv("DBGK_SLOW_EXIT")) exit(code);
+	if (DBGK_EXPERIMENT_ENV("DBGK_SLOW_EXIT")) exit(code);
 	_exit(code);
 }
 
@@ -166,18 +167,16 @@ int main(int argc, char *argv[])
 			fclose(fp);
 		}
 	}
-	if (getenv("DBGK_TIMINGS") && getenv("DBGK_SLOW_EXIT")) { // what the teardown that leave() skips would cost
+	if (DBGK_EXPERIMENT_ENV("DBGK_SLOW_EXIT") && getenv("DBGK_TIMINGS")) { // what the teardown that leave() skips would cost
 		const double t0 = wall_now();
 		free_hash(kset);
 		kset = NULL;
 		const double t1 = wall_now();
 		vector<string> none;
-		extern void dbgk_host_release_session();
 		dbgk_host_release_session();
 		cerr << "Teardown (s): free host KmerSet " << t1 - t0 << " destroy GPU handle " << wall_now() - t1 << endl;
 	}
-	if (getenv("DBGK_EXIT_DESTROY")) { // experiment: give the device memory back before leaving
-		extern void dbgk_host_release_session();
+	if (DBGK_EXPERIMENT_ENV("DBGK_EXIT_DESTROY")) { // experiment: give the device memory back before leaving
 		dbgk_host_release_session();
 	}
 	leave(0);

@@ -147,13 +147,14 @@ public:
 			int exit_head[4] = {0, 1, 2, 3}; // state after the head part
 			int exit_common = 0;
 			bool converged = false;
+			bool long_head[4] = {false, false, false, false}, long_common = false; // a line of >= 4 GiB among the sequences of that list
 		};
 		struct Window {
 			char *buf = NULL;
 			size_t cap = 0;
 			size_t have = 0, take = 0; // carried-over bytes, bytes read from the file
 			std::vector<Slice> slice;
-			bool ok = true, too_long = false;
+			bool ok = true;
 		} win[2];
 		for (Window &W : win) W.slice.resize((size_t)n_threads);
 		auto release = [&]() { for (Window &W : win) free(W.buf); };
@@ -166,7 +167,6 @@ public:
 		auto read_window = [&](Window &W, size_t file_off, const char *carry, size_t carry_len) {
 			W.take = std::min(WINDOW, size_ - file_off);
 			W.have = carry_len;
-			W.too_long = false;
 			W.ok = grow(W.buf, W.cap, W.have + W.take);
 			if (!W.ok) return;
 			if (carry_len) memcpy(W.buf, carry, carry_len);
@@ -191,7 +191,8 @@ public:
 			});
 			for (char f : failed) W.ok = W.ok && !f;
 			if (!W.ok) return;
-			std::vector<char> long_line((size_t)n_threads, 0);
+			// a line of 4 GiB or more where a sequence would be: noted per speculative list (and for the common part), so that only
+			// the list the file really takes can stop it -- the other three states are hypotheses the file never reaches
 			run_threads([&](int t) { // (2) the record rules over the lines that END in this slice
 				Slice &S = W.slice[(size_t)t];
 				for (auto &h : S.head) h.clear();
@@ -202,11 +203,13 @@ public:
 					if (!W.slice[(size_t)u].nl.empty()) { line_start = (size_t)W.slice[(size_t)u].nl.back() + 1; break; }
 				int st[4] = {0, 1, 2, 3};
 				int cur = 0;
-				auto step = [&](int &state, const char *line, size_t len, std::vector<ReadRef> &out) {
+				for (int e = 0; e < 4; e++) S.long_head[e] = false;
+				S.long_common = false;
+				auto step = [&](int &state, const char *line, size_t len, std::vector<ReadRef> &out, bool &too_long_here) {
 					switch (state) { // the record rules of for_each_read_in_file
 						case 0: if (len && line[0] == marker) state = 1; break;
 						case 1:
-							if (len >> 32) long_line[(size_t)t] = 1;
+							if (len >> 32) too_long_here = true;
 							out.push_back(ReadRef{line, (uint32_t)len});
 							state = (format == 1) ? 2 : 0;
 							break;
@@ -218,9 +221,9 @@ public:
 					const size_t pos = (size_t)pos64, len = pos - line_start;
 					const char *line = W.buf + line_start;
 					if (S.converged) {
-						step(cur, line, len, S.common);
+						step(cur, line, len, S.common, S.long_common);
 					} else {
-						for (int e = 0; e < 4; e++) step(st[e], line, len, S.head[e]);
+						for (int e = 0; e < 4; e++) step(st[e], line, len, S.head[e], S.long_head[e]);
 						if (st[0] == st[1] && st[1] == st[2] && st[2] == st[3]) {
 							S.converged = true;
 							cur = st[0];
@@ -231,7 +234,6 @@ public:
 				for (int e = 0; e < 4; e++) S.exit_head[e] = st[e];
 				S.exit_common = cur;
 			});
-			for (char f : long_line) W.too_long = W.too_long || f;
 		};
 		int state = 0;          // 0 look for header, 1 sequence line, 2/3 skip (FASTQ '+' and quality)
 		size_t file_off = 0;
@@ -241,7 +243,6 @@ public:
 		while (file_off < size_ && !(stop && *stop)) {
 			Window &W = win[cur];
 			if (!W.ok) return release(), false;
-			if (W.too_long) too_long = true;
 			const size_t end = W.have + W.take;
 			// the last newline of this window: what follows it is carried over to the next one
 			size_t after_last_nl = 0;
@@ -254,6 +255,7 @@ public:
 			for (int t = 0; t < n_threads && !(stop && *stop); t++) {
 				const Slice &S = W.slice[(size_t)t];
 				const std::vector<ReadRef> &h = S.head[state];
+				if (S.long_head[state] || (S.converged && S.long_common)) too_long = true; // (set BEFORE the callback that sees the line)
 				if (!h.empty()) cb(h.data(), h.size());
 				if (S.converged) {
 					if (!S.common.empty() && !(stop && *stop)) cb(S.common.data(), S.common.size());

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the DBGK_DEBUG_* / tile-geometry / schedule switches used here exist only in a library built with -DDBGK_EXPERIMENTS:
+#   profiles/tools/build_variant.sh exp dbg_assembly_amd/csrc -DDBGK_EXPERIMENTS  &&  export DBGK_LIB=$PWD/dbg_assembly_amd/_variants/exp.so
 # timing experiments for the level-2 kernel: DBGK_DEBUG_L2 0 = production, 1 = loads + ranking only, 2 = no copy-out,
 # 3 = copy-out into a 32 KiB window (no HBM write traffic)
 for m in 0 1 2 3; do

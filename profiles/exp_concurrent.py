@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment (round 2, result in profiles/r02_exp_l1_beside_l2.txt): does the level-1 kernel of one batch run BESIDE level 2 of another?  Two handles on one GPU, same
+"""(round 5: DBGK_L1_PER_CU and friends need a library built with -DDBGK_EXPERIMENTS, profiles/tools/build_variant.sh)
+Experiment (round 2, result in profiles/r02_exp_l1_beside_l2.txt): does the level-1 kernel of one batch run BESIDE level 2 of another?  Two handles on one GPU, same
 workload (cfg2): handle A only pushes (level 1, asynchronous), handle B has its records in place and finalizes
 (level 2, then the region build; DBGK_OVERLAP_CHUNKS=1 so that level 2 comes first).  Wall time of both together
 against each alone.  Run with and without DBGK_L2_DIRECT=1 (the unstaged level-2 kernel needs no LDS to speak of and

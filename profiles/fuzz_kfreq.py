@@ -88,12 +88,12 @@ def main():
         # configurations as 2-bit words
         lin = rng.choice(["1", "0", None])
         packed = pieces == 1 and rng.random() < 0.5
-        os.environ.pop("DBGK_L1_LINEAR", None)
+        os.environ.pop("DBGK_TEST_HOOKS", None)
         want = table_of(k, 0, bases, offsets, 1, 1 << 26)
         if lin is not None:
-            os.environ["DBGK_L1_LINEAR"] = lin
+            os.environ["DBGK_TEST_HOOKS"] = "l1_linear=%s" % lin
         got = table_of(k, expected, bases, offsets, pieces, max_batch, packed)
-        os.environ.pop("DBGK_L1_LINEAR", None)
+        os.environ.pop("DBGK_TEST_HOOKS", None)
         ok = got[1:] == want[1:] and np.array_equal(got[0], want[0])
         print("cfg %3d k=%2d L=%3d %s reads=%5d kmers=%8d expected=%9d pieces=%d batch=2^%d linear=%s %s distinct=%8d max=%3d  %s"
               % (c, k, L, "uniform" if uniform else "ragged ", len(reads), total, expected, pieces, max_batch.bit_length() - 1, lin, "packed" if packed else "ascii ",

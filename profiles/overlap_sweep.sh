@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the DBGK_DEBUG_* / tile-geometry / schedule switches used here exist only in a library built with -DDBGK_EXPERIMENTS:
+#   profiles/tools/build_variant.sh exp dbg_assembly_amd/csrc -DDBGK_EXPERIMENTS  &&  export DBGK_LIB=$PWD/dbg_assembly_amd/_variants/exp.so
 # level-2 / build overlap granularity: bucket chunks per step (DBGK_OVERLAP_CHUNKS); the finer the chunks, the sooner
 # the region build reads the records level 2 has just written (Infinity Cache reuse) -- at the price of more launches
 R=${GRAFT_REPO_ROOT:-/root/repo}

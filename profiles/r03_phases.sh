@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the DBGK_DEBUG_* / tile-geometry / schedule switches used here exist only in a library built with -DDBGK_EXPERIMENTS:
+#   profiles/tools/build_variant.sh exp dbg_assembly_amd/csrc -DDBGK_EXPERIMENTS  &&  export DBGK_LIB=$PWD/dbg_assembly_amd/_variants/exp.so
 # Phase timings of the three PARTITION kernels from their debug builds (results of those runs are wrong by design):
 #   DBGK_DEBUG_MODE  (level 1) 1 = extraction only, 2 = no copy-out, 3 = copy-out into a 32 KiB window
 #   DBGK_DEBUG_L2    (level 2) 1 = loads + ranking only, 2 = no copy-out, 3 = copy-out into a window

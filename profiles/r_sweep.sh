@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the DBGK_DEBUG_* / tile-geometry / schedule switches used here exist only in a library built with -DDBGK_EXPERIMENTS:
+#   profiles/tools/build_variant.sh exp dbg_assembly_amd/csrc -DDBGK_EXPERIMENTS  &&  export DBGK_LIB=$PWD/dbg_assembly_amd/_variants/exp.so
 # level-1 bucket width r (DBGK_PART_R): level-1 fan-out size >> r, level-2 fan-out 2^(r-12)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for r in ${RS:-20 21 22}; do

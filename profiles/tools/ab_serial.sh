@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5) the DBGK_DEBUG_* / tile-geometry / schedule switches used here exist only in a library built with -DDBGK_EXPERIMENTS:
+#   profiles/tools/build_variant.sh exp dbg_assembly_amd/csrc -DDBGK_EXPERIMENTS  &&  export DBGK_LIB=$PWD/dbg_assembly_amd/_variants/exp.so
 # ab_serial.sh lib...: each build with level 2 and the region build one after the other (DBGK_OVERLAP_CHUNKS=1: each kernel's time alone) and overlapped (default)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for round in $(seq 1 ${ROUNDS:-2}); do

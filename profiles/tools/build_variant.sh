@@ -3,7 +3,7 @@
 # travels to the GPU box) for A/B runs inside one gpurun call (profiles/ab_bench.sh, DBGK_LIB)
 set -e
 R=/root/repo
-name=$1; src=${2:-$R/dbg_assembly_amd/csrc}; shift; shift || true
+name=$1; src=${2:-$R/dbg_assembly_amd/csrc}; [ -z "$src" ] && src=$R/dbg_assembly_amd/csrc; shift; shift || true
 O=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$src -Wall -Wno-unused-result "$@" -c $src/dbgk.hip -o $O/dbgk.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/include -I$src -c $src/dbgk_sort.hip -o $O/dbgk_sort.o

@@ -67,3 +67,29 @@ def push_with_reference_schedule(g, files, params, capi):
                         break
                 doublings += 1
     return size
+
+
+def hooks_value(current, **kv):
+    """DBGK_TEST_HOOKS syntax (include/dbgk_env.h): "name=value,name=value"; merge kv into `current` (None removes a hook)"""
+    d = dict(item.split("=", 1) for item in (current or "").split(",") if item)
+    for k, v in kv.items():
+        if v is None:
+            d.pop(k, None)
+        else:
+            d[k] = str(v)
+    return ",".join("%s=%s" % kv for kv in d.items())
+
+
+def set_hooks(monkeypatch=None, **kv):
+    """force code paths of the library through DBGK_TEST_HOOKS (read at every use): set_hooks(monkeypatch, l1_linear=1, export_full=None)"""
+    import os
+    val = hooks_value(os.environ.get("DBGK_TEST_HOOKS"), **kv)
+    if monkeypatch is not None:
+        if val:
+            monkeypatch.setenv("DBGK_TEST_HOOKS", val)
+        else:
+            monkeypatch.delenv("DBGK_TEST_HOOKS", raising=False)
+    elif val:
+        os.environ["DBGK_TEST_HOOKS"] = val
+    else:
+        os.environ.pop("DBGK_TEST_HOOKS", None)

@@ -79,7 +79,7 @@ def test_cli_early_host_table_and_export_through_occupied_nodes(tmp_path, case):
     """The two host-table shortcuts of round 4 at sizes the goldens have: the array allocated (and touched) at the size -i asks for
     when the run starts -- kept when the reference's doubling schedule ends there, dropped when it enlarges (enlarge_* cases) -- and
     the table leaving the device as occupied nodes + occupancy bits.  Same dump, same final array size as the reference."""
-    r, dump, _ = run_cli(tmp_path, case, {"DBGK_EARLY_TABLE_MIN": "0", "DBGK_EXPORT_COMPACT_MIN": "0", "DBGK_EARLY_THREADS": "3"})
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_TEST_HOOKS": "early_table_min=0,export_compact_min=0,early_threads=3"})
     ref = case["ref"]
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert re.search(r"^count:\t%d$" % ref["count"], r.stderr, re.M)
@@ -89,7 +89,7 @@ def test_cli_early_host_table_and_export_through_occupied_nodes(tmp_path, case):
 def test_cli_small_batches_and_device_resize(tmp_path):
     """DIRECT engine: 1 MiB host batches + a tiny initial table force several device-side enlarges"""
     case = [c for c in golden_cases() if c["name"] == "enlarge_b50"][0]
-    r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_MB": "1", "DBGK_ENGINE": "1"})
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_BATCH_BYTES": "1048576", "DBGK_ENGINE": "1"})
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     assert "Enlarge device hash array size" in r.stderr
 
@@ -109,7 +109,7 @@ def test_cli_ascii_hand_over_equals_the_packed_one(tmp_path, name):
     over and the GPU packs them: same graph, with many small batches as well"""
     case = [c for c in golden_cases() if c["name"] == name][0]
     for extra in ({"DBGK_HOST_ASCII": "1"}, {"DBGK_HOST_ASCII": "1", "DBGK_BATCH_BYTES": "4096"}, {"DBGK_BATCH_BYTES": "4099"},
-                  {"DBGK_BATCH_BYTES": "4099", "DBGK_NO_ZERO_COPY": "1"}, {"DBGK_PARSE_SEQUENTIAL": "1", "DBGK_BATCH_BYTES": "5000"}):
+                  {"DBGK_BATCH_BYTES": "4099", "DBGK_TEST_HOOKS": "no_zero_copy=1"}, {"DBGK_TEST_HOOKS": "parse_sequential=1", "DBGK_BATCH_BYTES": "5000"}):
         r, dump, _ = run_cli(tmp_path, case, extra)
         assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"], extra
         assert "none of ACGTNacgtn" not in r.stderr
@@ -167,7 +167,7 @@ def test_cli_reference_layout_mode(tmp_path, oracle, case):
     reference's layout."""
     p = case["params"]
     img = tmp_path / "table.img"
-    r, dump, _ = run_cli(tmp_path, case, {"DBGK_LAYOUT": "ref", "DBGK_DUMP_TABLE": str(img), "DBGK_BATCH_MB": "1"})
+    r, dump, _ = run_cli(tmp_path, case, {"DBGK_LAYOUT": "ref", "DBGK_DUMP_TABLE": str(img), "DBGK_BATCH_BYTES": "1048576"})
     assert hashlib.sha256(dump.read_bytes()).hexdigest() == case["dump_sha256"]
     size, count, array, flags = oracle.read_table_image(str(img))
     res = oracle.build_graph(files=case_files(case), k=p["k"], max_read_len=p["max_read_len"], threads=1,
@@ -239,7 +239,7 @@ def test_cli_full_size_cfg2_equals_oracle_golden(tmp_path, cfg2_fasta, store):
     assert rows[0] == KMER_FREQ_HEADER and [int(x.split("\t")[1]) for x in rows[1:]] == gold["depth_stat"][1:]
 
 
-@pytest.mark.parametrize("k,env", [(63, {}), (33, {"DBGK_WIDE_PASSES": "3"}), (47, {"DBGK_GPU_LIST": "0,0,0"}), (63, {"DBGK_WIDE_DIRECT": "1"})],
+@pytest.mark.parametrize("k,env", [(63, {}), (33, {"DBGK_WIDE_PASSES": "3"}), (47, {"DBGK_GPU_LIST": "0,0,0"}), (63, {"DBGK_TEST_HOOKS": "wide_direct=1"})],
                          ids=["k63", "k33_three_passes", "k47_three_shards", "k63_atomic_kernels"])
 def test_cli_k_above_32_emits_the_128_bit_graph_PARITY_UNPINNED(tmp_path, k, env):
     """`debruijn_contig -k 33..63` (this build only: the reference stops at 31): files -> WIDE engine -> host KmerSet128 ->

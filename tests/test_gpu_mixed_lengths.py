@@ -5,6 +5,8 @@ engines, both forms of the input; and the CPU side of the workload generator."""
 import numpy as np
 import pytest
 
+from helpers import set_hooks
+
 from dbg_assembly_amd import workloads
 
 
@@ -75,7 +77,7 @@ def _shape_reads(rng, shape):
                                        ("mixed", 32, 250), ("mixed", 17, 120), ("mixed", 5, 250)])
 def test_prefix_level1_kernel_equals_oracle(oracle, monkeypatch, shape, k, r):
     """k_extract_scatter_prefix (every read exactly the lanes its windows need): reads of any lengths, reads without a window,
-    reads trimmed at -r, byte ranges that do not fit the LDS image -- against the oracle; ASCII and 2-bit input; DBGK_L1_PREFIX=1
+    reads trimmed at -r, byte ranges that do not fit the LDS image -- against the oracle; ASCII and 2-bit input; hook l1_prefix=1
     also sends the batches of the ragged form through it, =0 is the flat kernel (the A side of the comparison)"""
     import random
     from dbg_assembly_amd import capi
@@ -87,7 +89,7 @@ def test_prefix_level1_kernel_equals_oracle(oracle, monkeypatch, shape, k, r):
     words, other = capi.pack_bases(bases)
     size = capi.find_next_prime_ref(70000000)
     for env, packed, batch in (("1", False, 0), ("1", True, 0), ("1", True, 1 << 15), ("0", False, 0)):
-        monkeypatch.setenv("DBGK_L1_PREFIX", env)
+        set_hooks(monkeypatch, l1_prefix=env)
         with capi.Graph(k=k, table_slots=size, max_read_len=r, engine=capi.ENGINE_PARTITION, expected_kmers=max(len(bases), 1), max_batch_bases=batch) as g:
             if packed:
                 g.push_reads_packed(words, offsets, other)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases, golden_case_ids
-from helpers import case_reads, dump_sha256, push_with_reference_schedule
+from helpers import case_reads, dump_sha256, push_with_reference_schedule, set_hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -347,10 +347,10 @@ def test_partition_engine_streams_input_of_unknown_size(capi, oracle, store, exp
 @pytest.mark.parametrize("store_pieces", [0, 3])
 def test_early_level2_rounds_between_the_batches_equal_oracle(capi, oracle, monkeypatch, pieces, store_pieces):
     """EARLY level 2 (dbgk.hip early_l2): every push first scatters what the batches before it left in the level-1 buckets.  The input
-    comes in 2 / 6 / 40 host batches with a round in front of every batch (DBGK_EARLY_L2_MIN=1), once with all records resident
+    comes in 2 / 6 / 40 host batches with a round in front of every batch (hook early_l2_min=1), once with all records resident
     and once through a store that holds three batches (flush rounds in between: the incremental build, the counters of taken
     records reset with the store); mixed-length reads, poly-A, a heavy repeat.  Nodes, counts and host layout against the oracle;
-    the same input with the rounds switched off (DBGK_EARLY_L2=0) gives the same digest."""
+    the same input with the rounds switched off (hook early_l2=0) gives the same digest."""
     rng = random.Random(1000 + pieces)
     reads = rand_reads(rng, 9000, G=60000) + [b"A" * 150] * 200 + [b"ACGTTGCATGCAAGCTTAGCTAGGATCCGATCGATTACGAT" * 3] * 300
     rng.shuffle(reads)
@@ -363,8 +363,7 @@ def test_early_level2_rounds_between_the_batches_equal_oracle(capi, oracle, monk
     store = total if store_pieces == 0 else store_pieces * (total // pieces) + 4096
     digests = []
     for early in ("1", "0"):
-        monkeypatch.setenv("DBGK_EARLY_L2", early)
-        monkeypatch.setenv("DBGK_EARLY_L2_MIN", "1")
+        set_hooks(monkeypatch, early_l2=early, early_l2_min=1)
         with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=store, max_batch_bases=1 << 20) as g:
             for a in range(0, n, per):
                 b = min(n, a + per)
@@ -484,11 +483,11 @@ def test_ragged_level1_tiles_that_start_in_a_short_reads_empty_tail(capi, oracle
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[idx]].copy()
     size = capi.find_next_prime_ref(PART_SLOTS)
     res = []
-    # (since round 4 such a batch takes the prefix form by default -- exact lane counts per read; DBGK_L1_PREFIX=0 keeps the ragged form,
+    # (since round 4 such a batch takes the prefix form by default -- exact lane counts per read; the hook l1_prefix=0 keeps the ragged form,
     # which stays in the library: both are run)
     for engine, prefix in ((capi.ENGINE_DIRECT, None), (capi.ENGINE_PARTITION, "0"), (capi.ENGINE_PARTITION, "1")):
         if prefix is not None:
-            monkeypatch.setenv("DBGK_L1_PREFIX", prefix)
+            set_hooks(monkeypatch, l1_prefix=prefix)
         with capi.Graph(k=k, table_slots=size, engine=engine, expected_kmers=int(offsets[-1]), max_batch_bases=int(offsets[-1]) + 4096) as g:
             g.push_reads(bases, offsets)   # ONE batch: the tiles of interest need many reads in a row
             st = g.finalize()
@@ -527,7 +526,47 @@ def test_full_size_cfg2_bench_workload_equals_the_cpu_oracle(capi):
                    [int(x) for x in g.link_stats(2).depth_stat])
             d_bases.free()
             d_off.free()
+            sha = _sorted_sha256(g)
         assert got == (gold["total_reads"], gold["total_kmers"], gold["total_kmers"], gold["count"], gold["digest"], gold["depth_stat"]), engine
+        # "bit-exact kmerSet", literally: the canonical dump -- every node as the reference's 16-byte KmerNode, sorted by kmer -- hashed
+        # by the REAL reference at full size (ref_dbg -H, make_cfg2_full.py --ref) against the bytes dbgk_export_sorted returns
+        assert sha == gold["sorted_sha256"], engine
+
+
+def _sorted_sha256(g):
+    import hashlib
+    nodes = g.export_sorted()
+    assert nodes.dtype.itemsize == 16
+    h = hashlib.sha256()
+    view = nodes.view(np.uint8).reshape(-1)
+    for lo in range(0, len(view), 1 << 28):
+        h.update(view[lo:lo + (1 << 28)].data)
+    return h.hexdigest()
+
+
+def test_cfg3_generator_5m_reads_equal_the_real_reference(capi):
+    """cfg3's read generator (synth cfg = 3) pinned to the reference itself at a size it takes: the first 5 M reads of bench.py's cfg3
+    share (125 Mb genome), k = 31 -- counts, digest, DepthStat and the SHA-256 of the sorted 16-byte-node dump as the REAL reference
+    produced them (tests/golden/cfg3_pin.json, make_cfg2_full.py --ref-cfg3), both engines.  (The full cfg3 share stays an
+    engine-against-engine check, tests/test_gpu_cfg3.py: no CPU takes 25 M reads in a test.)"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_pin.json")))
+    n_reads = gold["n_reads"]
+    P = capi.synth_params(gold["genome_len"], 150, cfg=3)
+    size = capi.find_next_prime_ref(600000000)
+    for engine in (capi.ENGINE_PARTITION, capi.ENGINE_DIRECT):
+        with capi.Graph(k=gold["k"], table_slots=size, max_read_len=250, engine=engine,
+                        expected_kmers=n_reads * 120 if engine == capi.ENGINE_PARTITION else 0) as g:
+            d_bases, d_off, nb = g.synth_reads_device(P, 0, n_reads)
+            g.push_reads_device(d_bases.ptr, d_off.ptr, n_reads, nb)
+            st = g.finalize()
+            got = (int(st.total_reads), int(st.total_kmers), int(st.count), g.digest(), [int(x) for x in g.link_stats(2).depth_stat])
+            d_bases.free()
+            d_off.free()
+            sha = _sorted_sha256(g)
+        assert got == (gold["total_reads"], gold["total_kmers"], gold["count"], gold["digest"], gold["depth_stat"]), engine
+        assert sha == gold["sorted_sha256"], engine
 
 
 @pytest.mark.parametrize("slots,force", [(4_290_000_000, None), (600_000_000, "1"), (4_290_000_000, "0")])
@@ -539,7 +578,7 @@ def test_full_size_cfg2_reads_into_many_level1_buckets(capi, monkeypatch, slots,
     import json
     import os
     if force is not None:
-        monkeypatch.setenv("DBGK_L1_LINEAR", force)
+        set_hooks(monkeypatch, l1_linear=force)
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_full.json")))
     n_reads = gold["n_reads"]
     P = capi.synth_params(gold["genome_len"], 150, cfg=2)
@@ -830,10 +869,10 @@ def test_export_with_the_consumers_first_pass_on_the_device_PARITY_UNPINNED(capi
 @pytest.mark.parametrize("n_reads,size_hint", [(40_000, 17_000_000), (3, 17_000_000), (400_000, 60_000_000), (200_000, 25_165_857), (60_000, 7_000_000)])
 def test_host_table_through_the_occupied_nodes_only_equals_the_plain_copy(capi, oracle, monkeypatch, n_reads, size_hint):
     """Large host tables leave the device as the stream of their occupied nodes + the occupancy bits and are laid out at their slots
-    by host threads (d2h_compact, dbgk.hip); DBGK_EXPORT_FULL=1 copies every slot as before.  Same image on the device -> the two
+    by host threads (d2h_compact, dbgk.hip); the hook export_full=1 copies every slot as before.  Same image on the device -> the two
     must agree byte for byte, in buffers that held garbage before (every slot and every flag byte is written).  Sizes that are no
     multiple of 64 or 4096, a nearly empty and a well filled table, with and without the link pass."""
-    monkeypatch.setenv("DBGK_EXPORT_COMPACT_MIN", "0")
+    set_hooks(monkeypatch, export_compact_min=0)
     monkeypatch.setenv("DBGK_EXPORT_THREADS", "5")
     P = oracle.synth_params(300_000, 150, cfg=1)
     bases, offsets = oracle.synth_reads(P, 0, n_reads)
@@ -853,9 +892,9 @@ def test_host_table_through_the_occupied_nodes_only_equals_the_plain_copy(capi, 
         g.push_reads(bases, offsets)
         st = g.finalize()
         for links in (False, True):
-            monkeypatch.delenv("DBGK_EXPORT_FULL", raising=False)
+            set_hooks(monkeypatch, export_full=None)
             got = export(g, links)
-            monkeypatch.setenv("DBGK_EXPORT_FULL", "1")
+            set_hooks(monkeypatch, export_full=1)
             want = export(g, links)
             for a, b in zip(got, want):
                 assert np.array_equal(a, b)
@@ -871,7 +910,7 @@ def test_comm_export_with_the_consumers_first_pass_PARITY_UNPINNED(capi, oracle,
     node multiset against the oracle (parity of the link records unpinned: contig.cpp needs Boost)"""
     if staging:
         monkeypatch.setenv("DBGK_COMM_HOST_STAGING", "1")
-        monkeypatch.setenv("DBGK_EXPORT_COMPACT_MIN", "0")   # the small host table too leaves as occupied nodes + bits (d2h_compact)
+        set_hooks(monkeypatch, export_compact_min=0)   # the small host table too leaves as occupied nodes + bits (d2h_compact)
     rng = random.Random(40 + n_shards)
     reads = rand_reads(rng, 3000, G=20000) + [b"A" * 150] * 300 + [b"T" * 90] * 40
     rng.shuffle(reads)

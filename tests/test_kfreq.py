@@ -11,6 +11,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from helpers import set_hooks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "dbg_assembly_amd", "bin", "kmerfreq")
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
@@ -99,7 +101,7 @@ def test_kfreq_engine_counts_equal_oracle(oracle, k, expected):
 @pytest.mark.parametrize("k", [13, 15])
 def test_kfreq_direct_blocks_through_every_level1_form(oracle, monkeypatch, shape, k):
     """Direct blocks move 32-bit level-1 records (round 4): written by the wave-per-bucket copy-out, by the linear copy-out
-    (DBGK_L1_LINEAR=1: what a table of 4^18 bytes with its 1024 level-1 buckets takes) and read back by level 2.  Reads of one
+    (hook l1_linear=1: what a table of 4^18 bytes with its 1024 level-1 buckets takes) and read back by level 2.  Reads of one
     length (the level-1 instantiation compiled for this case), mostly full length (ragged tiles), any length (lane prefix / flat
     kernel), as ASCII and as 2-bit words: the same 4^k-byte table as the oracle's."""
     from dbg_assembly_amd import capi
@@ -125,7 +127,7 @@ def test_kfreq_direct_blocks_through_every_level1_form(oracle, monkeypatch, shap
     assert other == 0
     expected = sum(max(0, len(r) - k + 1) for r in reads)
     for lin in ("0", "1"):
-        monkeypatch.setenv("DBGK_L1_LINEAR", lin)
+        set_hooks(monkeypatch, l1_linear=lin)
         for packed in (False, True):
             with capi.Graph(k=k, table_slots=0, engine=capi.ENGINE_KFREQ, max_read_len=1000000, expected_kmers=expected) as g:
                 if packed:
@@ -210,7 +212,7 @@ def test_kfreq_communicator_equals_oracle(oracle, k, n_shards, expected, stage_m
     buffers of 1 MiB make the copy / add pipeline go through many chunks (4^13 = 64 MiB of counters)"""
     from dbg_assembly_amd import capi
     if stage_mb:
-        monkeypatch.setenv("DBGK_COMM_KFREQ_STAGE_MB", str(stage_mb))
+        set_hooks(monkeypatch, comm_kfreq_stage_mb=stage_mb)
     reads = _reads(random.Random(k * 31 + n_shards), 4000)
     want = oracle.kfreq_expected_counts([oracle.pack_reads(reads)], k)
     with capi.Comm(k, 0, [0] * n_shards, max_read_len=1000000, expected_kmers=expected, engine=capi.ENGINE_KFREQ) as c:

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_cases, golden_case_ids
-from helpers import case_reads, dump_sha256
+from helpers import case_reads, dump_sha256, set_hooks
 
 
 def _capi():
@@ -183,7 +183,7 @@ def _reads_for(rng, n, L, shape):
 @pytest.mark.parametrize("entry", ["host", "staging", "device"])
 def test_every_level1_form_takes_packed_batches(capi, oracle, shape, entry):
     """the PARTITION engine's level-1 kernels -- regular tiles + the general equal-length form (equal), the ragged form, the flat
-    kernel (mixed), each also in its linear form (DBGK_L1_LINEAR=1) -- and the other engines, packed == oracle"""
+    kernel (mixed), each also in its linear form (hook l1_linear=1) -- and the other engines, packed == oracle"""
     import os
     rng = random.Random(len(shape) * 131 + len(entry))
     reads = _reads_for(rng, 3000, 150, shape) + ([b"A" * 150] * 3 if shape == "equal" else [b"A" * 150, b"T" * 100, b"", b"ACGT"])
@@ -192,7 +192,7 @@ def test_every_level1_form_takes_packed_batches(capi, oracle, shape, entry):
     want = ref.nodes.astype(capi.NODE_DTYPE)
     size = capi.find_next_prime_ref(PART_SLOTS)
     for lin in ("0", "1"):
-        os.environ["DBGK_L1_LINEAR"] = lin
+        set_hooks(None, l1_linear=lin)
         try:
             with capi.Graph(k=31, table_slots=size, max_read_len=200, engine=capi.ENGINE_PARTITION, expected_kmers=len(bases)) as g:
                 _push(g, capi, bases, offsets, entry)
@@ -200,7 +200,7 @@ def test_every_level1_form_takes_packed_batches(capi, oracle, shape, entry):
                 assert (st.total_reads, st.total_kmers, st.count) == (ref.total_reads, ref.total_kmers, ref.count)
                 assert np.array_equal(g.export_sorted(), want), (shape, entry, lin)
         finally:
-            del os.environ["DBGK_L1_LINEAR"]
+            set_hooks(None, l1_linear=None)
     # k-mer frequency table (atomics; partitioned blocks) and 128-bit keys (atomics; records): packed == ASCII
     for k, engine, slots, expected in ((13, capi.ENGINE_KFREQ, 0, 0), (13, capi.ENGINE_KFREQ, 0, len(bases)), (47, capi.ENGINE_WIDE, 200003, 0),
                                        (47, capi.ENGINE_WIDE, 1 << 26, len(bases))):
