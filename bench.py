@@ -116,6 +116,10 @@ def parse_args():
                          "region hands to the device) or ASCII bytes")
     ap.add_argument("--no-also", action="store_true", help="default cfg2 run at N = 1: skip the three-step runs of cfg3 / cfg4 / cfg5")
     ap.add_argument("--brief", action="store_true", help="the timed loop and its check only (no H2D legs, probes, CPU baseline, also-runs)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print the geometry `--gpus N` would run with -- global table, level-1 buckets and their owners, records and bytes per "
+                         "rank -- as one JSON line and leave: no GPU, no process group (dbgk_plan_partition); what the first run on a real "
+                         "multi-GPU node starts from")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1: do not measure roofline.traffic in this run (two child processes of this bench under rocprofv3 --pmc, "
                          "one step each); the committed profiles/traffic_r*.json is used instead")
@@ -471,6 +475,15 @@ def rccl_record(ctx, args):
         rec["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:  # noqa: BLE001
         pass
+    # what the collectives of the timed steps cost, by stage (multigpu.stage: device events for RCCL, wall clock for host-staged
+    # transports; sums over the steps, bytes per rank): one SCALE line explains its own efficiency.  Rank 0's view.
+    from dbg_assembly_amd.multigpu import stage_summary
+    torch.cuda.synchronize()
+    st = stage_summary()
+    rec["stages"] = {k: {"calls": v["calls"], "ms": round(v["ms"], 3), "bytes_out": v["bytes_out"], "bytes_in": v["bytes_in"], "peers": v["peers"]}
+                     for k, v in sorted(st.items(), key=lambda kv: -kv[1]["ms"])}
+    rec["stages_note"] = "summed over warm-up and timed steps; a collective's ms include the wait for the slowest rank to arrive"
+    rec["collective_timeout_s"] = float(os.environ.get("DBGK_COLLECTIVE_TIMEOUT_S", "120"))
     return rec
 
 
@@ -1037,8 +1050,36 @@ def also_runs(args, ctx):
     return out
 
 
+def plan_only(args):
+    """the sharded geometry of run_graph for world = --gpus, computed without a device"""
+    from dbg_assembly_amd import capi
+    world = max(1, args.gpus)
+    sharded = world > 1 and args.engine == capi.ENGINE_PARTITION and args.exchange == "records"
+    per_gpu_slots = args.table_slots
+    if sharded and args.config == "cfg2":
+        per_gpu_slots = min(per_gpu_slots, (2 ** 32 - 2 ** 22) // world)
+    size = capi.find_next_prime_ref(per_gpu_slots * world if sharded else per_gpu_slots)
+    kpr = 150 - args.kmer + 1
+    plans = [capi.plan_partition(size, args.reads_per_gpu * kpr, world if sharded else 0, r if sharded else 0) for r in range(world if sharded else 1)]
+    p0 = plans[0]
+    worst = max(plans, key=lambda p: p.table_bytes + p.level1_store_bytes + p.inbox_bytes + p.final_store_bytes)
+    return {"config": args.config, "world": world, "sharded": bool(sharded), "reads_per_gpu": args.reads_per_gpu, "records_per_rank": args.reads_per_gpu * kpr,
+            "table_slots_global": int(p0.table_slots), "r": int(p0.r), "level1_buckets": int(p0.level1_buckets), "final_per_level1": int(p0.final_per_level1),
+            "three_level": bool(p0.three_level), "buckets_per_rank": int(p0.buckets_per_rank), "own_buckets": [int(p.own_buckets) for p in plans],
+            "slot_ranges": [[int(p.slot_lo), int(p.slot_hi)] for p in plans],
+            "records_per_level1_bucket": int(p0.records_per_level1_bucket), "records_per_final_bucket": int(p0.records_per_final_bucket),
+            "bytes_per_rank": {"table": int(worst.table_bytes), "level1_store": int(worst.level1_store_bytes), "inbox": int(worst.inbox_bytes),
+                               "final_buckets": int(worst.final_store_bytes), "reads_packed": args.reads_per_gpu * 150 // 4,
+                               "total": int(worst.table_bytes + worst.level1_store_bytes + worst.inbox_bytes + worst.final_store_bytes) + args.reads_per_gpu * 150 // 4},
+            "exchange_bytes_out_per_rank": int(args.reads_per_gpu * kpr * 8 * (world - 1) // world) if sharded else 0,
+            "exchange_chunks": args.exchange_chunks}
+
+
 def main():
     args = parse_args()
+    if args.plan_only:
+        print(json.dumps(plan_only(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     # stdout carries ONE line, the result.  RCCL prints a version banner to stdout when a communicator is

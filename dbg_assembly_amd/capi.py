@@ -58,6 +58,14 @@ class ShardInfo(C.Structure):
                 ("bucket_bytes", C.c_uint64), ("cnt_bucket_bytes", C.c_uint64)]
 
 
+class PlanInfo(C.Structure):
+    _fields_ = [("table_slots", C.c_uint64), ("r", C.c_uint32), ("level1_buckets", C.c_uint32), ("final_per_level1", C.c_uint32),
+                ("three_level", C.c_uint32), ("buckets_per_rank", C.c_uint32), ("own_buckets", C.c_uint32), ("first_bucket", C.c_uint32),
+                ("reserved", C.c_uint32), ("slot_lo", C.c_uint64), ("slot_hi", C.c_uint64), ("records_per_level1_bucket", C.c_uint64),
+                ("records_per_final_bucket", C.c_uint64), ("table_bytes", C.c_uint64), ("level1_store_bytes", C.c_uint64),
+                ("inbox_bytes", C.c_uint64), ("final_store_bytes", C.c_uint64)]
+
+
 class Stats(C.Structure):
     _fields_ = [("total_reads", C.c_uint64), ("total_kmers", C.c_uint64), ("stored_kmers", C.c_uint64),
                 ("count", C.c_uint64), ("count_conflict", C.c_uint64), ("table_slots", C.c_uint64),
@@ -137,6 +145,7 @@ SYMBOLS = [
     ("dbgk_partition_export", _i, [_vp, C.c_uint32, _vp, _u64]),
     ("dbgk_merge_nodes", _i, [_vp, _vp, _u64]),
     ("dbgk_refresh_stats", _i, [_vp, C.POINTER(Stats)]),
+    ("dbgk_plan_partition", _i, [_u64, _u64, C.c_uint32, C.c_uint32, C.POINTER(PlanInfo)]),
     ("dbgk_shard_buffers", _i, [_vp, C.POINTER(ShardInfo)]),
     ("dbgk_shard_mark_exchanged", _i, [_vp]),
     ("dbgk_shard_plan", _i, [_vp]),
@@ -777,3 +786,10 @@ def find_next_prime_ref(num):
     while not is_prime_ref(num):
         num += 2
     return num
+
+
+def plan_partition(table_slots, expected_kmers, shard_count=0, shard_index=0):
+    """geometry of a PARTITION handle with these parameters, computed on the host (no device is touched): PlanInfo"""
+    info = PlanInfo()
+    _chk(lib().dbgk_plan_partition(table_slots, expected_kmers, shard_count, shard_index, C.byref(info)), "dbgk_plan_partition")
+    return info

@@ -4032,6 +4032,47 @@ extern "C" int dbgk_copy_nodes_peer(dbgk_handle *dst, dbgk_node *d_dst, dbgk_han
 // ---------------------------------------------------------------------------------------------
 // sharded tables (one handle per GPU, each owning a contiguous slot range of one global table)
 // ---------------------------------------------------------------------------------------------
+extern "C" int dbgk_plan_partition(uint64_t table_slots, uint64_t expected_kmers, uint32_t shard_count, uint32_t shard_index, dbgk_plan_info *out)
+{
+	if (!out || table_slots == 0) return DBGK_ERR_ARG;
+	dbgk_handle *h = new (std::nothrow) dbgk_handle();   // never touches a device: plan_partition is host arithmetic
+	if (!h) return DBGK_ERR_NOMEM;
+	memset(&h->cfg, 0, sizeof h->cfg);
+	h->cfg.kmer_size = 31;
+	h->cfg.engine = DBGK_ENGINE_PARTITION;
+	h->cfg.table_slots = table_slots;
+	h->cfg.expected_kmers = expected_kmers;
+	h->cfg.shard_count = shard_count;
+	h->cfg.shard_index = shard_index;
+	h->size = table_slots;
+	h->magic = make_mod_magic(table_slots);
+	int rc = plan_partition(h);
+	if (rc == DBGK_OK && !h->part) rc = DBGK_ERR_ARG;
+	if (rc == DBGK_OK) {
+		const PartGeom &G = h->geom;
+		memset(out, 0, sizeof *out);
+		out->table_slots = G.size;
+		out->r = G.r;
+		out->level1_buckets = G.n1;
+		out->final_per_level1 = G.n2;
+		out->three_level = h->three ? 1u : 0u;
+		out->buckets_per_rank = G.B;
+		out->own_buckets = G.nb_own;
+		out->first_bucket = G.b_lo;
+		out->slot_lo = G.slot_lo;
+		out->slot_hi = G.slot_hi;
+		out->records_per_level1_bucket = G.cap1;
+		out->records_per_final_bucket = G.cap2;
+		const uint64_t n_entries = (uint64_t)G.n_ranks * G.B * G.n_sub;
+		out->table_bytes = (G.slot_hi - G.slot_lo) * sizeof(Node);
+		out->level1_store_bytes = n_entries * G.cap1 * 8;
+		out->inbox_bytes = h->sharded ? n_entries * G.cap1 * 8 : 0;
+		out->final_store_bytes = (uint64_t)G.nb_own * G.n2 * G.cap2 * 8 + (h->three ? (uint64_t)G.nb_own * h->fan_mid * h->g_mid.cap2 * 8 : 0);
+	}
+	delete h;
+	return rc;
+}
+
 extern "C" int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out)
 {
 	if (h && h->kfreq) return DBGK_ERR_STATE; // KFREQ handles have no node table

@@ -95,64 +95,194 @@ def _host_staged(t, group):
     return bool(t.is_cuda) and dist.get_backend(group) != "nccl"
 
 
-def all_reduce(t, op, group=None):
-    if _host_staged(t, group):
-        h = t.cpu()
-        dist.all_reduce(h, op=op, group=group)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t, op=op, group=group)
+# ---- every collective is a named STAGE with a wall-clock limit --------------------------------------------------
+# The first run on a real multi-GPU node is where a divergence between the ranks shows (one rank raises or takes another
+# branch, the others wait in a collective for ever).  Every wrapper below therefore runs inside `stage(name, ...)`: a
+# watchdog thread ends the PROCESS with the stage's name, the rank and the elapsed time when a stage has not completed within
+# DBGK_COLLECTIVE_TIMEOUT_S seconds (default 120; a torchrun job then goes down as a whole instead of hanging), and the
+# completed stages are logged -- milliseconds (device events for RCCL, wall clock for host-staged transports), bytes out / in,
+# peers -- so that one SCALE line can explain its own efficiency (bench.py "rccl.stages").
+import os
+import threading
+import time
 
 
-def all_to_all_single(out, inp, group=None):
-    if _host_staged(out, group):
-        h = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(h, inp.cpu(), group=group)
-        out.copy_(h)
-    else:
-        dist.all_to_all_single(out, inp, group=group)
+class _Stages:
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.open = {}
+        self.log = []
+        self.next_id = 0
+        self.thread = None
+
+    def timeout_s(self):
+        return float(os.environ.get("DBGK_COLLECTIVE_TIMEOUT_S", "120"))
+
+    def _watch(self):
+        while True:
+            time.sleep(0.2)
+            now = time.perf_counter()
+            with self.lock:
+                for sid, st in list(self.open.items()):
+                    ev = st.get("end_event")
+                    if ev is not None and ev.query():
+                        self._close(sid, st["start_event"].elapsed_time(ev))
+                    elif now - st["t0"] > st["limit"]:
+                        self._die(st, now)
+
+    def _die(self, st, now):
+        try:
+            rank = dist.get_rank() if dist.is_initialized() else -1
+        except Exception:  # noqa: BLE001
+            rank = -1
+        os.write(2, ("dbgk multigpu: rank %d: stage '%s' has not completed after %.0f s (limit %.0f s, DBGK_COLLECTIVE_TIMEOUT_S): "
+                     "the ranks have diverged or a peer is gone -- leaving\n" % (rank, st["name"], now - st["t0"], st["limit"])).encode())
+        os._exit(17)
+
+    def _close(self, sid, ms):
+        st = self.open.pop(sid)
+        self.log.append({"stage": st["name"], "ms": float(ms), "bytes_out": int(st["bytes_out"]), "bytes_in": int(st["bytes_in"]), "peers": int(st["peers"])})
+
+    def begin(self, name, bytes_out, bytes_in, peers, on_gpu):
+        with self.lock:
+            if self.thread is None:
+                self.thread = threading.Thread(target=self._watch, daemon=True, name="dbgk-collective-watchdog")
+                self.thread.start()
+            sid = self.next_id
+            self.next_id += 1
+            st = {"name": name, "t0": time.perf_counter(), "limit": self.timeout_s(), "bytes_out": bytes_out, "bytes_in": bytes_in, "peers": peers}
+            if on_gpu:
+                st["start_event"] = torch.cuda.Event(enable_timing=True)
+                st["start_event"].record()
+            self.open[sid] = st
+            return sid
+
+    def end(self, sid):
+        with self.lock:
+            st = self.open.get(sid)
+            if st is None:
+                return
+            if "start_event" in st:   # asynchronous transport: the stage stays open until the device has passed this point
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                st["end_event"] = ev
+            else:
+                self._close(sid, (time.perf_counter() - st["t0"]) * 1e3)
+
+    def drain(self):
+        """stages completed so far, summed by name (transfers still in flight stay open); the log is emptied"""
+        with self.lock:
+            for sid, st in list(self.open.items()):
+                ev = st.get("end_event")
+                if ev is not None and ev.query():
+                    self._close(sid, st["start_event"].elapsed_time(ev))
+            out = {}
+            for e in self.log:
+                d = out.setdefault(e["stage"], {"calls": 0, "ms": 0.0, "bytes_out": 0, "bytes_in": 0, "peers": e["peers"]})
+                d["calls"] += 1
+                d["ms"] += e["ms"]
+                d["bytes_out"] += e["bytes_out"]
+                d["bytes_in"] += e["bytes_in"]
+            self.log = []
+            return out
 
 
-def all_gather(outs, t, group=None):
-    if _host_staged(t, group):
-        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
-        dist.all_gather(hs, t.cpu(), group=group)
-        for o, h in zip(outs, hs):
-            o.copy_(h)
-    else:
-        dist.all_gather(outs, t, group=group)
+_STAGES = _Stages()
 
 
-def broadcast(buf, src, group=None):
-    if _host_staged(buf, group):
-        h = buf.cpu()
-        dist.broadcast(h, src=src, group=group)
-        buf.copy_(h)
-    else:
-        dist.broadcast(buf, src=src, group=group)
+class stage:
+    """with stage("exchange piece 3", bytes_out=..., bytes_in=..., peers=7, on_gpu=True): <collective calls>"""
+
+    def __init__(self, name, bytes_out=0, bytes_in=0, peers=0, on_gpu=False):
+        self.args = (name, bytes_out, bytes_in, peers, on_gpu)
+
+    def __enter__(self):
+        self.sid = _STAGES.begin(*self.args)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _STAGES.end(self.sid)
+        return False
 
 
-def _run_p2p(sends, recvs, group):
+def stage_summary():
+    """{stage name: calls, ms, bytes_out, bytes_in, peers} of the collectives completed since the last call"""
+    return _STAGES.drain()
+
+
+def _nbytes(t):
+    return int(t.numel()) * int(t.element_size())
+
+
+def _async(t, group):
+    return bool(t.is_cuda) and dist.get_backend(group) == "nccl"
+
+
+def all_reduce(t, op, group=None, name="all-reduce"):
+    with stage(name, _nbytes(t), _nbytes(t), dist.get_world_size(group) - 1, _async(t, group)):
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=group)
+
+
+def all_to_all_single(out, inp, group=None, name="all-to-all"):
+    world = dist.get_world_size(group)
+    with stage(name, _nbytes(inp) * (world - 1) // world, _nbytes(out) * (world - 1) // world, world - 1, _async(out, group)):
+        if _host_staged(out, group):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h, inp.cpu(), group=group)
+            out.copy_(h)
+        else:
+            dist.all_to_all_single(out, inp, group=group)
+
+
+def all_gather(outs, t, group=None, name="all-gather"):
+    with stage(name, _nbytes(t) * (len(outs) - 1), sum(_nbytes(o) for o in outs) - _nbytes(t), len(outs) - 1, _async(t, group)):
+        if _host_staged(t, group):
+            hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+            dist.all_gather(hs, t.cpu(), group=group)
+            for o, h in zip(outs, hs):
+                o.copy_(h)
+        else:
+            dist.all_gather(outs, t, group=group)
+
+
+def broadcast(buf, src, group=None, name="broadcast"):
+    with stage(name, _nbytes(buf), _nbytes(buf), dist.get_world_size(group) - 1, _async(buf, group)):
+        if _host_staged(buf, group):
+            h = buf.cpu()
+            dist.broadcast(h, src=src, group=group)
+            buf.copy_(h)
+        else:
+            dist.broadcast(buf, src=src, group=group)
+
+
+def _run_p2p(sends, recvs, group, name="point-to-point batch"):
     """sends / recvs: lists of (tensor view, peer).  One batch of point-to-point transfers, complete on return (NCCL: the
     current stream is ordered behind it)."""
     if not sends and not recvs:
         return
-    staged = _host_staged((sends or recvs)[0][0], group)
-    ops, landing = [], []
-    for t, peer in sends:
-        ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group))
-    for t, peer in recvs:
-        h = torch.empty(t.shape, dtype=t.dtype) if staged else t
-        landing.append((t, h))
-        ops.append(dist.P2POp(dist.irecv, h, peer, group))
-    for work in dist.batch_isend_irecv(ops):
-        work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
-    if staged:
-        for t, h in landing:
-            t.copy_(h)
+    first = (sends or recvs)[0][0]
+    staged = _host_staged(first, group)
+    with stage(name, sum(_nbytes(t) for t, _ in sends), sum(_nbytes(t) for t, _ in recvs), len({p for _, p in sends} | {p for _, p in recvs}), _async(first, group)):
+        ops, landing = [], []
+        for t, peer in sends:
+            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group))
+        for t, peer in recvs:
+            h = torch.empty(t.shape, dtype=t.dtype) if staged else t
+            landing.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, peer, group))
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()  # NCCL: orders the current stream behind the transfer; gloo: blocks until done
+        if staged:
+            for t, h in landing:
+                t.copy_(h)
 
 
-def exchange_slices(pairs, rank, group=None):
+def exchange_slices(pairs, rank, group=None, name="exchange"):
     """pairs: list of (send_view, recv_view, peer) of uint8 tensors, equal sizes on both ends of a pair.
     Moves send_view of every pair to the peer's recv_view."""
     longest = max([int(sv.numel()) for sv, _, _ in pairs] + [0])
@@ -168,10 +298,10 @@ def exchange_slices(pairs, rank, group=None):
             else:
                 sends.append((sv[off:hi], peer))
                 recvs.append((rv[off:hi], peer))
-        _run_p2p(sends, recvs, group)
+        _run_p2p(sends, recvs, group, name)
 
 
-def _exchange_uneven(pairs, rank, group=None):
+def _exchange_uneven(pairs, rank, group=None, name="exchange (uneven)"):
     """like exchange_slices, but the two directions of a pair have their own lengths"""
     longest = max([max(int(sv.numel()), int(rv.numel())) for sv, rv, _ in pairs] + [0])
     for off in range(0, longest, MAX_MESSAGE_BYTES):
@@ -187,7 +317,7 @@ def _exchange_uneven(pairs, rank, group=None):
                 sends.append((sv[off:min(sn, off + MAX_MESSAGE_BYTES)], peer))
             if off < rn:
                 recvs.append((rv[off:min(rn, off + MAX_MESSAGE_BYTES)], peer))
-        _run_p2p(sends, recvs, group)
+        _run_p2p(sends, recvs, group, name)
 
 
 def exchange_and_merge(engine, group=None):
@@ -274,13 +404,13 @@ def wrap_device_memory(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def _exchange_range(send, recv, info, j0, j1, world, rank, group):
+def _exchange_range(send, recv, info, j0, j1, world, rank, group, name="level-1 exchange"):
     """buckets [j0, j1) of every destination's chunk -> the same buckets of chunk `rank` at the destination"""
     pairs = []
     for peer in range(world):
         lo, hi = peer * info.chunk_bytes + j0 * info.bucket_bytes, peer * info.chunk_bytes + j1 * info.bucket_bytes
         pairs.append((send[lo:hi], recv[lo:hi], peer))
-    exchange_slices(pairs, rank, group)
+    exchange_slices(pairs, rank, group, name)
 
 
 def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
@@ -303,11 +433,11 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
 
     # 1. per-bucket k-mer counts of the whole job
     bucket_counts = send_cnt.view(torch.int32).to(torch.int64)
-    all_reduce(bucket_counts, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(bucket_counts, op=dist.ReduceOp.SUM, group=group, name="bucket-count all-reduce")
     records_global = int(bucket_counts.sum().item())
 
     # 2. the exchange
-    all_to_all_single(recv_cnt, send_cnt, group=group)
+    all_to_all_single(recv_cnt, send_cnt, group=group, name="fill-count all-to-all")
     # every own bucket must have received exactly what the all-reduce says the job holds for it (counts are capped by the
     # bucket capacity on both sides alike): a wrong fill count would silently drop or invent records
     B = int(info.buckets_per_rank)
@@ -315,12 +445,12 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
     mine = recv_cnt.view(torch.int32).to(torch.int64).view(world, per).sum(dim=0)
     want = bucket_counts.view(world, per)[rank]
     flag = torch.tensor([0 if bool(torch.equal(mine, want)) else 1], dtype=torch.int64, device=device)
-    all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    all_reduce(flag, op=dist.ReduceOp.MAX, group=group, name="fill-count agreement")
     if int(flag.item()):
         raise RuntimeError("rank %d: the exchanged bucket fill counts disagree with the all-reduced totals (here or on another rank)" % rank)
     n_chunks = max(1, min(int(exchange_chunks), B))
     if n_chunks <= 1:
-        _exchange_range(send, recv, info, 0, B, world, rank, group)
+        _exchange_range(send, recv, info, 0, B, world, rank, group, "level-1 exchange (one piece)")
         if on_gpu:
             torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
     else:
@@ -329,8 +459,8 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
         per = (B + n_chunks - 1) // n_chunks
         ranges = [(j0, min(j0 + per, B)) for j0 in range(0, B, per)]
         arrived = []
-        for j0, j1 in ranges:  # all transfers are queued before anything is waited for
-            _exchange_range(send, recv, info, j0, j1, world, rank, group)
+        for piece, (j0, j1) in enumerate(ranges):  # all transfers are queued before anything is waited for
+            _exchange_range(send, recv, info, j0, j1, world, rank, group, "level-1 exchange piece %d of %d" % (piece, len(ranges)))
             if on_gpu:
                 ev = torch.cuda.Event()
                 ev.record()
@@ -352,10 +482,10 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
         sent = torch.stack([send[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
         got = torch.stack([recv[p * cb:(p + 1) * cb].view(torch.int64).sum() for p in range(world)])
         theirs = torch.empty_like(sent)
-        all_to_all_single(theirs, sent, group=group)   # theirs[p] = checksum of what rank p sent to me
+        all_to_all_single(theirs, sent, group=group, name="exchange checksums")   # theirs[p] = checksum of what rank p sent to me
         bad = [p for p in range(world) if int(theirs[p]) != int(got[p])]
         flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=device)
-        all_reduce(flag, op=dist.ReduceOp.MAX, group=group)   # every rank stops, not only the one that saw it (no rank is left waiting)
+        all_reduce(flag, op=dist.ReduceOp.MAX, group=group, name="exchange checksum agreement")   # every rank stops, not only the one that saw it (no rank is left waiting)
         if int(flag.item()):
             raise RuntimeError("rank %d: the level-1 record buckets received from rank(s) %r differ from what was sent "
                                "(a truncated or corrupted transfer%s)" % (rank, bad, "" if bad else " seen by another rank"))
@@ -363,12 +493,12 @@ def _exchange_level1(g, device, group, wrap, exchange_chunks, verify):
     return records_global
 
 
-def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
+def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu, name="list gather"):
     """all-gather of one device list per rank (n entries of node_bytes): -> (sizes per rank, padded tensors per rank)"""
     world = dist.get_world_size(group)
     sizes = torch.tensor([n], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    all_gather(all_sizes, sizes, group=group)
+    all_gather(all_sizes, sizes, group=group, name=name + ": sizes")
     all_sizes = torch.stack(all_sizes).cpu().numpy()[:, 0]
     longest = int(all_sizes.max())
     if not longest:
@@ -377,7 +507,7 @@ def _gather_lists(ptr, n, node_bytes, device, group, wrap, on_gpu):
     if n:
         mine[:n * node_bytes] = wrap(ptr, n * node_bytes, device)
     lists = [torch.empty_like(mine) for _ in range(world)]
-    all_gather(lists, mine, group=group)
+    all_gather(lists, mine, group=group, name=name)
     if on_gpu:
         torch.cuda.synchronize()  # device-wide: also the communication stream RCCL works on
     return all_sizes, lists
@@ -387,7 +517,7 @@ def _agree(ok, what, device, group):
     """every rank learns whether ANY rank failed a local step, so that all of them leave together (a rank that raised alone
     would leave the others waiting in the next collective): all-reduce (min) of an ok flag, then the same exception everywhere"""
     flag = torch.tensor([1 if ok is None else 0], dtype=torch.int64, device=device)
-    all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    all_reduce(flag, op=dist.ReduceOp.MIN, group=group, name="agreement: " + what)
     if int(flag.item()) == 0:
         raise RuntimeError("%s failed on %s" % (what, ("this rank: %s" % ok) if ok is not None else "another rank"))
 
@@ -420,7 +550,7 @@ def _hand_offs(g, device, group, wrap, node_bytes):
         return box["v"]
 
     p_ovf, n_ovf = fetch(g.shard_overflow, "reading the bucket-overflow list")
-    ovf_sizes, lists = _gather_lists(p_ovf, n_ovf, node_bytes, device, group, wrap, on_gpu)
+    ovf_sizes, lists = _gather_lists(p_ovf, n_ovf, node_bytes, device, group, wrap, on_gpu, "bucket-overflow observations")
     if lists is not None:
         def merge_observations():
             for src in range(world):
@@ -431,13 +561,13 @@ def _hand_offs(g, device, group, wrap, node_bytes):
     p_hh, n_hh = fetch(g.shard_heavy, "reading the heavy-hitter side table")
     sizes = torch.tensor([n_hh], dtype=torch.int64, device=device)
     hh_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    all_gather(hh_sizes, sizes, group=group)
+    all_gather(hh_sizes, sizes, group=group, name="heavy-hitter table sizes")
     hh_sizes = torch.stack(hh_sizes).cpu().numpy()[:, 0]
     for src in range(world):
         if hh_sizes[src]:
             nbytes = int(hh_sizes[src]) * node_bytes
             buf = wrap(p_hh, nbytes, device).clone() if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
-            broadcast(buf, src=src, group=group)
+            broadcast(buf, src=src, group=group, name="heavy-hitter table of rank %d" % src)
             if on_gpu:
                 torch.cuda.synchronize()
             _agree(attempt(lambda: g.shard_merge(buf.data_ptr(), int(hh_sizes[src]))), "merging a heavy-hitter side table", device, group)
@@ -447,7 +577,8 @@ def _hand_offs(g, device, group, wrap, node_bytes):
     for rnd in range(world + 1):
         p_out, n_out = fetch(g.shard_outgoing, "reading the list of nodes that left the shard")
         fresh = int(n_out) - delivered
-        out_sizes, lists = _gather_lists(int(p_out) + delivered * node_bytes if fresh else p_out, fresh, node_bytes, device, group, wrap, on_gpu)
+        out_sizes, lists = _gather_lists(int(p_out) + delivered * node_bytes if fresh else p_out, fresh, node_bytes, device, group, wrap, on_gpu,
+                                         "ring hand-off round %d" % rnd)
         moved = int(out_sizes.sum())   # (the same number on every rank: all of them leave the loop, or fail, together)
         if moved == 0:
             break
@@ -483,7 +614,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8, verify
     # 5. key-0 node onto rank 0, totals
     links = torch.tensor([int(st.polyA_l_link), int(st.polyA_r_link)], dtype=torch.int64, device=device)
     all_links = [torch.zeros_like(links) for _ in range(world)]
-    all_gather(all_links, links, group=group)
+    all_gather(all_links, links, group=group, name="key-0 links gather")
     if rank == 0:
         for src in range(1, world):
             l, r = (int(x) for x in all_links[src].cpu().numpy())
@@ -491,7 +622,7 @@ def sharded_finalize(g, device, group=None, wrap=None, exchange_chunks=8, verify
                 g.add_polyA(l, r)
     owned = g.refresh_stats()
     tot = torch.tensor([local[0], local[1], local[2], int(owned.count)], dtype=torch.int64, device=device)
-    all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(tot, op=dist.ReduceOp.SUM, group=group, name="totals all-reduce")
     tot = tot.cpu().numpy()
     return {"total_reads": int(tot[0]), "total_kmers": int(tot[1]), "stored_kmers": int(tot[2]), "count": int(tot[3]),
             "owned_count": int(owned.count), "records_global": records_global,

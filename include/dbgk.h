@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DBGK_ABI_VERSION 5
+#define DBGK_ABI_VERSION 6
 
 /* status codes */
 #define DBGK_OK               0
@@ -429,6 +429,24 @@ typedef struct dbgk_shard_info {
 	uint32_t buckets_per_rank, own_buckets;
 	uint64_t bucket_bytes, cnt_bucket_bytes;
 } dbgk_shard_info;
+
+/* The geometry a PARTITION handle of these parameters would get -- level-1 bucket width, fan-outs, this shard's slot range and
+ * buckets, the bytes of its table shard and record stores -- WITHOUT touching a device (ABI 6): what a multi-GPU launcher plans
+ * with before any rank has created its handle (bench.py --plan-only, tests/test_multigpu_gloo.py).  shard_count 0 = one
+ * unsharded handle.  DBGK_ERR_ARG when the engine cannot take the table (2^26 <= table_slots < 2^34).                        */
+typedef struct dbgk_plan_info {
+	uint64_t table_slots;          /* the (global) table                                                       */
+	uint32_t r;                    /* level-1 bucket = slot >> r                                               */
+	uint32_t level1_buckets;       /* of the global table                                                      */
+	uint32_t final_per_level1;     /* 4096-slot regions per level-1 bucket = level-2 fan-out                   */
+	uint32_t three_level;          /* 1: level 2 runs as two passes (tables of 2^33 slots and more)            */
+	uint32_t buckets_per_rank, own_buckets, first_bucket;
+	uint32_t reserved;
+	uint64_t slot_lo, slot_hi;     /* this shard's slot range                                                  */
+	uint64_t records_per_level1_bucket, records_per_final_bucket; /* capacities                               */
+	uint64_t table_bytes, level1_store_bytes, inbox_bytes, final_store_bytes; /* device memory of this shard   */
+} dbgk_plan_info;
+int dbgk_plan_partition(uint64_t table_slots, uint64_t expected_kmers, uint32_t shard_count, uint32_t shard_index, dbgk_plan_info *out);
 
 int dbgk_shard_buffers(dbgk_handle *h, dbgk_shard_info *out);
 int dbgk_shard_mark_exchanged(dbgk_handle *h);

@@ -643,8 +643,8 @@ def _corrupt_worker(rank, world, port, reads, k, size, q):
     g = FakeShardGraph(O, reads[rank::world], k, world, rank, size)
     real = M._exchange_range
 
-    def truncated(send, recv, info, j0, j1, world_, rank_, group):   # rank 1 "receives" only part of what rank 0 sent it
-        real(send, recv, info, j0, j1, world_, rank_, group)
+    def truncated(send, recv, info, j0, j1, world_, rank_, group, name="level-1 exchange"):   # rank 1 "receives" only part of what rank 0 sent it
+        real(send, recv, info, j0, j1, world_, rank_, group, name)
         if rank_ == 1:
             lo = 0 * info.chunk_bytes + j0 * info.bucket_bytes
             recv[lo + 16:lo + 64] = 0
@@ -770,3 +770,69 @@ def test_ring_hand_off_repeats_until_nothing_moves_and_all_ranks_fail_together(s
             assert sum("this rank" in r[2] for r in res) == 1 and sum("another rank" in r[2] for r in res) == 2
         else:
             assert all("the table is full" in r[2] for r in res)
+
+
+# ---- first-contact hardening: a collective that cannot complete ends the process with the stage's name ----------------------
+def _diverge_worker(rank, world, port, q):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dbg_assembly_amd import multigpu as M
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DBGK_COLLECTIVE_TIMEOUT_S"] = "3"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(4, dtype=torch.int64)
+    M.all_reduce(t, op=dist.ReduceOp.SUM, name="bucket-count all-reduce")   # everyone takes part: completes, is logged
+    q.put((rank, "first", M.stage_summary()))
+    if rank == 0:
+        M.all_reduce(t, op=dist.ReduceOp.SUM, name="exchange piece 3 of 8")   # rank 1 never joins this one
+        q.put((rank, "returned", None))
+    else:
+        time.sleep(30)   # "took another branch": the watchdog of rank 0 must end rank 0 long before this
+
+
+def test_a_collective_that_cannot_complete_ends_the_process_with_the_stage_name(capfd):
+    """multigpu.stage: every collective runs under a wall-clock limit (DBGK_COLLECTIVE_TIMEOUT_S); when the ranks diverge, the
+    rank that waits leaves with exit code 17 and names the stage on stderr instead of hanging the job; completed stages are
+    logged with their bytes and peers (bench.py's rccl.stages)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    first = dict((r, s) for r, _, s in (q.get(timeout=60) for _ in range(2)))
+    for r in (0, 1):
+        st = first[r]["bucket-count all-reduce"]
+        assert st["calls"] == 1 and st["bytes_out"] == 32 and st["peers"] == 1 and st["ms"] >= 0.0
+    procs[0].join(timeout=40)
+    assert procs[0].exitcode == 17, procs[0].exitcode
+    procs[1].terminate()
+    procs[1].join(timeout=20)
+    assert q.empty(), "the all-reduce nobody else joined must not return"
+    err = capfd.readouterr().err
+    assert "stage 'exchange piece 3 of 8' has not completed" in err and "rank 0" in err
+
+
+def test_bench_plans_its_geometry_for_2_4_and_8_ranks_without_a_gpu():
+    """`bench.py --gpus N` dry run of the argument / geometry planning for N = 2, 4, 8 (no GPU call): the table sizes, per-rank
+    shares and level-1 bucket ownership the sharded flow would use -- what the first run on a real node starts from"""
+    import subprocess
+    import sys
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for config in ("cfg2", "cfg3"):
+        for n in (2, 4, 8):
+            out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", config, "--plan-only"],
+                                 check=True, capture_output=True, text=True).stdout
+            plan = json.loads(out.strip().splitlines()[-1])
+            assert plan["world"] == n and plan["config"] == config
+            assert plan["table_slots_global"] < 2 ** 34 and plan["table_slots_global"] >= 2 ** 26
+            assert plan["level1_buckets"] <= 1024 and plan["buckets_per_rank"] * n >= plan["level1_buckets"]
+            assert sum(plan["own_buckets"]) == plan["level1_buckets"] and all(b > 0 for b in plan["own_buckets"])
+            assert plan["records_per_rank"] == plan["reads_per_gpu"] * 120
+            # what a rank holds must fit one MI355X (288 GB): its table shard, the level-1 store it fills and the inbox it receives
+            assert plan["bytes_per_rank"]["total"] < 288e9
+            if config == "cfg2":
+                assert plan["table_slots_global"] < 2 ** 32, "cfg2 keeps the global table below 2^32 slots (level-2 fan-out 1024)"
