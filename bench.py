@@ -188,7 +188,7 @@ def live_traffic(args):
         for counter in sums:
             out_dir = os.path.join(work, counter)
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                   "--steps", "1", "--warmup", "0", "--brief", "--no-live-traffic", "--config", args.config, "--input", args.input,
+                   "--steps", "1", "--warmup", "1", "--brief", "--no-live-traffic", "--config", args.config, "--input", args.input,
                    "--engine", str(args.engine), "--reads-per-gpu", str(args.reads_per_gpu), "--genome-per-gpu", str(args.genome_per_gpu),
                    "--table-slots", str(args.table_slots), "--kmer", str(args.kmer)]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
@@ -196,13 +196,17 @@ def live_traffic(args):
             if r.returncode != 0 or not files:
                 print("live traffic: the %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:]), file=sys.stderr)
                 return None
+            # the child runs one warm-up step and one timed step (first-step one-off work is excluded): only the launches of the LAST
+            # step count -- everything from the last dbgk_reset (k_zero_list) on
+            rows = []
             for f in files:
-                for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") != counter:
-                        continue
-                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("dbgk::", "")
-                    if any(k.startswith(w) for w in TRAFFIC_KERNELS):
-                        sums[counter]["k_prefix_*" if k.startswith("k_prefix") else k] += float(row["Counter_Value"])
+                rows += [row for row in csv.DictReader(open(f)) if row.get("Counter_Name") == counter]
+            rows.sort(key=lambda row: int(row.get("Start_Timestamp") or row.get("Dispatch_Id") or 0))
+            resets = [i for i, row in enumerate(rows) if "k_zero_list" in row["Kernel_Name"]]
+            for row in rows[(resets[-1] if resets else 0):]:
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("dbgk::", "")
+                if any(k.startswith(w) for w in TRAFFIC_KERNELS):
+                    sums[counter]["k_prefix_*" if k.startswith("k_prefix") else k] += float(row["Counter_Value"])
     except Exception as e:  # noqa: BLE001  (a profiler that is missing or refuses to run must not take the bench line with it)
         print("live traffic: %s" % e, file=sys.stderr)
         return None
@@ -441,6 +445,7 @@ def setup_process(args):
     c.multi = c.world > 1 or args.force_sharded
     c.dev_index, c.device = start_ranks(args, torch, dist, c.world, c.local_rank, single=args.force_sharded)
     c.copy_bw = None
+    c.copy_bw_memcpy = None
     return c
 
 
@@ -448,7 +453,7 @@ def copy_bandwidth(ctx, g):
     """the measured-HBM denominator, once per process (N = 1): best of the runtime's DtoD memcpy and the library's own copy kernels"""
     if ctx.copy_bw is None and ctx.world == 1:
         try:
-            ctx.copy_bw = g.copy_bandwidth(PROBE_BYTES, 5)
+            ctx.copy_bw, ctx.copy_bw_memcpy = g.copy_bandwidth_detail(PROBE_BYTES, 5)
         except Exception as e:  # noqa: BLE001
             print("copy bandwidth probe failed: %s" % e, file=sys.stderr)
     return ctx.copy_bw
@@ -626,6 +631,9 @@ def run_kfreq(args, ctx, brief=False):
                "roofline": {"bound": "hbm", "kernel": "whole step: " + ("" if blocks else "reset -> ") + " -> ".join(ms) + ("" if blocks else " -> table summary"), "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
+                         "copy_bandwidth_hipmemcpy_GBs": ctx.copy_bw_memcpy,
+                         "frac_of_measured_definition": "achieved / copy_bandwidth_GBs; the denominator is the best of the library's own copy kernels (16 B per lane, "
+                                                        "2 GiB buffers, default and non-temporal, 1 and 2 workgroups per CU) and hipMemcpyDtoD, read + written bytes, same run",
                             "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step, "traffic": traffic,
                             "own_bytes_per_step": own_total,
                             "own_traffic_ratio": own_total / (kmers_step * b_alg),
@@ -981,11 +989,15 @@ def run_graph(args, ctx, brief=False):
             "roofline": {"bound": "hbm", "kernel": "whole step: " + " -> ".join(kernel_ms), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured": achieved / copy_bw if copy_bw else None, "copy_bandwidth_GBs": copy_bw,
+                         "copy_bandwidth_hipmemcpy_GBs": ctx.copy_bw_memcpy,
+                         "frac_of_measured_definition": "achieved / copy_bandwidth_GBs; the denominator is the best of the library's own copy kernels (16 B per lane, "
+                                                        "2 GiB buffers, default and non-temporal, 1 and 2 workgroups per CU) and hipMemcpyDtoD, read + written bytes, same run",
                          "bytes_per_kmer": b_alg, "kmers_per_step": kmers_step, "step_ms": ms_per_step,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else (sum(live.values()) if live else measured_traffic(args, size, None)),
                          "traffic_source": "--traffic-bytes" if args.traffic_bytes is not None else
                                            ("measured in this run: two child processes of this bench (one step each) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                                             "KiB, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)" if live else "profiles/traffic_r*.json (committed PMC passes of this workload)"),
+                         "traffic_measured_in_run": bool(live) and args.traffic_bytes is None,
                          "traffic_committed": measured_traffic(args, size, None),
                          "kernels_only_ms": pipeline_ms, "kernels_only_frac": kmers_step * b_alg / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "l2_build_wall_ms": wall_ms, "l2_build_chunks": chunks, "kernels": kernels},

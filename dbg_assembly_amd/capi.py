@@ -183,6 +183,7 @@ SYMBOLS = [
     ("dbgk_reset_timings", _i, [_vp]),
     ("dbgk_stream", _vp, [_vp]),
     ("dbgk_measure_copy_bandwidth", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double)]),
+    ("dbgk_measure_copy_bandwidth2", _i, [_vp, C.c_size_t, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dbgk_measure_gather_bandwidth", _i, [_vp, C.c_size_t, _u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dbgk_device_count", _i, []),
     ("dbgk_abi_version", _i, []),
@@ -640,6 +641,12 @@ class Graph:
         g = C.c_double()
         _chk(lib().dbgk_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "dbgk_measure_copy_bandwidth")
         return g.value
+
+    def copy_bandwidth_detail(self, nbytes=1 << 30, iters=10):
+        """(best of the library's copy kernels and the runtime's memcpy, the runtime's hipMemcpyDtoD alone), GB/s read + written"""
+        g, m = C.c_double(), C.c_double()
+        _chk(lib().dbgk_measure_copy_bandwidth2(self._h, nbytes, iters, C.byref(g), C.byref(m)), "dbgk_measure_copy_bandwidth2")
+        return g.value, m.value
 
     def gather_bandwidth(self, nbytes=16 << 30, n_accesses=1 << 30):
         """random 64-byte sectors of an nbytes buffer: (GB/s, G sectors/s)"""

@@ -546,6 +546,8 @@ void *dbgk_stream(dbgk_handle *h);
  * memcpy and this library's own streaming copy kernels (16 bytes per lane, default and non-temporal policy, 1 and 2 workgroups
  * per CU) over two buffers of `bytes` each (use >= 2 GiB: far beyond the 256 MiB Infinity Cache), `iters` copies per variant   */
 int dbgk_measure_copy_bandwidth(dbgk_handle *h, size_t bytes, int iters, double *gbps);
+/* the same, and the runtime's hipMemcpyDtoD figure alone next to the best (ABI 6): bench.py reports both denominators */
+int dbgk_measure_copy_bandwidth2(dbgk_handle *h, size_t bytes, int iters, double *gbps, double *runtime_memcpy_gbps);
 /* random 64-byte gather over a buffer of `bytes` (the practical random-access ceiling of the engines
  * that touch one random node per k-mer occurrence): n_accesses sectors fetched, GB/s and G sectors/s             */
 int dbgk_measure_gather_bandwidth(dbgk_handle *h, size_t bytes, uint64_t n_accesses, double *gbps, double *gaccesses_per_s);
