@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic_r04.json from the PMC summaries of profiles/run_profile.sh (gpurun_out/prof_<tag>/pmc_summary.csv):
+"""profiles/traffic_r05.json (TRAFFIC_OUT) from the PMC summaries of profiles/run_profile.sh (gpurun_out/prof_<tag>/pmc_summary.csv):
 HBM bytes per STEP and kernel = FETCH_SIZE (KiB; doubled for these kernels' coalesced streaming reads, MI355X_MICROARCH.md section HBM)
 + WRITE_SIZE (KiB, as is), summed over the launches of the one step each PMC pass runs.
     python profiles/make_traffic.py tag:config:reads:kmer:table_slots:engine:input[:kernel-prefixes] ..."""
@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/run_profile.sh <tag> [--config ...]: bench.py --steps 1 "
-                      "--warmup 0 --brief under the profiler), round-4 kernels.  PER STEP; kernels launched once per bucket chunk are summed.  "
+                      "--warmup 0 --brief under the profiler), kernels of the round that made the file.  PER STEP; kernels launched once per bucket chunk are summed.  "
                       "Counter values are KiB; FETCH_SIZE doubled, WRITE_SIZE as is (MI355X_MICROARCH.md, section HBM).  Made by profiles/make_traffic.py.",
        "workloads": []}
 for spec in sys.argv[1:]:
@@ -34,6 +34,6 @@ for spec in sys.argv[1:]:
     out["workloads"].append({"workload": {"config": config, "reads_per_gpu": reads, "kmer": kmer, "table_slots": slots, "engine": engine, "input": inp, "tag": tag},
                              "bytes_per_launch": per,
                              "fetch_KiB_as_counted": dict(fetch), "write_KiB": dict(write)})
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_r04.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", os.environ.get("TRAFFIC_OUT", "traffic_r05.json")), "w"), indent=1)
 for w in out["workloads"]:
     print(w["workload"]["tag"], {k: "%.2f GB" % (v / 1e9) for k, v in w["bytes_per_launch"].items()}, "sum %.2f GB" % (sum(w["bytes_per_launch"].values()) / 1e9))
