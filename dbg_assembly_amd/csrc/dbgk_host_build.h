@@ -31,20 +31,20 @@ template <int DBG>
 static void launch_l2(dbgk_handle *h, int grid, uint32_t j0, uint32_t j1)
 {
 	if (h->three) { // mid pass, plan of the mid buckets filled so far, final pass (see the handle's comment)
-		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->g_mid, h->s_mid, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(l2_threads(kMaxBuckets)), sizeof(ScatterLdsL2), h->stream, h->g_mid, h->s_mid, h->tile_prefix, h->d_ctr, j0, j1);
 		hipLaunchKernelGGL(k_plan_l2, dim3(1), dim3(kMaxBuckets), 0, h->stream, h->g_fin, h->s_fin, h->tile_prefix2);
-		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->g_fin, h->s_fin, h->tile_prefix2, h->d_ctr,
+		hipLaunchKernelGGL(k_scatter_l2<0>, dim3(grid), dim3(l2_threads(kMaxBuckets)), sizeof(ScatterLdsL2), h->stream, h->g_fin, h->s_fin, h->tile_prefix2, h->d_ctr,
 		                   j0 * h->fan_mid, j1 * h->fan_mid);
 		return;
 	}
 	if (h->geom.n2 > 2048u) // tables of 2^33 slots and more
-		hipLaunchKernelGGL((k_scatter_l2<0, 4096>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<4096>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL((k_scatter_l2<0, 4096>), dim3(grid), dim3(l2_threads(4096)), sizeof(ScatterLdsL2T<4096>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else if (h->geom.n2 > (uint32_t)kMaxBuckets) // 2^32 .. 2^33 slots
-		hipLaunchKernelGGL((k_scatter_l2<0, 2048>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2T<2048>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL((k_scatter_l2<0, 2048>), dim3(grid), dim3(l2_threads(2048)), sizeof(ScatterLdsL2T<2048>), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else if (h->geom.kf == 2u) // KFREQ, direct blocks: 32-bit level-1 records (n2 <= 1024 always)
-		hipLaunchKernelGGL((k_scatter_l2<0, kMaxBuckets, true>), dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL((k_scatter_l2<0, kMaxBuckets, true>), dim3(grid), dim3(l2_threads(kMaxBuckets)), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 	else
-		hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(kL2Threads), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
+		hipLaunchKernelGGL(k_scatter_l2<DBG>, dim3(grid), dim3(l2_threads(kMaxBuckets)), sizeof(ScatterLdsL2), h->stream, h->geom, h->store, h->tile_prefix, h->d_ctr, j0, j1);
 }
 
 static RedoList redo_list(dbgk_handle *h)

@@ -92,6 +92,7 @@ static int plan_partition(dbgk_handle *h)
 		G.r_rec = r;
 		G.l2_shift = kKfBlockBits - (uint32_t)kRegionBits; // level 2 splits by block, not by 4096-slot region
 		G.kf = 2u;
+		G.l2_records = 16u * (uint32_t)l2_threads((int)G.n2);
 		G.kf_mask = (uint32_t)((1ull << (bits - kKfBlockBits)) - 1ull);
 		if (G.n1 > (uint32_t)kL1MaxB || G.n2 > (uint32_t)kMaxBuckets) return DBGK_OK; // (cannot happen for 13 <= k <= 18)
 		h->shard_rank = 0;
@@ -163,6 +164,7 @@ static int plan_partition(dbgk_handle *h)
 	G.cap2 = (G.cap2 + 15u) & ~15ull;
 	G.r_rec = r;
 	G.l2_shift = 0;
+	G.l2_records = 16u * (uint32_t)l2_threads((int)G.n2);
 	h->tslots = G.slot_hi - G.slot_lo;
 	h->sharded = want_shard;
 	h->part = true;
@@ -177,6 +179,7 @@ static int plan_partition(dbgk_handle *h)
 		const uint64_t cap_mid = ((uint64_t)(per_slot * (double)n_ranks * (double)(1ull << (r - lg)) * 1.08) + 8192 + 15u) & ~15ull;
 		h->g_mid = G;
 		h->g_mid.n2 = h->fan_mid;
+		h->g_mid.l2_records = 16u * (uint32_t)l2_threads((int)h->fan_mid);
 		h->g_mid.l2_shift = 6;      // the low 6 bits of the final-bucket index are left to the final pass
 		h->g_mid.cap2 = cap_mid;
 		h->g_fin = G;
@@ -189,6 +192,7 @@ static int plan_partition(dbgk_handle *h)
 		h->g_fin.b_lo = G.b_lo * h->fan_mid;
 		h->g_fin.nb_own = G.nb_own * h->fan_mid;
 		h->g_fin.n2 = 64;
+		h->g_fin.l2_records = 16u * (uint32_t)l2_threads(64);
 		h->g_fin.cap1 = cap_mid;
 	}
 	return DBGK_OK;

@@ -102,6 +102,7 @@ struct PartGeom {
 	                     // fixed (lb = 0, rb = none), so the A counter of l_link is the saturating occurrence count.
 	                     // 2: DIRECT BLOCKS -- `size` is 4^k itself and slot = kf_slot_of_key(key), see below
 	uint32_t kf_mask;    // kf == 2: 2^(2k - 16) - 1, the mask of a block index
+	uint32_t l2_records; // records of a level-2 tile = 16 x the threads of the level-2 kernel this geometry is scattered by (l2_threads(n2))
 };
 
 // ---- KFREQ, direct blocks (kf == 2) --------------------------------------------------------------------------------
@@ -228,9 +229,12 @@ using ScatterLds = ScatterLdsT<kTileThreads, kL1MaxB>;   // level 1: 16384-recor
 #ifndef DBGK_L2_THREADS
 #define DBGK_L2_THREADS 512
 #endif
-constexpr int kL2Threads = DBGK_L2_THREADS;
-constexpr int kL2Records = kL2Threads * 16;
-template <int MAXB> using ScatterLdsL2T = ScatterLdsT<kL2Threads, MAXB, true>;
+// Level-2 workgroup: 1024 threads and 16 K-record tiles (140 KiB of LDS, one workgroup per CU) for fan-outs up to 1024 -- a final
+// bucket then gets 16 records = one whole 128-byte line per tile instead of half a line (round 5: level 2 alone 4.48 -> 4.09 ms on a
+// box whose HBM is on the slow side, profiles/r05_l2_1024_threads_ab.txt); the 2048- and 4096-way forms keep 512 threads and 8 K-record
+// tiles (their histograms would not fit beside a 128 KiB stage).  The tile plan (k_plan_l2) takes the tile size from PartGeom.l2_records.
+constexpr int l2_threads(int maxb) { return maxb <= 1024 ? 2 * DBGK_L2_THREADS : DBGK_L2_THREADS; }
+template <int MAXB> using ScatterLdsL2T = ScatterLdsT<l2_threads(MAXB), MAXB, true>;
 using ScatterLdsL2 = ScatterLdsL2T<kMaxBuckets>;
 constexpr int kMaxBucketsL2 = 4096;             // largest level-2 fan-out (tables below 2^34 slots)
 
@@ -1523,7 +1527,7 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 				P.l2_done[entry] = (uint32_t)done;
 				P.l2_upto[entry] = (uint32_t)filled;
 			}
-			v = (uint32_t)((filled - done + kL2Records - 1) / kL2Records);
+			v = (uint32_t)((filled - done + G.l2_records - 1) / G.l2_records);
 		}
 		uint32_t inc = v;
 #pragma unroll
@@ -1552,7 +1556,7 @@ __global__ __launch_bounds__(kMaxBuckets) void k_plan_l2(PartGeom G, PartStore P
 template <bool KF32>
 using L2RecIn = typename std::conditional<KF32, uint32_t, uint64_t>::type;
 
-template <bool KF32 = false>
+template <bool KF32 = false, int THREADS = 512>
 __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore &P, const uint32_t *__restrict__ tile_prefix,
                                              uint32_t g, uint32_t n_tiles, L2RecIn<KF32> (&rec)[16], uint32_t &b1_out, uint32_t &n_out)
 {
@@ -1570,6 +1574,7 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 	const uint32_t e = flat_to_entry(G, lo, own_j);
 	b1_out = own_j; // own bucket index j
 	const uint64_t filled = P.l2_done ? (uint64_t)P.l2_upto[e] : (P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1); // (EARLY level 2: as planned)
+	constexpr uint32_t kL2Threads = (uint32_t)THREADS, kL2Records = 16u * (uint32_t)THREADS; // (== G.l2_records: the host plans with the kernel's tile)
 	const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kL2Records + (P.l2_done ? P.l2_done[e] : 0u);
 	const uint64_t *in = P.inbox + (uint64_t)e * G.cap1;
 	const uint32_t tid = fresh_tid();
@@ -1601,8 +1606,10 @@ __device__ __forceinline__ void l2_load_tile(const PartGeom &G, const PartStore 
 }
 
 // a tile with an odd number of records (the last tile of a level-1 bucket, at most): the second half of its last pair is not a record
+template <int THREADS>
 __device__ __forceinline__ void l2_fix_odd_tail(uint64_t (&rec)[16], uint32_t n)
 {
+	constexpr uint32_t kL2Threads = (uint32_t)THREADS;
 	if (!(n & 1u)) return; // (wave-uniform)
 	const uint32_t tid = fresh_tid();
 #pragma unroll
@@ -1614,7 +1621,7 @@ __device__ __forceinline__ void l2_fix_odd_tail(uint64_t (&rec)[16], uint32_t n)
 // 130 it silently halved the occupancy and the pair of level 2 and build went from 9.2 to 12.8 ms; the forms for more buckets have
 // always run one workgroup per CU)
 template <int DBG = 0, int MAXB = kMaxBuckets, bool KF32 = false>
-__global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 256 : 1) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
+__global__ __launch_bounds__(l2_threads(MAXB), MAXB <= kMaxBuckets ? 4 : 1) void k_scatter_l2(PartGeom G, PartStore P, const uint32_t *__restrict__ tile_prefix,
                                                              Counters *__restrict__ ctr, uint32_t j0, uint32_t j1)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1635,12 +1642,12 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 	}
 	L2RecIn<KF32> nxt[16];
 	uint32_t nxt_b1, nxt_n; // own level-1 bucket index j = b1 - b_lo; records of the tile
-	l2_load_tile<KF32>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1, nxt_n);
+	l2_load_tile<KF32, l2_threads(MAXB)>(G, P, tile_prefix, lo_tile + local, hi_tile, nxt, nxt_b1, nxt_n);
 	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
 		uint64_t rec[16];
 		uint32_t bkt[16];
 		const uint32_t j = nxt_b1;
-		if constexpr (!KF32) l2_fix_odd_tail(nxt, nxt_n);
+		if constexpr (!KF32) l2_fix_odd_tail<l2_threads(MAXB)>(nxt, nxt_n);
 #pragma unroll
 		for (int u = 0; u < 16; u++) {
 			if constexpr (KF32) rec[u] = nxt[u] == ~0u ? ~0ull : (uint64_t)nxt[u];
@@ -1648,7 +1655,7 @@ __global__ __launch_bounds__(kL2Threads, MAXB <= kMaxBuckets ? 2 * kL2Threads / 
 			// an all-ones word is never a record: the neighbour fields only take the values 0..4
 			bkt[u] = (rec[u] == ~0ull) ? 0xFFFFu : ((uint32_t)(rec[u] >> (6 + kRegionBits + G.l2_shift)) & (G.n2 - 1u));
 		}
-		l2_load_tile<KF32>(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1, nxt_n); // in flight during the scatter below
+		l2_load_tile<KF32, l2_threads(MAXB)>(G, P, tile_prefix, g + n_local, hi_tile, nxt, nxt_b1, nxt_n); // in flight during the scatter below
 		// (KFREQ, direct blocks: the final buckets hold 16-bit records -- the same index arithmetic on a quarter of the bytes)
 		uint64_t *out = G.kf == 2u ? reinterpret_cast<uint64_t *>(reinterpret_cast<uint16_t *>(P.l2) + (uint64_t)j * G.n2 * G.cap2)
 		                           : P.l2 + (uint64_t)j * G.n2 * G.cap2;
