@@ -103,6 +103,10 @@ struct PartGeom {
 	                     // 2: DIRECT BLOCKS -- `size` is 4^k itself and slot = kf_slot_of_key(key), see below
 	uint32_t kf_mask;    // kf == 2: 2^(2k - 16) - 1, the mask of a block index
 	uint32_t l2_records; // records of a level-2 tile = 16 x the threads of the level-2 kernel this geometry is scattered by (l2_threads(n2))
+	uint32_t l1_pad;     // 16 or 0: level 1 pads every run it appends to a level-1 bucket to a multiple of 16 records with all-ones
+	                     // words (no record: level 2 skips them), so that every run starts and ends on a 128-byte line -- set when the
+	                     // runs are long (n1 <= 256: >= 64 records per bucket and tile); round 5: level 1 4.89 -> 4.75 ms, level 2 no
+	                     // slower for 7 % more input (profiles/r05_l1_padded_runs_ab.txt)
 };
 
 // ---- KFREQ, direct blocks (kf == 2) --------------------------------------------------------------------------------
@@ -274,7 +278,8 @@ __device__ __forceinline__ uint32_t scan_hist(LDS &L)
 // after every record has been ranked (hist complete): reserve global space, scan
 template <class LDS>
 __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[LDS::kBpt],
-                                                         uint32_t stride = 1u) // bucket b counts in cnt[b * stride]; returns the records of the tile
+                                                         uint32_t stride = 1u, // bucket b counts in cnt[b * stride]; returns the records of the tile
+                                                         uint32_t pad = 0u)    // a power of two: every reservation is rounded up to a multiple of it (PartGeom.l1_pad)
 {
 	const int t = (int)fresh_tid();
 	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
@@ -282,7 +287,7 @@ __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buck
 #pragma unroll
 	for (int j = 0; j < LDS::kBpt; j++) {
 		const uint32_t b = LDS::kBpt * t + j, c = L.hist[b];
-		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], c) : 0u;
+		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], pad ? ((c + pad - 1u) & ~(pad - 1u)) : c) : 0u;
 	}
 	const uint32_t all = scan_hist(L);
 	lds_barrier();
@@ -301,13 +306,17 @@ __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buck
 // those instantiations carry the 32-bit copy-out
 // N_SURE > 0 and `sure`: the caller knows that the lane's first N_SURE records all have a bucket (regular level-1 tiles without a
 // zero key); a wave in which every lane says so stages them without a test per record, the lbase reads issued together
-template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, int N_SURE = 0, class LDS>
+struct NoPre { __device__ __forceinline__ void operator()() const {} };
+// `pre` runs on every thread right BEFORE the barrier in front of the copy-out (the histogram has been read, the tile's packed words
+// are no longer needed): a caller whose next tile starts with LDS writes that only need "a barrier before they are read" puts them
+// there and saves the barrier of its own (the regular-tile form of level 1: the next tile's packed words and the cleared histogram)
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, int N_SURE = 0, class LDS, class Pre = NoPre>
 __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                                    const PartStore &P, Counters *ctr, uint32_t stride = 1u, // bucket b lives at out + b * stride * cap
                                                    uint32_t flat_total = 0u, // FLAT: the records of the tile (scatter_reserve_scan)
-                                                   bool sure = false)
+                                                   bool sure = false, Pre pre = Pre())
 {
 	const int t = (int)fresh_tid();
 	if (FLAT) { // the histogram has been consumed by the scan: every thread clears its own entries for the NEXT tile now, which then
@@ -341,6 +350,7 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		if (FLAT) L.desc[b] = (typename LDS::Desc)(my_gbase[j] - L.lbase[b]); // global place of staged record p of bucket b = desc[b] + p (modulo 2^32)
 		else L.desc[b] = (typename LDS::Desc)(((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b]);
 	}
+	pre();
 	lds_barrier();
 	if (FLAT) {
 		if (DBG != 2) {
@@ -415,6 +425,25 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		uint64_t *o = out + (uint64_t)b * stride * cap + dst;
 		if (DBG == 3) { // timing experiment: same instruction stream, stores land in a 32 KiB window per workgroup (no HBM write traffic)
 			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * stride * cap + dst + i) & 4095ull)] = L.stage[src + i];
+		} else if (G.l1_pad && bucket_is_b1) {
+			// padded runs (PartGeom.l1_pad): the reservation was a multiple of 16 records from a 128-byte boundary; what lies behind
+			// the run's last record is filled with all-ones words, which are no records
+			typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+			const uint32_t n_pad = (n + G.l1_pad - 1u) & ~(G.l1_pad - 1u);
+			if ((uint64_t)dst + n_pad <= cap) {
+				for (uint32_t i = 2u * lane; i < n_pad; i += 128u) {
+					const uint64_t a = i < n ? L.stage[src + i] : ~0ull, b2 = i + 1u < n ? L.stage[src + i + 1u] : ~0ull;
+					const u32x4_a16 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
+					*reinterpret_cast<u32x4_a16 *>(o + i) = v;
+				}
+			} else { // the bucket is full: records beyond its capacity go to the overflow list, the padding ends with the bucket
+				for (uint32_t i = lane; i < n_pad; i += 64) {
+					const bool is_rec = i < n;
+					const uint64_t rcd = is_rec ? L.stage[src + i] : ~0ull;
+					if ((uint64_t)dst + i < cap) o[i] = rcd;
+					else if (is_rec) push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+				}
+			}
 		} else if ((uint64_t)dst + n <= cap) {
 			// two records per lane and store instruction (16 bytes, 8-byte aligned): the memory pipe charges per instruction,
 			// whatever its lane count (level 1: 5.68 -> 5.54 ms against one record per lane, profiles/ab_bench.sh)
@@ -742,9 +771,9 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 }
 
 // after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
-template <int DBG, bool KF32_POSSIBLE = true, int N_SURE = 0>
+template <int DBG, bool KF32_POSSIBLE = true, int N_SURE = 0, class Pre = NoPre>
 __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
-                                                const uint32_t (&bkt)[16], bool sure = false)
+                                                const uint32_t (&bkt)[16], bool sure = false, Pre pre = Pre())
 {
 	lds_barrier(); // hist complete
 	// the parked records come back into registers BEFORE the reservation and the scan: the barriers inside the scan then
@@ -755,8 +784,8 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 	uint32_t my_gbase[ScatterLds::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
-	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure);
+	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub, G.l1_pad);
+	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure, pre);
 }
 
 // LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
@@ -1113,23 +1142,39 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	};
 
 	RawU raw = fetch(blockIdx.x, r0, c0);
-	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	// the tile's bytes (block tid, block tid + 1024) go into LDS packed 16 bases per word, the histogram is cleared
+	auto open_tile = [&](const RawU &rw) {
 		const uint32_t tid = fresh_tid();
-		// pack the tile's bytes (block tid, block tid + 1024) into LDS, 16 bases per word
 		if constexpr (PACKED) {
-			if (tid < raw.n_blocks) UL.pk[tid] = raw.a;
-			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = raw.b;
+			if (tid < rw.n_blocks) UL.pk[tid] = rw.a;
+			if (tid + kL1Threads < rw.n_blocks) UL.pk[tid + kL1Threads] = rw.b;
 		} else if (rb.packed) {
-			if (tid < raw.n_blocks) UL.pk[tid] = raw.a.x;
-			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = raw.b.x;
+			if (tid < rw.n_blocks) UL.pk[tid] = rw.a.x;
+			if (tid + kL1Threads < rw.n_blocks) UL.pk[tid + kL1Threads] = rw.b.x;
 		} else {
-			if (tid < raw.n_blocks) UL.pk[tid] = pack16_ascii(raw.a, rb.other_seen);
-			if (tid + kL1Threads < raw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(raw.b, rb.other_seen);
+			if (tid < rw.n_blocks) UL.pk[tid] = pack16_ascii(rw.a, rb.other_seen);
+			if (tid + kL1Threads < rw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(rw.b, rb.other_seen);
 		}
-		uint32_t bkt[16];
 #pragma unroll
 		for (int j = 0; j < SLds::kBpt; j++) L.hist[SLds::kBpt * tid + j] = 0;
+	};
+	// regular tiles (wave-per-bucket tail): the NEXT tile is opened inside the tail, right before the barrier in front of the
+	// copy-out (scatter_stage_copy `pre`: by then nobody reads the packed words or the histogram of this tile any more).  The
+	// barrier a tile begins with -- no record may be parked in the stage buffer while a slower wave still copies the last tile
+	// out of it -- then stands BEHIND the lane's decode instead of in front of it: a wave that has finished its copy-out funnels
+	// its next window out of the packed words while the others finish.  The other forms open their tile at the top of the loop
+	constexpr bool kOpenInTail = REG && !LIN && DBG == 0;
+	if (kOpenInTail && blockIdx.x < n_tiles) {
+		open_tile(raw);
 		lds_barrier();
+	}
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		uint32_t bkt[16];
+		if constexpr (!kOpenInTail) {
+			open_tile(raw);
+			lds_barrier();
+		}
 		const uint64_t p = raw.p;                        // flat position of the lane's first window
 		// the packed stream starts one base earlier (left neighbour) -- except at position 0, and (regular tiles, whose byte
 		// range starts ON a read start) for a read's first chunk, whose first window has no left neighbour anyway
@@ -1158,6 +1203,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
 			c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
 		}
+		if constexpr (kOpenInTail) lds_barrier(); // (every wave has left the copy-out of the tile before: the stage buffer is free)
 		const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile
@@ -1175,7 +1221,8 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
 		if constexpr (LIN) l1_scatter_tail_linear<DBG, C, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
-		else l1_scatter_tail<DBG, (WIDE_D >= 2), (REG ? C : 0)>(L, G, P, ctr, tid, bkt, REG && !zero_seen); // (regular tiles: every window of every lane is valid)
+		else if constexpr (kOpenInTail) l1_scatter_tail<DBG, (WIDE_D >= 2), C>(L, G, P, ctr, tid, bkt, !zero_seen, [&]() { open_tile(nxt); }); // (regular tiles: every window of every lane is valid)
+		else l1_scatter_tail<DBG, (WIDE_D >= 2), (REG ? C : 0)>(L, G, P, ctr, tid, bkt, REG && !zero_seen);
 		raw = nxt;
 	}
 }
@@ -1482,7 +1529,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 			for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 			uint32_t my_gbase[ScatterLds::kBpt];
 			const uint32_t sub = blockIdx.x % G.n_sub;
-			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
+			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub, G.l1_pad);
 			scatter_stage_copy<16, 0, false, (WIDE_D >= 2)>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 		}
 		raw = nxt;
