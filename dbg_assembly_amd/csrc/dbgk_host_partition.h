@@ -92,7 +92,6 @@ static int plan_partition(dbgk_handle *h)
 		G.r_rec = r;
 		G.l2_shift = kKfBlockBits - (uint32_t)kRegionBits; // level 2 splits by block, not by 4096-slot region
 		G.kf = 2u;
-		G.l1_pad = 0; // (32-bit level-1 records: their copy-out does not pad)
 		G.l2_records = 16u * (uint32_t)l2_threads((int)G.n2);
 		G.kf_mask = (uint32_t)((1ull << (bits - kKfBlockBits)) - 1ull);
 		if (G.n1 > (uint32_t)kL1MaxB || G.n2 > (uint32_t)kMaxBuckets) return DBGK_OK; // (cannot happen for 13 <= k <= 18)
@@ -159,12 +158,7 @@ static int plan_partition(dbgk_handle *h)
 	// expected_kmers = occurrences THIS handle extracts; a region receives the global density
 	const uint64_t expected = h->cfg.expected_kmers ? h->cfg.expected_kmers : h->size * 2 / n_ranks;
 	const double per_slot = (double)expected / (double)h->size;
-	// padded runs (PartGeom.l1_pad) where a bucket's run per tile is long: on average 8 all-ones words per bucket and 16 K-record tile
-	// (not for shards: their fill counts ARE the per-bucket k-mer counts the ranks all-reduce; with two ranks and more the
-	// global table has more than 256 level-1 buckets anyway)
-	G.l1_pad = (G.n1 <= 256u && kSubStores == 1 && !want_shard) ? 16u : 0u;
-	const double pad_share = G.l1_pad ? 8.0 * (double)G.n1 / (double)ScatterLds::kRecords : 0.0;
-	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * (1.05 + pad_share) / (double)G.n_sub) + 65536 / G.n_sub + (G.n_sub > 1 ? 8192 : 0); // per sub-store
+	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05 / (double)G.n_sub) + 65536 / G.n_sub + (G.n_sub > 1 ? 8192 : 0); // per sub-store
 	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
 	G.cap1 = (G.cap1 + 15u) & ~15ull; // every bucket starts on a 128-byte line: the 16-byte record loads of level 2 and of the build are aligned
 	G.cap2 = (G.cap2 + 15u) & ~15ull;

@@ -103,10 +103,6 @@ struct PartGeom {
 	                     // 2: DIRECT BLOCKS -- `size` is 4^k itself and slot = kf_slot_of_key(key), see below
 	uint32_t kf_mask;    // kf == 2: 2^(2k - 16) - 1, the mask of a block index
 	uint32_t l2_records; // records of a level-2 tile = 16 x the threads of the level-2 kernel this geometry is scattered by (l2_threads(n2))
-	uint32_t l1_pad;     // 16 or 0: level 1 pads every run it appends to a level-1 bucket to a multiple of 16 records with all-ones
-	                     // words (no record: level 2 skips them), so that every run starts and ends on a 128-byte line -- set when the
-	                     // runs are long (n1 <= 256: >= 64 records per bucket and tile); round 5: level 1 4.89 -> 4.75 ms, level 2 no
-	                     // slower for 7 % more input (profiles/r05_l1_padded_runs_ab.txt)
 };
 
 // ---- KFREQ, direct blocks (kf == 2) --------------------------------------------------------------------------------
@@ -278,8 +274,7 @@ __device__ __forceinline__ uint32_t scan_hist(LDS &L)
 // after every record has been ranked (hist complete): reserve global space, scan
 template <class LDS>
 __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buckets, uint32_t *__restrict__ cnt, uint32_t (&my_gbase)[LDS::kBpt],
-                                                         uint32_t stride = 1u, // bucket b counts in cnt[b * stride]; returns the records of the tile
-                                                         uint32_t pad = 0u)    // a power of two: every reservation is rounded up to a multiple of it (PartGeom.l1_pad)
+                                                         uint32_t stride = 1u) // bucket b counts in cnt[b * stride]; returns the records of the tile
 {
 	const int t = (int)fresh_tid();
 	// one global atomic per non-empty bucket per tile: issued now, consumed only at copy-out, so its
@@ -287,7 +282,7 @@ __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buck
 #pragma unroll
 	for (int j = 0; j < LDS::kBpt; j++) {
 		const uint32_t b = LDS::kBpt * t + j, c = L.hist[b];
-		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], pad ? ((c + pad - 1u) & ~(pad - 1u)) : c) : 0u;
+		my_gbase[j] = (b < n_buckets && c) ? atomicAdd(&cnt[b * stride], c) : 0u;
 	}
 	const uint32_t all = scan_hist(L);
 	lds_barrier();
@@ -425,25 +420,6 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		uint64_t *o = out + (uint64_t)b * stride * cap + dst;
 		if (DBG == 3) { // timing experiment: same instruction stream, stores land in a 32 KiB window per workgroup (no HBM write traffic)
 			for (uint32_t i = lane; i < n; i += 64) out[(uint64_t)blockIdx.x * 4096u + (((uint64_t)b * stride * cap + dst + i) & 4095ull)] = L.stage[src + i];
-		} else if (G.l1_pad && bucket_is_b1) {
-			// padded runs (PartGeom.l1_pad): the reservation was a multiple of 16 records from a 128-byte boundary; what lies behind
-			// the run's last record is filled with all-ones words, which are no records
-			typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
-			const uint32_t n_pad = (n + G.l1_pad - 1u) & ~(G.l1_pad - 1u);
-			if ((uint64_t)dst + n_pad <= cap) {
-				for (uint32_t i = 2u * lane; i < n_pad; i += 128u) {
-					const uint64_t a = i < n ? L.stage[src + i] : ~0ull, b2 = i + 1u < n ? L.stage[src + i + 1u] : ~0ull;
-					const u32x4_a16 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
-					*reinterpret_cast<u32x4_a16 *>(o + i) = v;
-				}
-			} else { // the bucket is full: records beyond its capacity go to the overflow list, the padding ends with the bucket
-				for (uint32_t i = lane; i < n_pad; i += 64) {
-					const bool is_rec = i < n;
-					const uint64_t rcd = is_rec ? L.stage[src + i] : ~0ull;
-					if ((uint64_t)dst + i < cap) o[i] = rcd;
-					else if (is_rec) push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
-				}
-			}
 		} else if ((uint64_t)dst + n <= cap) {
 			// two records per lane and store instruction (16 bytes, 8-byte aligned): the memory pipe charges per instruction,
 			// whatever its lane count (level 1: 5.68 -> 5.54 ms against one record per lane, profiles/ab_bench.sh)
@@ -784,7 +760,7 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 	uint32_t my_gbase[ScatterLds::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
-	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub, G.l1_pad);
+	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure, pre);
 }
 
@@ -1529,7 +1505,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 			for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
 			uint32_t my_gbase[ScatterLds::kBpt];
 			const uint32_t sub = blockIdx.x % G.n_sub;
-			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub, G.l1_pad);
+			scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
 			scatter_stage_copy<16, 0, false, (WIDE_D >= 2)>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub);
 		}
 		raw = nxt;

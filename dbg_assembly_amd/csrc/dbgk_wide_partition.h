@@ -660,44 +660,24 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 		L.links[i] = 0ull;
 	}
 	uint32_t n_new = 0, n_conf = 0;
-	// Persistent workgroups pull regions from a cursor and consume their records as ONE stream of 512-record batches across
-	// regions (round 5, as the 64-bit build does): while batch i is inserted, batch i + 1 -- the next 512 records of this region or
-	// the first ones of the region after it -- is already in flight, so no batch waits for its own load any more.
-	auto grab = [&]() { // one region index per workgroup, broadcast through LDS
+	for (;;) {
 		if (t == 0) {
 			const unsigned int kx = atomicAdd(cursor, 1u);
 			L.next_region = kx < n_regions ? kx : kNone;
 		}
-	};
-	auto load_rec = [&](uint32_t f_, uint32_t base_, bool &live_) -> ull2 {
-		live_ = false;
-		if (f_ == kNone) return ull2{0ull, 0ull};
-		const uint32_t filled_ = (uint32_t)(P.cnt2[f_] < G.cap2 ? P.cnt2[f_] : G.cap2);
-		const uint32_t i_ = base_ + fresh_tid();
-		live_ = i_ < filled_;
-		return live_ ? __builtin_nontemporal_load(P.l2 + (uint64_t)f_ * G.cap2 + i_) : ull2{0ull, 0ull};
-	};
-	grab();
-	lds_barrier(); // also: the image is empty
-	uint32_t fl = __builtin_amdgcn_readfirstlane(L.next_region); // final bucket inside the chunk's level-2 store
-	lds_barrier();
-	grab(); // the region after it
-	lds_barrier();
-	uint32_t f_after = __builtin_amdgcn_readfirstlane(L.next_region);
-	uint32_t base = 0;
-	bool live = false;
-	ull2 rec = load_rec(fl, 0u, live);
-	while (fl != kNone) {
+		lds_barrier(); // also: the image is empty
+		const uint32_t fl = __builtin_amdgcn_readfirstlane(L.next_region); // final bucket inside the chunk's level-2 store
+		if (fl == kNone) break;
 		const uint32_t b1 = G.b_lo + G.pass_j0 + j0 + (fl >> (G.r - kWRegionBits)); // global level-1 bucket
 		const uint64_t region_slot0 = ((uint64_t)b1 << G.r) + ((uint64_t)(fl & (G.n2 - 1u)) << kWRegionBits); // global slot of the region's first entry
 		// (the table -- or this shard -- may end inside, or before, the last bucket's regions)
 		const uint32_t region_len = region_slot0 >= G.slot_hi ? 0u : (uint32_t)((G.slot_hi - region_slot0 < (uint64_t)kWRegionSlots) ? G.slot_hi - region_slot0 : kWRegionSlots);
 		const uint32_t filled = (uint32_t)(P.cnt2[fl] < G.cap2 ? P.cnt2[fl] : G.cap2);
-		const bool last_of_region = base + kWBuildThreads >= filled;
-		const uint32_t f_nxt = last_of_region ? f_after : fl, base_nxt = last_of_region ? 0u : base + kWBuildThreads;
-		bool live_nxt = false;
-		const ull2 nxt = load_rec(f_nxt, base_nxt, live_nxt); // in flight during the insert below
-		{
+		const ull2 *in = P.l2 + (uint64_t)fl * G.cap2;
+		for (uint32_t base = 0; base < filled; base += kWBuildThreads) {
+			const uint32_t i = base + t;
+			const bool live = i < filled;
+			const ull2 rec = live ? __builtin_nontemporal_load(in + i) : ull2{0ull, 0ull};
 			const unsigned long long id = (rec.y >> 6) + 1ull, want_hi1 = rec.x + 1ull;
 			const uint32_t lb = (uint32_t)(rec.y >> 3) & 7u, rb = (uint32_t)rec.y & 7u;
 			const uint32_t home = (uint32_t)(rec.y >> 6) & (kWRegionSlots - 1u);
@@ -742,12 +722,6 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 			}
 			if (live && lost) wide_push_overflow(P, wide_record_key(rec, b1, G), lb, rb, ctr);
 		}
-		if (!last_of_region) {
-			base = base_nxt;
-			rec = nxt;
-			live = live_nxt;
-			continue;
-		}
 		lds_barrier();
 		// emit the region: slot i of the table <- LDS slot i, the low word recomputed from (q, slot) and the high word;
 		// the image is cleared on the way
@@ -785,13 +759,7 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 				}
 			}
 		}
-		grab(); // the region after the one whose first batch is already in flight
-		lds_barrier(); // the image is empty again, next_region is visible
-		f_after = __builtin_amdgcn_readfirstlane(L.next_region); // (the next grab writes it behind the next region's pre-emit barrier)
-		fl = f_nxt;
-		base = 0;
-		rec = nxt;
-		live = live_nxt;
+		// (the barrier at the top of the loop separates this clearing from the next region's inserts)
 	}
 	const unsigned long long a = block_sum_n<kWBuildThreads>(n_new, L.red);
 	const unsigned long long b = block_sum_n<kWBuildThreads>(n_conf, L.red);
