@@ -572,53 +572,28 @@ __global__ __launch_bounds__(kWL2Threads) void k_wide_scatter_l2(WPartGeom G, WP
 	// final bucket come through ONE L2 and merge into full lines there
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, n_local = gridDim.x >> 3; // gridDim.x is a multiple of 8
 	const uint32_t lo_tile = first_tile + (uint32_t)(((uint64_t)span * xcd) >> 3), hi_tile = first_tile + (uint32_t)(((uint64_t)span * (xcd + 1u)) >> 3);
-	// the records of tile i + 1 are loaded into registers before tile i is scattered (round 5, as the 64-bit level 2 does): HBM reads,
-	// the LDS work and the stores of consecutive tiles overlap
-	struct Tile {
-		ull2 rec[8];
-		uint32_t jj, b1;
-		uint32_t live; // bit u: record u exists
-	};
-	auto load_tile = [&](uint32_t g, Tile &T) {
-		T.live = 0u;
-		T.jj = 0u;
-		T.b1 = 0u;
-#pragma unroll
-		for (int u = 0; u < 8; u++) T.rec[u] = ull2{0ull, 0ull};
-		if (g >= hi_tile) return;
+	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
 		uint32_t lo = f0, hi = f1; // last flat entry with tile_prefix[f] <= g (empty entries repeat the prefix: take the last)
 		while (hi - lo > 1u) {
 			const uint32_t mid = (lo + hi) >> 1;
 			if (tile_prefix[mid] <= g) lo = mid; else hi = mid;
 		}
-		const uint32_t e = wide_flat_entry(G, lo, T.jj);
-		T.b1 = G.b_lo + G.pass_j0 + T.jj; // global level-1 bucket
+		uint32_t jj;
+		const uint32_t e = wide_flat_entry(G, lo, jj);
+		const uint32_t b1 = G.b_lo + G.pass_j0 + jj; // global level-1 bucket
 		const uint64_t filled = P.inbox_cnt[e] < G.cap1 ? P.inbox_cnt[e] : G.cap1;
 		const uint64_t first = (uint64_t)(g - tile_prefix[lo]) * kWL2Records;
 		const ull2 *in = P.inbox + (uint64_t)e * G.cap1;
 		const uint32_t t = fresh_tid();
-#pragma unroll
-		for (int u = 0; u < 8; u++) { // coalesced: consecutive lanes read consecutive records
-			const uint64_t i = first + (uint64_t)u * kWL2Threads + t;
-			if (i < filled) {
-				T.rec[u] = __builtin_nontemporal_load(in + i);
-				T.live |= 1u << u;
-			}
-		}
-	};
-	Tile nxt;
-	load_tile(lo_tile + local, nxt);
-	for (uint32_t g = lo_tile + local; g < hi_tile; g += n_local) {
-		const uint32_t jj = nxt.jj, b1 = nxt.b1;
-		const uint32_t t = fresh_tid();
 		ull2 rec[8];
 		uint32_t bkt[8];
 #pragma unroll
-		for (int u = 0; u < 8; u++) {
-			rec[u] = nxt.rec[u];
-			bkt[u] = ((nxt.live >> u) & 1u) ? ((uint32_t)(rec[u].y >> (6 + kWRegionBits)) & (G.n2 - 1u)) : 0xFFFFu;
+		for (int u = 0; u < 8; u++) { // coalesced: consecutive lanes read consecutive records
+			const uint64_t i = first + (uint64_t)u * kWL2Threads + t;
+			const bool have = i < filled;
+			rec[u] = have ? __builtin_nontemporal_load(in + i) : ull2{0ull, 0ull};
+			bkt[u] = have ? ((uint32_t)(rec[u].y >> (6 + kWRegionBits)) & (G.n2 - 1u)) : 0xFFFFu;
 		}
-		load_tile(g + n_local, nxt); // in flight during the scatter below
 #pragma unroll
 		for (int j = 0; j < kBpt; j++) L.hist[kBpt * t + j] = 0u;
 		lds_barrier();
