@@ -107,7 +107,8 @@ static int setup_wide_partition(dbgk_handle *h)
 	          hipMalloc(&P.cnt1, (size_t)G.n_l1 * 4) == hipSuccess && hipMalloc(&P.cnt2, (size_t)G.chunk_buckets * G.n2 * 4) == hipSuccess &&
 	          hipMalloc(&P.ovf, P.ovf_cap * sizeof(dbgk_node32)) == hipSuccess && hipMalloc(&P.spill, P.spill_cap * sizeof(dbgk_node32)) == hipSuccess &&
 	          hipMalloc(&P.ovf_n, 16) == hipSuccess && hipMalloc(&h->w_tile_prefix, ((size_t)G.n_l1 + 1) * 4) == hipSuccess &&
-	          hipMalloc(&h->w_cursor, 4) == hipSuccess && hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(dbgk_node32)) == hipSuccess &&
+	          hipMalloc(&h->w_cursor, (3 + (size_t)G.chunk_buckets * G.n2) * 4) == hipSuccess && // fast cursor, redo cursor, redo count, redo list
+	          hipMalloc(&P.outgoing, P.outgoing_cap * sizeof(dbgk_node32)) == hipSuccess &&
 	          hipMalloc(&P.outgoing_n, 8) == hipSuccess && hipMalloc(&h->w_side_out, ((size_t)kWideSideSlots + 1) * sizeof(dbgk_node32)) == hipSuccess &&
 	          hipMalloc(&h->w_side_n, 8) == hipSuccess;
 	if (ok && h->sharded) ok = hipMalloc(&h->winbox, l1_bytes) == hipSuccess && hipMalloc(&h->winbox_cnt, (size_t)G.n_l1 * 4) == hipSuccess;
@@ -132,7 +133,9 @@ static int setup_wide_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<2>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<1024>, sizeof(WL2Lds<1024>));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<2048>, sizeof(WL2Lds<2048>));
-	DBGK_LDS_ATTR(k_wide_build_regions, sizeof(WBuildLds));
+	DBGK_LDS_ATTR((k_wide_build_regions<true, false>), sizeof(WBuildLds));
+	DBGK_LDS_ATTR((k_wide_build_regions<false, false>), sizeof(WBuildLds));
+	DBGK_LDS_ATTR((k_wide_build_regions<false, true>), sizeof(WBuildLds));
 	h->store_capacity = h->cfg.expected_kmers;
 	h->pending_kmers = 0;
 	h->wpass_open = true; // pass 0 is open from the start
@@ -188,9 +191,20 @@ static int wide_build_range(dbgk_handle *h, uint32_t j0, uint32_t j1)
 		const uint32_t n_regions = (c1 - c0) * G.n2;
 		rc = span_begin(h, PH_BUILD, sp);
 		if (rc) return rc;
-		HIPCHK(hipMemsetAsync(h->w_cursor, 0, 4, h->stream));
-		hipLaunchKernelGGL(k_wide_build_regions, dim3(std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 3u)), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P,
-		                   h->wnodes, h->d_ctr, h->w_cursor, c0, n_regions);
+		HIPCHK(hipMemsetAsync(h->w_cursor, 0, 12, h->stream)); // both cursors and the redo count
+		const WRedoList redo{h->w_cursor + 3, h->w_cursor + 2, G.chunk_buckets * G.n2};
+		const uint32_t bgrid = std::min<uint32_t>(n_regions, (uint32_t)h->n_cu * 3u);
+		if (dbgk_hook("build_exact") && atoi(dbgk_hook("build_exact")) != 0) {
+			hipLaunchKernelGGL((k_wide_build_regions<false, false>), dim3(bgrid), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P, h->wnodes, h->d_ctr,
+			                   h->w_cursor, c0, n_regions, redo);
+		} else {
+			// the fast insert, then the exact pass over the regions it flagged (normally none: the kernel finds an empty list and returns);
+			// right here, while the level-2 store still holds this chunk's records
+			hipLaunchKernelGGL((k_wide_build_regions<true, false>), dim3(bgrid), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P, h->wnodes, h->d_ctr,
+			                   h->w_cursor, c0, n_regions, redo);
+			hipLaunchKernelGGL((k_wide_build_regions<false, true>), dim3(std::min<uint32_t>(bgrid, (uint32_t)h->n_cu)), dim3(kWBuildThreads), sizeof(WBuildLds), h->stream, G, P,
+			                   h->wnodes, h->d_ctr, h->w_cursor + 1, c0, n_regions, redo);
+		}
 		HIPCHK(hipGetLastError());
 		rc = span_end(h, sp);
 		if (rc) return rc;

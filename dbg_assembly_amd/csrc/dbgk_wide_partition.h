@@ -638,6 +638,19 @@ struct WBuildLds {
 	unsigned long long links[kWRegionSlots + kWSpillSlots];
 	unsigned long long red[kWBuildThreads / 64];
 	uint32_t next_region;
+	uint32_t redo;                 // FAST build: a counter of the current region passed 255 (or the region is full): the exact pass rebuilds it
+};
+
+// FAST (round 5, as k_build_regions<FAST> of the 64-bit engine): the two neighbour counters of a record are bumped with ONE
+// ds_add_rtn_u64 instead of a saturating compare-swap loop.  A plain add cannot saturate, so the returned bytes are folded into a
+// per-thread maximum; a region in which a byte that already held 255 was bumped (or whose image is full) emits NOTHING -- no slots,
+// no spill nodes, no counts, no overflow observations -- and is appended to `redo`; the exact form of this kernel (FAST = false,
+// FROM_LIST = true) rebuilds the listed regions from their records right after the chunk's fast launch (the level-2 store still
+// holds them).  Exact for any input; a region pays twice only when one of its k-mers has a neighbour seen more than 255 times.
+struct WRedoList {
+	uint32_t *list;        // region indices inside the chunk
+	unsigned int *n;       // appended so far
+	uint32_t cap;
 };
 
 // Persistent workgroups pull regions from a cursor.  A slot is claimed with a CAS on `ident`; the winner then
@@ -646,9 +659,11 @@ struct WBuildLds {
 // wave never wait on each other, and another wave publishes without waiting for anybody.
 // `table` holds this handle's slot range [slot_lo, slot_hi); the launch covers the final buckets of the own buckets
 // pass_j0 + [j0, j0 + n_regions / n2) whose records level 2 has just put into the level-2 store.
+template <bool FAST, bool FROM_LIST>
 __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom G, WPartStore P, WNode *__restrict__ table, Counters *__restrict__ ctr,
-                                                                     unsigned int *__restrict__ cursor, uint32_t j0, uint32_t n_regions)
+                                                                     unsigned int *__restrict__ cursor, uint32_t j0, uint32_t n_regions, WRedoList redo)
 {
+	static_assert(!(FAST && FROM_LIST), "the exact pass is what the list is for");
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	WBuildLds &L = *reinterpret_cast<WBuildLds *>(lds_raw);
 	const uint32_t t = fresh_tid();
@@ -659,13 +674,19 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 		L.hi1[i] = 0ull;
 		L.links[i] = 0ull;
 	}
+	if (t == 0) L.redo = 0u;
 	uint32_t n_new = 0, n_conf = 0;
 	for (;;) {
 		if (t == 0) {
 			const unsigned int kx = atomicAdd(cursor, 1u);
-			L.next_region = kx < n_regions ? kx : kNone;
+			if (FROM_LIST) {
+				const unsigned int n_list = *redo.n < redo.cap ? *redo.n : redo.cap; // complete: the fast launch has finished
+				L.next_region = kx < n_list ? redo.list[kx] : kNone;
+			} else {
+				L.next_region = kx < n_regions ? kx : kNone;
+			}
 		}
-		lds_barrier(); // also: the image is empty
+		lds_barrier(); // also: the image is empty, the flag is clear
 		const uint32_t fl = __builtin_amdgcn_readfirstlane(L.next_region); // final bucket inside the chunk's level-2 store
 		if (fl == kNone) break;
 		const uint32_t b1 = G.b_lo + G.pass_j0 + j0 + (fl >> (G.r - kWRegionBits)); // global level-1 bucket
@@ -674,6 +695,8 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 		const uint32_t region_len = region_slot0 >= G.slot_hi ? 0u : (uint32_t)((G.slot_hi - region_slot0 < (uint64_t)kWRegionSlots) ? G.slot_hi - region_slot0 : kWRegionSlots);
 		const uint32_t filled = (uint32_t)(P.cnt2[fl] < G.cap2 ? P.cnt2[fl] : G.cap2);
 		const ull2 *in = P.l2 + (uint64_t)fl * G.cap2;
+		uint32_t n_new_r = 0, n_conf_r = 0, sat = 0; // of this region: committed only when the region is emitted
+		bool flag = false;
 		for (uint32_t base = 0; base < filled; base += kWBuildThreads) {
 			const uint32_t i = base + t;
 			const bool live = i < filled;
@@ -691,7 +714,7 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 					if (prev == 0ull) {
 						__hip_atomic_store(&L.hi1[idx], want_hi1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						mine = true;
-						n_new += idx < region_len ? 1u : 0u; // spilled nodes are counted when they are merged
+						n_new_r += idx < region_len ? 1u : 0u; // spilled nodes are counted when they are merged
 					}
 					cur = prev == 0ull ? id : prev;
 				}
@@ -702,13 +725,24 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 					step = h1 != 0ull && !hit; // 0: its owner is about to publish the high word -- look at this slot again
 				}
 				idx += step ? 1u : 0u;
-				n_conf += step ? 1u : 0u;
+				n_conf_r += step ? 1u : 0u;
 				lost = idx >= kAll; // region + spill area completely full
 				probing = !hit && !lost;
 			}
 			// saturating +1 on the observed neighbour bytes, both dwords at once (see k_build_regions)
 			const uint32_t dl = (lb != 4u) ? (1u << (24u - 8u * lb)) : 0u, dr = (rb != 4u) ? (1u << (24u - 8u * rb)) : 0u;
 			bool pending = live && !lost;
+			if constexpr (FAST) {
+				if (pending) {
+					const unsigned long long was = atomicAdd(&L.links[idx], ((unsigned long long)dr << 32) | dl);
+					// the bumped byte moved to the top of a word: >= 0xFF000000 says it already held 255 (a side without neighbour shifts its word out)
+					const uint32_t sh_l = 8u * lb, sh_r = 8u * rb;
+					const uint32_t bl = (uint32_t)((uint64_t)(uint32_t)was << sh_l), br = (uint32_t)((uint64_t)(uint32_t)(was >> 32) << sh_r);
+					sat = max(sat, max(bl, br));
+				}
+				flag = flag || (live && lost); // the exact pass sends it to the overflow list
+				pending = false;
+			}
 			unsigned long long old = pending ? L.links[idx] : 0ull;
 			while (pending) {
 				const uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
@@ -720,9 +754,33 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 				pending = prev != old;
 				old = prev;
 			}
-			if (live && lost) wide_push_overflow(P, wide_record_key(rec, b1, G), lb, rb, ctr);
+			if (!FAST && live && lost) wide_push_overflow(P, wide_record_key(rec, b1, G), lb, rb, ctr);
 		}
-		lds_barrier();
+		bool redo_region = false;
+		if constexpr (FAST) {
+			if (flag || sat >= 0xFF000000u) L.redo = 1u;
+			lds_barrier();
+			redo_region = __builtin_amdgcn_readfirstlane(L.redo) != 0u;
+		} else {
+			lds_barrier();
+		}
+		if (!redo_region) {
+			n_new += n_new_r;
+			n_conf += n_conf_r;
+		} else {
+			if (t == 0) {
+				const unsigned int j = atomicAdd(redo.n, 1u);
+				if (j < redo.cap) redo.list[j] = fl; else atomicOr(&ctr->error, 2u);
+			}
+			for (uint32_t i = t; i < kAll; i += kWBuildThreads) { // nothing of this region is emitted: the exact pass writes it
+				L.ident[i] = 0ull;
+				L.hi1[i] = 0ull;
+				L.links[i] = 0ull;
+			}
+			lds_barrier();            // (everybody has read the flag: that happened before its clearing loop, i.e. before this barrier)
+			if (t == 0) L.redo = 0u;  // visible behind the barrier at the top of the loop
+			continue;
+		}
 		// emit the region: slot i of the table <- LDS slot i, the low word recomputed from (q, slot) and the high word;
 		// the image is cleared on the way
 		for (uint32_t i = t; i < kAll; i += kWBuildThreads) {
