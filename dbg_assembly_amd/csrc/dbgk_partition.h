@@ -268,6 +268,37 @@ __device__ __forceinline__ uint32_t scan_hist(LDS &L)
 	return all;
 }
 
+// The same prefix sum computed by EVERY wave for itself (level 1, whose fan-out is small next to its 16 waves): lane l of a wave owns
+// the buckets [E l, E l + E), E = ceil(n_buckets / 64) <= 16, scans them with wave shuffles and writes lbase -- all waves write the
+// same values -- so no wave_tot exchange and no barrier inside the scan: a wave reads back only what it has written itself.
+template <class LDS>
+__device__ __forceinline__ void scan_hist_per_wave(LDS &L, uint32_t n_buckets, uint32_t hist_off = 0u) // hist_off: the histogram to scan, in words from L.hist (the pipelined level 1 has two)
+{
+	const uint32_t *hist = L.hist + hist_off;
+	const uint32_t lane = fresh_tid() & 63u;
+	const uint32_t E = (n_buckets + 63u) >> 6; // (wave-uniform)
+	uint32_t sum = 0;
+	for (uint32_t j = 0; j < E; j++) { // (E <= 16; buckets beyond n_buckets hold zero: the histogram is cleared up to kMaxB)
+		const uint32_t b = E * lane + j;
+		sum += b < (uint32_t)LDS::kMaxB ? hist[b] : 0u;
+	}
+	uint32_t inc = sum;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t n = __shfl_up(inc, off, 64);
+		if ((int)lane >= off) inc += n;
+	}
+	uint32_t run = inc - sum;
+	for (uint32_t j = 0; j < E; j++) {
+		const uint32_t b = E * lane + j;
+		if (b < (uint32_t)LDS::kMaxB) {
+			const uint32_t c = hist[b];
+			L.lbase[b] = run;
+			run += c;
+		}
+	}
+}
+
 // Phases of the workgroup-wide bucket scatter of one tile (<= 16 records per thread).
 //   br[u] = (bucket << 16) | rank-within-bucket, bucket >= kMaxBuckets = no record
 
@@ -301,17 +332,13 @@ __device__ __forceinline__ uint32_t scatter_reserve_scan(LDS &L, uint32_t n_buck
 // those instantiations carry the 32-bit copy-out
 // N_SURE > 0 and `sure`: the caller knows that the lane's first N_SURE records all have a bucket (regular level-1 tiles without a
 // zero key); a wave in which every lane says so stages them without a test per record, the lbase reads issued together
-struct NoPre { __device__ __forceinline__ void operator()() const {} };
-// `pre` runs on every thread right BEFORE the barrier in front of the copy-out (the histogram has been read, the tile's packed words
-// are no longer needed): a caller whose next tile starts with LDS writes that only need "a barrier before they are read" puts them
-// there and saves the barrier of its own (the regular-tile form of level 1: the next tile's packed words and the cleared histogram)
-template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, int N_SURE = 0, class LDS, class Pre = NoPre>
+template <int PER_THREAD, int DBG = 0, bool FLAT = false, bool KF32_POSSIBLE = true, int N_SURE = 0, class LDS>
 __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)[PER_THREAD], const uint32_t (&br)[PER_THREAD],
                                                    const uint32_t (&my_gbase)[LDS::kBpt], uint32_t n_buckets, uint64_t *__restrict__ out,
                                                    uint64_t cap, uint32_t b1_of_bucket0, bool bucket_is_b1, const PartGeom &G,
                                                    const PartStore &P, Counters *ctr, uint32_t stride = 1u, // bucket b lives at out + b * stride * cap
                                                    uint32_t flat_total = 0u, // FLAT: the records of the tile (scatter_reserve_scan)
-                                                   bool sure = false, Pre pre = Pre())
+                                                   bool sure = false)
 {
 	const int t = (int)fresh_tid();
 	if (FLAT) { // the histogram has been consumed by the scan: every thread clears its own entries for the NEXT tile now, which then
@@ -345,7 +372,6 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 		if (FLAT) L.desc[b] = (typename LDS::Desc)(my_gbase[j] - L.lbase[b]); // global place of staged record p of bucket b = desc[b] + p (modulo 2^32)
 		else L.desc[b] = (typename LDS::Desc)(((uint64_t)my_gbase[j] << 32) | (L.hist[b] << 16) | L.lbase[b]);
 	}
-	pre();
 	lds_barrier();
 	if (FLAT) {
 		if (DBG != 2) {
@@ -651,20 +677,30 @@ __device__ __forceinline__ Chunk16 decode_chunk16(const RawChunk &raw, const Rea
 // per-position validity test is gone.
 // ROLL32 (k >= 17, any validity pattern -- the prefix form of reads of any lengths): the two savings of SPECIAL that do not depend on
 // every window being valid -- the 32-bit rolls, and the neighbour codes taken after the strand select
-template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds, bool SPECIAL = false, bool ROLL32 = SPECIAL>
+// IN_REGS (pipelined regular tiles, SPECIAL): the records stay in registers (rec[]) instead of being parked in the stage buffer --
+// which still holds the sorted records of the tile before -- the ranks are taken in `hist` (one of two histograms), and mid(i) runs
+// in front of position i: the caller copies one run of the tile before out of the stage buffer there, its LDS read and its store in
+// the shadow of the position's arithmetic
+struct NoMid { __device__ __forceinline__ void operator()(uint32_t) const {} };
+template <int WIDE_D, int NPOS = 16, class LDS = ScatterLds, bool SPECIAL = false, bool ROLL32 = SPECIAL, bool IN_REGS = false, class Mid = NoMid>
 __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 c, uint32_t tid, uint64_t head_mask, uint32_t rc_shift,
-                                             uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16])
+                                             uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16], uint64_t *rec = nullptr,
+                                             uint32_t hist_off = 0u, Mid mid = Mid()) // hist_off: the histogram in use, in words from L.hist
 {
+	static_assert(!IN_REGS || (SPECIAL && WIDE_D != 3), "records in registers: regular tiles of a graph handle");
+	uint32_t *const hh = L.hist + (IN_REGS ? hist_off : 0u);
 	// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
 	// first / last window are patched afterwards (rare per lane, so the loop stays lean).
 	// Complemented neighbour codes (3 - x == x ^ 3) for all 16 positions at once:
 	const uint32_t lwc = ~c.lw, nbc = ~c.nb;
 	uint32_t rev_mask = 0;
 	bool zero_any = false; // some canonical k-mer of this lane is 0 (the key-0 node is kept apart, DBGgraph.cpp:418)
+	uint32_t zero_acc = 0u;
 #pragma unroll
 	for (uint32_t i = NPOS; i < 16; i++) bkt[i] = (uint32_t)kL1MaxB << 16; // lanes own NPOS positions: the rest never holds a record
 #pragma unroll
 	for (uint32_t i = 0; i < (uint32_t)NPOS; i++) {
+		mid(i);
 		const uint32_t sh = 30u - 2u * i;
 		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
 		const bool rev = c.rc < c.kbit;                         // tie -> forward (DBGgraph.cpp:80)
@@ -713,13 +749,29 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 		// ((q << r | place in the bucket) << 6) | links, as two shift-or instructions (q_shift = r + 6)
 		const uint32_t rec_lo = (((q_lo << (q_shift - 6u)) | (slot & rel_mask)) << 6) | links;
 		const uint32_t rec_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 32u - q_shift);
-		L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
+		if constexpr (IN_REGS) {
+			// (built HERE: left to itself the compiler sinks the packing below the loop and keeps q, slot and links alive instead --
+			// four registers per position for two; the rank of the position before is folded into its bucket word one position late,
+			// when the LDS atomic has long returned)
+			uint32_t lo_now = rec_lo, hi_now = rec_hi;
+			asm volatile("" : "+v"(lo_now), "+v"(hi_now));
+			rec[i] = ((uint64_t)hi_now << 32) | lo_now;
+			if (i > 0u) asm volatile("" : "+v"(bkt[i - 1u]));
+		} else {
+			L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
+		}
 		const bool valid = SPECIAL ? true : (bool)((c.valid >> i) & 1u);
 		const bool zero = key == 0ull;
-		zero_any = zero_any || zero; // (the compare is needed below anyway: an OR of condition masks)
+		if constexpr (IN_REGS) { // (a select per position into one register: with the copy-out's branches between the positions the compiler
+			// would keep fifteen condition masks alive and OR them behind the loop)
+			zero_acc = zero ? 1u : zero_acc;
+			asm volatile("" : "+v"(zero_acc));
+		} else {
+			zero_any = zero_any || zero; // (the compare is needed below anyway: an OR of condition masks)
+		}
 		// positions without a record rank themselves in a per-lane dummy bin: no exec juggling around the LDS atomic
 		const uint32_t b = (valid && !zero) ? bucket : (uint32_t)kL1MaxB + (tid & 63u);
-		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
+		bkt[i] = (b << 16) | atomicAdd(&hh[b], 1u);
 		// roll to the next position (DBGgraph.cpp:71-73)
 		if constexpr (ROLL32) {
 			const uint32_t klo = (uint32_t)c.kbit, khi = (uint32_t)(c.kbit >> 32);
@@ -734,6 +786,22 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	}
 	// windows without a left / right neighbour: that side's code becomes 4 = none
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
+	if constexpr (IN_REGS) { // (SPECIAL: only a read's first window, a lane's position 0, and its last one, a lane's position NPOS - 1, lack a side)
+#pragma unroll
+		for (uint32_t e = 0; e < 2u; e++) {
+			const uint32_t i = e ? (uint32_t)NPOS - 1u : 0u;
+			if (e && NPOS == 1) break;
+			const bool nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+			if (nl || nr) {
+				const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u);
+				uint32_t lb = ((uint32_t)rec[i] >> 3) & 7u, rbb = (uint32_t)rec[i] & 7u;
+				if (fwd ? nl : nr) lb = 4u;
+				if (fwd ? nr : nl) rbb = 4u;
+				rec[i] = (rec[i] & ~63ull) | (lb << 3) | rbb;
+			}
+		}
+		return zero_acc != 0u;
+	}
 	for (uint32_t fix = (WIDE_D == 3 || (!SPECIAL && G.kf)) ? 0u : ((no_l | no_r) & c.valid); fix; fix &= fix - 1u) {
 		const uint32_t i = (uint32_t)__builtin_ctz(fix);
 		const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
@@ -747,9 +815,9 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 }
 
 // after the positions of a tile: reserve, scan, move the parked records into sorted order, copy out
-template <int DBG, bool KF32_POSSIBLE = true, int N_SURE = 0, class Pre = NoPre>
+template <int DBG, bool KF32_POSSIBLE = true, int N_SURE = 0>
 __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G, const PartStore &P, Counters *ctr, uint32_t tid,
-                                                const uint32_t (&bkt)[16], bool sure = false, Pre pre = Pre())
+                                                const uint32_t (&bkt)[16], bool sure = false)
 {
 	lds_barrier(); // hist complete
 	// the parked records come back into registers BEFORE the reservation and the scan: the barriers inside the scan then
@@ -757,11 +825,11 @@ __device__ __forceinline__ void l1_scatter_tail(ScatterLds &L, const PartGeom &G
 	// (one barrier less per tile; with the one dropped after the copy-out: 5.53 -> 5.47 ms)
 	uint64_t rec[16];
 #pragma unroll
-	for (int u = 0; u < 16; u++) rec[u] = L.stage[u * kL1Threads + tid];
+	for (int u = 0; u < 16; u++) rec[u] = (N_SURE == 0 || u < N_SURE) ? L.stage[u * kL1Threads + tid] : 0ull; // (N_SURE = C: a lane owns C positions, the rest never holds a record)
 	uint32_t my_gbase[ScatterLds::kBpt];
 	const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (its XCD under round-robin dispatch)
 	scatter_reserve_scan(L, G.n1, P.cnt1 + sub, my_gbase, G.n_sub);
-	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure, pre);
+	scatter_stage_copy<16, DBG, false, KF32_POSSIBLE, N_SURE>(L, rec, bkt, my_gbase, G.n1, P.l1 + (uint64_t)sub * G.cap1, G.cap1, 0u, true, G, P, ctr, G.n_sub, 0u, sure);
 }
 
 // LINEAR form for MANY level-1 buckets (large tables, and every rank of a multi-GPU job: the level-1 buckets are those
@@ -980,6 +1048,7 @@ constexpr int kPkWords = 1792 * kTileThreads / 1024; // packed words of one tile
 struct UniformLds {
 	ScatterLds s;
 	uint32_t pk[kPkWords];
+	uint32_t gbase[kL1MaxB]; // pipelined regular tiles: a bucket's reserved place, from the thread that reserved it to the wave that copies the run
 };
 template <int C>
 struct UniformLdsLin {
@@ -1119,7 +1188,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 
 	RawU raw = fetch(blockIdx.x, r0, c0);
 	// the tile's bytes (block tid, block tid + 1024) go into LDS packed 16 bases per word, the histogram is cleared
-	auto open_tile = [&](const RawU &rw) {
+	auto open_tile = [&](const RawU &rw, uint32_t hist_off = 0u) { // hist_off: the histogram to clear, in words from L.hist (the pipelined form has two)
 		const uint32_t tid = fresh_tid();
 		if constexpr (PACKED) {
 			if (tid < rw.n_blocks) UL.pk[tid] = rw.a;
@@ -1132,25 +1201,10 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			if (tid + kL1Threads < rw.n_blocks) UL.pk[tid + kL1Threads] = pack16_ascii(rw.b, rb.other_seen);
 		}
 #pragma unroll
-		for (int j = 0; j < SLds::kBpt; j++) L.hist[SLds::kBpt * tid + j] = 0;
+		for (int j = 0; j < SLds::kBpt; j++) L.hist[hist_off + SLds::kBpt * tid + j] = 0;
 	};
-	// regular tiles (wave-per-bucket tail): the NEXT tile is opened inside the tail, right before the barrier in front of the
-	// copy-out (scatter_stage_copy `pre`: by then nobody reads the packed words or the histogram of this tile any more).  The
-	// barrier a tile begins with -- no record may be parked in the stage buffer while a slower wave still copies the last tile
-	// out of it -- then stands BEHIND the lane's decode instead of in front of it: a wave that has finished its copy-out funnels
-	// its next window out of the packed words while the others finish.  The other forms open their tile at the top of the loop
-	constexpr bool kOpenInTail = REG && !LIN && DBG == 0;
-	if (kOpenInTail && blockIdx.x < n_tiles) {
-		open_tile(raw);
-		lds_barrier();
-	}
-	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const uint32_t tid = fresh_tid();
-		uint32_t bkt[16];
-		if constexpr (!kOpenInTail) {
-			open_tile(raw);
-			lds_barrier();
-		}
+	// a lane's window of 16 positions out of the tile's packed words
+	auto decode = [&](const RawU &raw) {
 		const uint64_t p = raw.p;                        // flat position of the lane's first window
 		// the packed stream starts one base earlier (left neighbour) -- except at position 0, and (regular tiles, whose byte
 		// range starts ON a read start) for a read's first chunk, whose first window has no left neighbour anyway
@@ -1159,27 +1213,141 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		const uint32_t first_w = (uint32_t)C * raw.cc;   // index of the lane's first window inside its read
 		const bool live = first_w < raw.W;               // (raw.W == 0 for lanes beyond the batch)
 		Chunk16 c;
-		{
-			const uint32_t rel = live ? (uint32_t)(s0 - raw.B0) : 0u;
-			const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u), sh = 2u * (rel & 15u);
-			const uint32_t x0 = UL.pk[d], x1 = UL.pk[d + 1], x2 = UL.pk[d + 2], x3 = UL.pk[d + 3], x4 = UL.pk[d + 4];
-			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
-			// stream Y starts at position p (X starts at p - 1 unless p == 0)
-			const uint32_t adv = no_prev ? 0u : 2u;
-			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
-			c.lw = no_prev ? (X0 >> 2) : X0; // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
-			c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
-			c.rc = revcomp_kbit(c.kbit, (int)k);
-			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
-			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
-			c.nb = funnel_left(ya, yb, wsh);
-			const uint32_t nv = live ? min((uint32_t)C, raw.W - first_w) : 0u;
-			const uint32_t nr = (live && first_w + 1u < raw.W) ? min((uint32_t)C, raw.W - 1u - first_w) : 0u;
-			c.valid = (1u << nv) - 1u;
-			c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
-			c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
+		const uint32_t rel = live ? (uint32_t)(s0 - raw.B0) : 0u;
+		const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u), sh = 2u * (rel & 15u);
+		const uint32_t x0 = UL.pk[d], x1 = UL.pk[d + 1], x2 = UL.pk[d + 2], x3 = UL.pk[d + 3], x4 = UL.pk[d + 4];
+		const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
+		// stream Y starts at position p (X starts at p - 1 unless p == 0)
+		const uint32_t adv = no_prev ? 0u : 2u;
+		const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
+		c.lw = no_prev ? (X0 >> 2) : X0; // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
+		c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
+		c.rc = revcomp_kbit(c.kbit, (int)k);
+		const uint32_t widx = k >> 4, wsh = 2u * (k & 15u); // bases p+k .. p+k+15 (wave-uniform selection)
+		const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
+		c.nb = funnel_left(ya, yb, wsh);
+		const uint32_t nv = live ? min((uint32_t)C, raw.W - first_w) : 0u;
+		const uint32_t nr = (live && first_w + 1u < raw.W) ? min((uint32_t)C, raw.W - 1u - first_w) : 0u;
+		c.valid = (1u << nv) - 1u;
+		c.has_r = (1u << nr) - 1u;            // the read's last window has no right neighbour
+		c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
+		return c;
+	};
+	// PIPELINED regular tiles (round 5: level 1 4.74 -> 4.13 ms, profiles/r05_l1_pipelined_ab.txt): the copy-out of a tile runs INSIDE
+	// the position loop of the next one -- a run's LDS read and its store between two positions' arithmetic, instead of a phase of its
+	// own in which the vector ALUs idle.  The records of a tile stay in registers until they are staged in sorted order (nothing is
+	// parked in the stage buffer, which holds the tile before), the ranks of consecutive tiles go to two histograms in turn (the second
+	// one lives in the descriptor array: the copying wave holds its buckets' descriptors in registers -- lane l of wave w copies
+	// bucket w + 16 l; count and first staged index it reads itself, the global base comes from the reserving thread through
+	// UniformLds::gbase), the next tile's packed words are written in the tail, and a tile costs TWO barriers: (C) ranks complete and
+	// the stage buffer read out, (E) records staged, the next tile's words and cleared histogram in place.
+	constexpr bool kPipe = REG && !LIN && DBG == 0;
+	if constexpr (kPipe) {
+		constexpr uint32_t kWaves = kL1Threads / 64;
+		constexpr uint32_t kHist2 = (uint32_t)((offsetof(ScatterLds, desc) - offsetof(ScatterLds, hist)) / 4u);
+		static_assert(sizeof(ScatterLds::desc) >= sizeof(ScatterLds::hist), "the second histogram lives in the descriptor array");
+		const uint32_t tid = fresh_tid(), lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+		static_assert(kL1MaxB <= kL1Threads, "thread b reserves bucket b");
+		const uint32_t per_wave = (G.n1 + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * l < n1  (<= 64)
+		const uint32_t mine = wave + kWaves * lane;
+		const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (l1_scatter_tail)
+		uint64_t *const out = P.l1 + (uint64_t)sub * G.cap1;
+		uint32_t *const cnt = P.cnt1 + sub;
+		const uint64_t bucket_stride = (uint64_t)G.n_sub * G.cap1;
+		uint32_t d_lo = 0u, d_gb = 0u; // the runs this wave copies out of the stage buffer: lane l = records << 16 | first staged index, and the global base
+		auto copy_run = [&](uint32_t kk, uint64_t &slow) { // (kk: wave-uniform)
+			const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
+			const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
+			if (n == 0u) return;
+			if ((uint64_t)dst + n > G.cap1) { // the bucket is full: after the positions, record by record
+				slow |= 1ull << kk;
+				return;
+			}
+			// (the bucket's address is scalar arithmetic redone per run: hoisted out of the tile loop, fifteen 64-bit bases cost more
+			// registers than the kernel has)
+			uint32_t b = wave + kWaves * kk;
+			asm volatile("" : "+s"(b));
+			uint64_t *o = out + (uint64_t)b * bucket_stride + dst;
+			typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+			for (uint32_t i = 2u * lane; i < n; i += 128u) { // two records per lane and store instruction (scatter_stage_copy)
+				const uint64_t a = L.stage[src + i];
+				if (i + 1u < n) {
+					const uint64_t b2 = L.stage[src + i + 1u];
+					const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
+					*reinterpret_cast<u32x4_a8 *>(o + i) = v;
+				} else {
+					o[i] = a;
+				}
+			}
+		};
+		auto copy_slow = [&](uint64_t slow) {
+			while (slow) {
+				const uint32_t kk = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(slow));
+				slow &= slow - 1ull;
+				const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
+				const uint32_t n = lo >> 16, src = lo & 0xFFFFu, b = wave + kWaves * kk;
+				uint64_t *o = out + (uint64_t)b * G.n_sub * G.cap1 + dst;
+				for (uint32_t i = lane; i < n; i += 64u) {
+					const uint64_t rcd = L.stage[src + i];
+					if ((uint64_t)dst + i < G.cap1) o[i] = rcd;
+					else push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+				}
+			}
+		};
+		uint32_t cur = 0u; // the histogram of the current tile, in words from L.hist: 0 or kHist2
+		if (blockIdx.x < n_tiles) {
+			open_tile(raw, 0u);
+			lds_barrier();
 		}
-		if constexpr (kOpenInTail) lds_barrier(); // (every wave has left the copy-out of the tile before: the stage buffer is free)
+		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			const Chunk16 c = decode(raw);
+			uint32_t bkt[16];
+			uint64_t rec[16];
+			uint64_t slow = 0ull;
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, true, true, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
+			                                                                    [&](uint32_t i) { copy_run(i, slow); });
+			for (uint32_t kk = (uint32_t)C; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow); // (more than 16 C buckets)
+			if (slow) copy_slow(slow);
+			if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
+			const RawU nxt = fetch(tile + gridDim.x, r0, c0); // (regular tiles: fetch works from the tile index alone)
+			lds_barrier(); // (C) every rank of this tile has been taken, every wave has copied its runs of the tile before
+			// one reservation per non-empty bucket, by thread b as everywhere else: consecutive lanes, consecutive counters -- a handful of
+			// atomic REQUESTS per tile.  (Reserved by the copying lanes themselves -- bucket w + 16 l, sixteen instructions of nine scattered
+			// lanes -- the same 144 atomics took 23 ms instead of 4.7: the counters' five cache lines saw sixteen times the requests.)
+			const uint32_t c_t = tid < G.n1 ? L.hist[cur + tid] : 0u;
+			const uint32_t g_t = c_t ? atomicAdd(&cnt[tid * G.n_sub], c_t) : 0u;
+			const uint32_t c_mine = lane < per_wave ? L.hist[cur + mine] : 0u;
+			scan_hist_per_wave(L, G.n1, cur);
+			d_lo = (c_mine << 16) | (lane < per_wave ? L.lbase[mine] : 0u);
+			if (__builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
+				uint32_t at[C];
+#pragma unroll
+				for (int u = 0; u < C; u++) at[u] = L.lbase[bkt[u] >> 16];
+#pragma unroll
+				for (int u = 0; u < C; u++) L.stage[at[u] + (bkt[u] & 0xFFFFu)] = rec[u];
+			} else {
+#pragma unroll
+				for (int u = 0; u < C; u++)
+					if ((bkt[u] >> 16) < (uint32_t)kL1MaxB) L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
+			}
+			if (tid < G.n1) UL.gbase[tid] = g_t;
+			open_tile(nxt, cur ^ kHist2);
+			lds_barrier(); // (E) the tile is staged, the next one's packed words and cleared histogram are in place
+			d_gb = lane < per_wave ? UL.gbase[mine] : 0u;
+			cur ^= kHist2;
+			raw = nxt;
+		}
+		uint64_t slow = 0ull; // the runs of the workgroup's last tile
+		for (uint32_t kk = 0; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow);
+		if (slow) copy_slow(slow);
+		return;
+	}
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		uint32_t bkt[16];
+		open_tile(raw);
+		lds_barrier();
+		const Chunk16 c = decode(raw);
 		const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile
@@ -1197,7 +1365,6 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		}
 		const RawU nxt = fetch(tile + gridDim.x, r0, c0);
 		if constexpr (LIN) l1_scatter_tail_linear<DBG, C, (WIDE_D >= 2)>(L, G, P, ctr, tid, bkt);
-		else if constexpr (kOpenInTail) l1_scatter_tail<DBG, (WIDE_D >= 2), C>(L, G, P, ctr, tid, bkt, !zero_seen, [&]() { open_tile(nxt); }); // (regular tiles: every window of every lane is valid)
 		else l1_scatter_tail<DBG, (WIDE_D >= 2), (REG ? C : 0)>(L, G, P, ctr, tid, bkt, REG && !zero_seen);
 		raw = nxt;
 	}

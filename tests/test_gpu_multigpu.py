@@ -221,3 +221,24 @@ def test_several_ranks_on_one_gpu_build_the_whole_jobs_graph(extra):
     assert out["verified"] and "== the" in out["verified"] and not out["verified"].startswith("not run"), out["verified"]
     if "cfg4" not in extra:
         assert out["config"]["nodes"] > 1000000
+
+
+@pytest.mark.parametrize("world,rank", [(2, 1), (4, 0), (8, 7)])
+def test_plan_partition_equals_the_geometry_a_sharded_handle_really_gets(world, rank):
+    """dbgk_plan_partition (the device-free planner behind `bench.py --plan-only`) must say what a real sharded handle of the same
+    parameters reports through dbgk_shard_buffers: slot range, buckets per rank and own buckets, bucket and chunk sizes -- for cfg2's
+    per-GPU share at N = 2, 4, 8 (small record stores: only the geometry matters here)"""
+    from dbg_assembly_amd import capi
+    per_gpu = min(600_000_000, (2 ** 32 - 2 ** 22) // world)
+    size = capi.find_next_prime_ref(per_gpu * world)
+    expected = 4_000_000
+    plan = capi.plan_partition(size, expected, world, rank)
+    with capi.Graph(k=31, table_slots=size, engine=capi.ENGINE_PARTITION, expected_kmers=expected, shard_count=world, shard_index=rank) as g:
+        info = g.shard_info()
+        assert (int(info.n_ranks), int(info.rank), int(info.table_slots_global)) == (world, rank, size)
+        assert (int(info.slot_lo), int(info.slot_hi)) == (int(plan.slot_lo), int(plan.slot_hi))
+        assert (int(info.buckets_per_rank), int(info.own_buckets)) == (int(plan.buckets_per_rank), int(plan.own_buckets))
+        assert int(info.bucket_bytes) == int(plan.records_per_level1_bucket) * 8
+        assert int(info.chunk_bytes) == int(plan.buckets_per_rank) * int(plan.records_per_level1_bucket) * 8
+        assert int(plan.inbox_bytes) == world * int(info.chunk_bytes) == int(plan.level1_store_bytes)
+        assert int(plan.table_bytes) == (int(info.slot_hi) - int(info.slot_lo)) * 16
