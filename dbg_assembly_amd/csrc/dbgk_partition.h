@@ -687,7 +687,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16], uint64_t *rec = nullptr,
                                              uint32_t hist_off = 0u, Mid mid = Mid()) // hist_off: the histogram in use, in words from L.hist
 {
-	static_assert(!IN_REGS || (SPECIAL && WIDE_D != 3), "records in registers: regular tiles of a graph handle");
+	static_assert(!IN_REGS || SPECIAL || WIDE_D == 3, "records in registers: regular tiles of a graph handle, or a KFREQ handle with direct blocks (nothing to patch)");
 	uint32_t *const hh = L.hist + (IN_REGS ? hist_off : 0u);
 	// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
 	// first / last window are patched afterwards (rare per lane, so the loop stays lean).
@@ -754,8 +754,13 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 			// four registers per position for two; the rank of the position before is folded into its bucket word one position late,
 			// when the LDS atomic has long returned)
 			uint32_t lo_now = rec_lo, hi_now = rec_hi;
-			asm volatile("" : "+v"(lo_now), "+v"(hi_now));
-			rec[i] = ((uint64_t)hi_now << 32) | lo_now;
+			if constexpr (WIDE_D == 3) { // (32-bit records: q = 0)
+				asm volatile("" : "+v"(lo_now));
+				rec[i] = lo_now;
+			} else {
+				asm volatile("" : "+v"(lo_now), "+v"(hi_now));
+				rec[i] = ((uint64_t)hi_now << 32) | lo_now;
+			}
 			if (i > 0u) asm volatile("" : "+v"(bkt[i - 1u]));
 		} else {
 			L.stage[i * kL1Threads + tid] = ((uint64_t)rec_hi << 32) | rec_lo;
@@ -788,7 +793,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
 	if constexpr (IN_REGS) { // (SPECIAL: only a read's first window, a lane's position 0, and its last one, a lane's position NPOS - 1, lack a side)
 #pragma unroll
-		for (uint32_t e = 0; e < 2u; e++) {
+		for (uint32_t e = 0; e < (WIDE_D == 3 ? 0u : 2u); e++) {
 			const uint32_t i = e ? (uint32_t)NPOS - 1u : 0u;
 			if (e && NPOS == 1) break;
 			const bool nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
@@ -1241,8 +1246,12 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	// bucket w + 16 l; count and first staged index it reads itself, the global base comes from the reserving thread through
 	// UniformLds::gbase), the next tile's packed words are written in the tail, and a tile costs TWO barriers: (C) ranks complete and
 	// the stage buffer read out, (E) records staged, the next tile's words and cleared histogram in place.
-	constexpr bool kPipe = REG && !LIN && DBG == 0;
+	// The same for a KFREQ handle with direct blocks (WIDE_D == 3, equal-length reads of any length): 32-bit records, four per lane
+	// and store in the copy-out, the stage buffer used as 32-bit words.
+	constexpr bool kRec32 = WIDE_D == 3;
+	constexpr bool kPipe = !LIN && DBG == 0 && (REG || (kRec32 && !RAGGED));
 	if constexpr (kPipe) {
+		uint32_t *const stage32 = reinterpret_cast<uint32_t *>(L.stage);
 		constexpr uint32_t kWaves = kL1Threads / 64;
 		constexpr uint32_t kHist2 = (uint32_t)((offsetof(ScatterLds, desc) - offsetof(ScatterLds, hist)) / 4u);
 		static_assert(sizeof(ScatterLds::desc) >= sizeof(ScatterLds::hist), "the second histogram lives in the descriptor array");
@@ -1267,6 +1276,23 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			// registers than the kernel has)
 			uint32_t b = wave + kWaves * kk;
 			asm volatile("" : "+s"(b));
+			if constexpr (kRec32) { // (a level-1 record is (place in the bucket) << 6 | 4 and travels as 32 bits, scatter_stage_copy)
+				static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
+				uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
+				typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+				for (uint32_t i = 4u * lane; i < n; i += 256u) {
+					const uint32_t v0 = stage32[src + i];
+					if (i + 3u < n) {
+						const u32x4_a4 v = {v0, stage32[src + i + 1u], stage32[src + i + 2u], stage32[src + i + 3u]};
+						*reinterpret_cast<u32x4_a4 *>(o32 + i) = v;
+					} else {
+						o32[i] = v0;
+						if (i + 1u < n) o32[i + 1u] = stage32[src + i + 1u];
+						if (i + 2u < n) o32[i + 2u] = stage32[src + i + 2u];
+					}
+				}
+				return;
+			}
 			uint64_t *o = out + (uint64_t)b * bucket_stride + dst;
 			typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 			for (uint32_t i = 2u * lane; i < n; i += 128u) { // two records per lane and store instruction (scatter_stage_copy)
@@ -1287,10 +1313,13 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 				const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
 				const uint32_t n = lo >> 16, src = lo & 0xFFFFu, b = wave + kWaves * kk;
 				uint64_t *o = out + (uint64_t)b * G.n_sub * G.cap1 + dst;
+				uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
 				for (uint32_t i = lane; i < n; i += 64u) {
-					const uint64_t rcd = L.stage[src + i];
-					if ((uint64_t)dst + i < G.cap1) o[i] = rcd;
-					else push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+					const uint64_t rcd = kRec32 ? (uint64_t)stage32[src + i] : L.stage[src + i];
+					if ((uint64_t)dst + i < G.cap1) {
+						if constexpr (kRec32) o32[i] = (uint32_t)rcd;
+						else o[i] = rcd;
+					} else push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
 				}
 			}
 		};
@@ -1304,12 +1333,17 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			uint32_t bkt[16];
 			uint64_t rec[16];
 			uint64_t slow = 0ull;
-			const bool zero_seen = l1_positions<WIDE_D, C, SLds, true, true, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG, REG, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
 			                                                                    [&](uint32_t i) { copy_run(i, slow); });
 			for (uint32_t kk = (uint32_t)C; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow); // (more than 16 C buckets)
 			if (slow) copy_slow(slow);
 			if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
-			const RawU nxt = fetch(tile + gridDim.x, r0, c0); // (regular tiles: fetch works from the tile index alone)
+			if constexpr (!REG) { // (regular tiles: fetch works from the tile index alone)
+				r0 += stride_r;
+				c0 += stride_c;
+				if (c0 >= U.Q) { c0 -= U.Q; r0 += 1u; }
+			}
+			const RawU nxt = fetch(tile + gridDim.x, r0, c0);
 			lds_barrier(); // (C) every rank of this tile has been taken, every wave has copied its runs of the tile before
 			// one reservation per non-empty bucket, by thread b as everywhere else: consecutive lanes, consecutive counters -- a handful of
 			// atomic REQUESTS per tile.  (Reserved by the copying lanes themselves -- bucket w + 16 l, sixteen instructions of nine scattered
@@ -1319,7 +1353,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			const uint32_t c_mine = lane < per_wave ? L.hist[cur + mine] : 0u;
 			scan_hist_per_wave(L, G.n1, cur);
 			d_lo = (c_mine << 16) | (lane < per_wave ? L.lbase[mine] : 0u);
-			if (__builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
+			if (REG && __builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
 				uint32_t at[C];
 #pragma unroll
 				for (int u = 0; u < C; u++) at[u] = L.lbase[bkt[u] >> 16];
@@ -1328,7 +1362,10 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			} else {
 #pragma unroll
 				for (int u = 0; u < C; u++)
-					if ((bkt[u] >> 16) < (uint32_t)kL1MaxB) L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
+					if ((bkt[u] >> 16) < (uint32_t)kL1MaxB) {
+						if constexpr (kRec32) stage32[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = (uint32_t)rec[u];
+						else L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
+					}
 			}
 			if (tid < G.n1) UL.gbase[tid] = g_t;
 			open_tile(nxt, cur ^ kHist2);
