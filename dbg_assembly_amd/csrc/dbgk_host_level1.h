@@ -248,9 +248,18 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		h->uniform_launches++;
 		const int grid = (int)std::min<uint64_t>((WU.n_lanes + kWL1Threads - 1) / kWL1Threads, (uint64_t)h->n_cu);
 		const int wd = h->size >= (1ull << 32) ? 2 : (h->size >= (1ull << 31) ? 1 : 0); // how hash / size is computed
+		// the pipelined form keeps a tile's packed words beside the stage buffer: taken when the bytes a tile of 1024 lanes can touch fit there
+		const bool wpipe = !dbgk_hook("wide_l1_plain") &&
+		                   ((uint64_t)kWL1Threads / WU.Q + 2) * WU.L + 96 <= (uint64_t)(kWPipePkWords - 8u) * 16;
 #define DBGK_LAUNCH_WIDE_L1U(WD)                                                                                                                    \
-	hipLaunchKernelGGL((k_wide_scatter_l1_uniform<WD>), dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, WU, h->wgeom, h->wstore, h->wref(), \
-	                   h->d_ctr)
+	do {                                                                                                                                            \
+		if (wpipe)                                                                                                                                  \
+			hipLaunchKernelGGL((k_wide_scatter_l1_uniform<WD, true>), dim3(grid), dim3(kWL1Threads), sizeof(WL1PipeLds), h->stream, rb, WU, h->wgeom, \
+			                   h->wstore, h->wref(), h->d_ctr);                                                                                     \
+		else                                                                                                                                        \
+			hipLaunchKernelGGL((k_wide_scatter_l1_uniform<WD, false>), dim3(grid), dim3(kWL1Threads), sizeof(WL1Lds), h->stream, rb, WU, h->wgeom,    \
+			                   h->wstore, h->wref(), h->d_ctr);                                                                                     \
+	} while (0)
 		if (wd == 2) DBGK_LAUNCH_WIDE_L1U(2); else if (wd == 1) DBGK_LAUNCH_WIDE_L1U(1); else DBGK_LAUNCH_WIDE_L1U(0);
 #undef DBGK_LAUNCH_WIDE_L1U
 	} else if (wrec) {

@@ -128,9 +128,12 @@ static int setup_wide_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 1>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<false, 2>), sizeof(WL1Lds));
 	DBGK_LDS_ATTR((k_wide_scatter_l1<true, 2>), sizeof(WL1Lds));
-	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<0>), sizeof(WL1Lds));
-	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<1>), sizeof(WL1Lds));
-	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<2>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<0, false>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<1, false>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<2, false>), sizeof(WL1Lds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<0, true>), sizeof(WL1PipeLds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<1, true>), sizeof(WL1PipeLds));
+	DBGK_LDS_ATTR((k_wide_scatter_l1_uniform<2, true>), sizeof(WL1PipeLds));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<1024>, sizeof(WL2Lds<1024>));
 	DBGK_LDS_ATTR(k_wide_scatter_l2<2048>, sizeof(WL2Lds<2048>));
 	DBGK_LDS_ATTR((k_wide_build_regions<true, false>), sizeof(WBuildLds));

@@ -237,6 +237,60 @@ struct WideL1Consts {
 	uint64_t mask_hi, mask_lo;
 };
 
+// One position of a lane's chunk: the canonical k-mer's record (key.hi | q, slot bits, neighbour codes) and its store entry
+// (1024 + lane: none); the chunk state is rolled to the next position.  rev / zero_lo: reverse strand taken, canonical key.lo == 0.
+struct WidePos {
+	uint64_t key_hi, w;
+	uint32_t b;
+	bool rev, zero_lo;
+};
+template <int WIDE_D>
+__device__ __forceinline__ WidePos wide_l1_position(const WPartGeom &G, WChunk16 &c, const WideL1Consts &K, uint32_t i, uint32_t tid)
+{
+	WidePos o;
+	const uint32_t sh = 30u - 2u * i;
+	const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
+	// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97).  Both neighbours are
+	// assumed to exist; windows at a read's first / last position are patched by the caller.
+	const bool rev = c.rc.hi < c.fwd.hi || (c.rc.hi == c.fwd.hi && c.rc.lo < c.fwd.lo);
+	const Key128 key{rev ? c.rc.hi : c.fwd.hi, rev ? c.rc.lo : c.fwd.lo};
+	const uint32_t links = rev ? (((3u - right) << 3) | (3u - left)) : ((left << 3) | right);
+	o.rev = rev;
+	const bool valid = (c.valid >> i) & 1u;
+	o.zero_lo = valid && key.lo == 0ull; // rare: handled by the caller through the atomic path
+	uint64_t q;
+	const uint64_t hv = hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo);
+	uint32_t slot_lo, bucket;
+	if (WIDE_D == 2) {
+		const uint64_t s64 = fast_divmod(hv, G.magic, q);
+		slot_lo = (uint32_t)s64;
+		bucket = (uint32_t)(s64 >> G.r);
+	} else {
+		slot_lo = WIDE_D ? divmod_u64_u32(hv, G.div, q) : divmod_magic_small(hv, G.magic.m, (uint32_t)G.magic.d, q);
+		bucket = slot_lo >> G.r;
+	}
+	o.key_hi = key.hi;
+	o.w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & K.rmask) << 6) | links;
+	// store entry of the bucket: (owner rank, own-bucket index inside this pass's window); other passes' buckets are dropped
+	uint32_t entry = bucket;
+	bool keep = true;
+	if (G.n_l1 != G.n1) {
+		const uint32_t d = (uint32_t)(((uint64_t)bucket * G.bmagic) >> 32);
+		const uint32_t jj = bucket - d * G.B - G.pass_j0;
+		keep = jj < G.Bp;
+		entry = d * G.Bp + jj;
+	}
+	o.b = (valid && key.lo != 0ull && keep) ? entry : 1024u + (tid & 63u);
+	// roll to the next position
+	c.fwd.hi = ((c.fwd.hi << 2) | (c.fwd.lo >> 62)) & K.mask_hi;
+	c.fwd.lo = ((c.fwd.lo << 2) | right) & K.mask_lo;
+	c.rc.lo = (c.rc.lo >> 2) | (c.rc.hi << 62);
+	c.rc.hi >>= 2;
+	const uint64_t comp = (uint64_t)(3u - right);
+	if (K.top >= 64u) c.rc.hi |= comp << (K.top - 64u); else c.rc.lo |= comp << K.top;
+	return o;
+}
+
 template <int WIDE_D>
 __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, const WPartStore &P, const WTable &T, Counters *ctr, WChunk16 &c,
                                              const WideL1Consts &K, unsigned long long &n_new, unsigned long long &n_conf, bool &full)
@@ -246,47 +300,11 @@ __device__ __forceinline__ void wide_l1_tile(WL1Lds &L, const WPartGeom &G, cons
 	uint32_t rev_mask = 0, zero_lo = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < 8u; i++) {
-		const uint32_t sh = 30u - 2u * i;
-		const uint32_t left = (c.lw >> sh) & 3u, right = (c.nb >> sh) & 3u;
-		// canonical pick: tie -> forward (DBGgraph.cpp:80); reverse strand: (comp(right), comp(left)) (:82-97).  The loop
-		// assumes both neighbours exist; windows at a read's first / last position are patched afterwards.
-		const bool rev = c.rc.hi < c.fwd.hi || (c.rc.hi == c.fwd.hi && c.rc.lo < c.fwd.lo);
-		const Key128 key{rev ? c.rc.hi : c.fwd.hi, rev ? c.rc.lo : c.fwd.lo};
-		const uint32_t links = rev ? (((3u - right) << 3) | (3u - left)) : ((left << 3) | right);
-		rev_mask |= (rev ? 1u : 0u) << i;
-		const bool valid = (c.valid >> i) & 1u;
-		zero_lo |= (valid && key.lo == 0ull ? 1u : 0u) << i; // rare: handled after the loop through the atomic path
-		uint64_t q;
-		const uint64_t hv = hash_code(key.hi ? (key.lo ^ hash_code(key.hi)) : key.lo);
-		uint32_t slot_lo, bucket;
-		if (WIDE_D == 2) {
-			const uint64_t s64 = fast_divmod(hv, G.magic, q);
-			slot_lo = (uint32_t)s64;
-			bucket = (uint32_t)(s64 >> G.r);
-		} else {
-			slot_lo = WIDE_D ? divmod_u64_u32(hv, G.div, q) : divmod_magic_small(hv, G.magic.m, (uint32_t)G.magic.d, q);
-			bucket = slot_lo >> G.r;
-		}
-		const uint64_t w = (q << (G.r + 6u)) | ((uint64_t)(slot_lo & K.rmask) << 6) | links;
-		// store entry of the bucket: (owner rank, own-bucket index inside this pass's window); other passes' buckets are dropped
-		uint32_t entry = bucket;
-		bool keep = true;
-		if (G.n_l1 != G.n1) {
-			const uint32_t d = (uint32_t)(((uint64_t)bucket * G.bmagic) >> 32);
-			const uint32_t jj = bucket - d * G.B - G.pass_j0;
-			keep = jj < G.Bp;
-			entry = d * G.Bp + jj;
-		}
-		const uint32_t b = (valid && key.lo != 0ull && keep) ? entry : 1024u + (tid & 63u);
-		L.stage[i * kWL1Threads + tid] = ull2{key.hi, w};
-		bkt[i] = (b << 16) | atomicAdd(&L.hist[b], 1u);
-		// roll to the next position
-		c.fwd.hi = ((c.fwd.hi << 2) | (c.fwd.lo >> 62)) & K.mask_hi;
-		c.fwd.lo = ((c.fwd.lo << 2) | right) & K.mask_lo;
-		c.rc.lo = (c.rc.lo >> 2) | (c.rc.hi << 62);
-		c.rc.hi >>= 2;
-		const uint64_t comp = (uint64_t)(3u - right);
-		if (K.top >= 64u) c.rc.hi |= comp << (K.top - 64u); else c.rc.lo |= comp << K.top;
+		const WidePos o = wide_l1_position<WIDE_D>(G, c, K, i, tid);
+		rev_mask |= (o.rev ? 1u : 0u) << i;
+		zero_lo |= (o.zero_lo ? 1u : 0u) << i;
+		L.stage[i * kWL1Threads + tid] = ull2{o.key_hi, o.w};
+		bkt[i] = (o.b << 16) | atomicAdd(&L.hist[o.b], 1u);
 	}
 	// windows without a left / right neighbour: that side's code becomes 4 = none; keys with lo == 0 go through the
 	// atomic path with their final codes (their parked record sits in a dummy bin and is never copied out)
@@ -408,13 +426,27 @@ struct WUniformGeom {
 };
 constexpr uint32_t kWPkWords = kWL1Threads * 8 * 2 / 4; // the bucket-tag array seen as 32-bit words (4096)
 
-template <int WIDE_D>
+// PIPE (round 5, as the 64-bit engine's regular tiles): the copy-out of a tile runs inside the position loop of the next one -- the
+// records of a tile stay in registers until they are staged in sorted order, the stage buffer, the bucket tags and the descriptors
+// keep the tile before while the next one is ranked, and the tile's packed words get an array of their own (kWPipePkWords: what is
+// left of the 160 KiB beside the stage buffer -- the host takes this form when a tile's byte range fits, wide_uniform_mode).
+struct WL1PipeLds : WL1Lds {
+	static constexpr int kPkWords = (160 * 1024 - 128 - (int)sizeof(WL1Lds)) / 4; // (128 bytes: the static array of wide_l1_finish)
+	uint32_t pk[kPkWords];
+};
+constexpr uint32_t kWPipePkWords = WL1PipeLds::kPkWords;
+
+template <int WIDE_D, bool PIPE = false>
 __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBatch rb, WUniformGeom U, WPartGeom G, WPartStore P, WTable T,
                                                                         Counters *__restrict__ ctr)
 {
+	using LdsT = typename std::conditional<PIPE, WL1PipeLds, WL1Lds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	WL1Lds &L = *reinterpret_cast<WL1Lds *>(lds_raw);
-	uint32_t *pk = reinterpret_cast<uint32_t *>(L.bucket_of);
+	LdsT &L = *reinterpret_cast<LdsT *>(lds_raw);
+	uint32_t *pk;
+	if constexpr (PIPE) pk = L.pk;
+	else pk = reinterpret_cast<uint32_t *>(L.bucket_of);
+	constexpr uint32_t kPk = PIPE ? kWPipePkWords : kWPkWords;
 	unsigned long long n_new = 0, n_conf = 0;
 	bool full = false;
 	const uint32_t k = (uint32_t)rb.k;
@@ -438,7 +470,7 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 		const uint32_t drl = (xl * U.qmagic) >> 22;
 		uint64_t end = (R.r0 + drl) * U.L + 8u * (xl - drl * U.Q) + 8u + k + 2u;
 		end = min(end, (rb.n_bases + 15u) & ~15ull);
-		R.n_blocks = end > R.B0 ? min((uint32_t)((end - R.B0 + 15u) >> 4), kWPkWords - 8u) : 0u;
+		R.n_blocks = end > R.B0 ? min((uint32_t)((end - R.B0 + 15u) >> 4), kPk - 8u) : 0u;
 		return R;
 	};
 	// the first two 16-byte blocks of a lane (block tid, block tid + 1024) are requested one tile ahead
@@ -453,72 +485,196 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 			if (t + kWL1Threads < R.n_blocks) b = load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + t + kWL1Threads);
 		}
 	};
-	Range R = range_of(blockIdx.x);
-	uint4 ra, rb2;
-	fetch(R, ra, rb2);
-	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const uint32_t tid = fresh_tid();
-		const uint64_t lane0 = tile * kWL1Threads;
-		const uint64_t r0 = R.r0, B0 = R.B0;
-		const uint32_t c0 = R.c0, n_blocks = R.n_blocks;
-		// (+ 8 words of 'A' padding: a lane reads seven words from its first)
+	// the tile's packed words into LDS (+ 8 words of 'A' padding: a lane reads seven words from its first)
+	auto fill_pk = [&](const Range &R, const uint4 &ra, const uint4 &rb2) {
+		const uint32_t tid = fresh_tid(), n_blocks = R.n_blocks;
 		if (rb.packed) {
 			if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? ra.x : 0u;
 			if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? rb2.x : 0u;
 			for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
-				pk[b] = b < n_blocks ? packed_word(rb, (B0 >> 4) + b) : 0u;
+				pk[b] = b < n_blocks ? packed_word(rb, (R.B0 >> 4) + b) : 0u;
 		} else {
 			if (tid < n_blocks + 8u) pk[tid] = tid < n_blocks ? pack16_ascii(ra, rb.other_seen) : 0u;
 			if (tid + kWL1Threads < n_blocks + 8u) pk[tid + kWL1Threads] = tid + kWL1Threads < n_blocks ? pack16_ascii(rb2, rb.other_seen) : 0u;
 			for (uint32_t b = tid + 2u * kWL1Threads; b < n_blocks + 8u; b += kWL1Threads) // long reads: the rest of the range, loaded here
-				pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (B0 >> 4) + b), rb.other_seen) : 0u;
+				pk[b] = b < n_blocks ? pack16_ascii(load_ascii16(rb.bases, rb.n_bases, (R.B0 >> 4) + b), rb.other_seen) : 0u;
 		}
+	};
+	// a lane's chunk of 8 windows out of the packed words
+	auto decode = [&](const Range &R, uint64_t lane0) {
+		const uint32_t tid = fresh_tid();
+		WChunk16 c;
+		const uint32_t x = R.c0 + tid;
+		const uint32_t dr = (x * U.qmagic) >> 22;
+		const uint32_t cc = x - dr * U.Q;
+		const uint32_t first_w = 8u * cc;   // index of the lane's first window inside its read
+		const bool live = lane0 + tid < U.n_lanes && first_w < U.W;
+		const uint64_t p = (R.r0 + dr) * U.L + first_w; // flat position of the lane's first window
+		const uint64_t s0 = p ? p - 1u : 0u;           // the packed stream starts one base earlier (left neighbour)
+		const uint32_t rel = live ? (uint32_t)(s0 - R.B0) : 0u;
+		const uint32_t d = rel >> 4, sh = 2u * (rel & 15u);
+		const uint32_t x0 = pk[d], x1 = pk[d + 1], x2 = pk[d + 2], x3 = pk[d + 3], x4 = pk[d + 4], x5 = pk[d + 5], x6 = pk[d + 6];
+		const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh),
+		               X4 = funnel_left(x4, x5, sh), X5 = funnel_left(x5, x6, sh);
+		// stream Y starts at position p (X starts at p - 1 unless p == 0)
+		const uint32_t adv = p ? 2u : 0u;
+		const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = funnel_left(X3, X4, adv),
+		               Y4 = funnel_left(X4, X5, adv);
+		c.lw = p ? X0 : (X0 >> 2); // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
+		const uint64_t A = ((uint64_t)Y0 << 32) | Y1, B = ((uint64_t)Y2 << 32) | Y3, C = (uint64_t)Y4 << 32;
+		if (2u * k <= 64u) {
+			c.fwd.hi = 0ull;
+			c.fwd.lo = A >> (64u - 2u * k);
+		} else {
+			const uint32_t s2 = 128u - 2u * k; // 2..62
+			c.fwd.hi = A >> s2;
+			c.fwd.lo = (B >> s2) | (A << (64u - s2));
+		}
+		c.rc = dbgk_wide::revcomp(c.fwd, (int)k);
+		{
+			const uint32_t off = 2u * k; // 2..126
+			const uint64_t top = (uint64_t)(((((u128)A << 64) | B) << off) >> 64);
+			const uint64_t tail = off > 64u ? (C >> (128u - off)) : 0ull;
+			c.nb = (uint32_t)((top | tail) >> 32);
+		}
+		const uint32_t nv = live ? min(8u, U.W - first_w) : 0u;
+		const uint32_t nr = (live && first_w + 1u < U.W) ? min(8u, U.W - 1u - first_w) : 0u;
+		c.valid = (1u << nv) - 1u;
+		c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
+		c.has_l = cc ? 0xFFu : 0xFEu;       // its first window no left one
+		return c;
+	};
+	Range R = range_of(blockIdx.x);
+	uint4 ra, rb2;
+	fetch(R, ra, rb2);
+	if constexpr (PIPE) {
+		const uint32_t tid = fresh_tid();
+		uint32_t total_prev = 0u; // records of the tile before, sorted in the stage buffer
+		// element u of the tile before: staged record u * 1024 + t goes to its bucket; a full bucket's records are left for after the positions
+		auto copy_elem = [&](uint32_t u, uint32_t &slow) {
+			const uint32_t p = u * kWL1Threads + tid;
+			if (p >= total_prev) return;
+			const ull2 rcd = L.stage[p];
+			const uint32_t b = L.bucket_of[p];
+			const uint64_t off = (uint64_t)(uint32_t)(L.desc[b] + p); // desc = reserved place - first staged index
+			if (off < G.cap1) P.l1[(uint64_t)b * G.cap1 + off] = rcd;
+			else slow |= 1u << u;
+		};
+		auto copy_slow = [&](uint32_t slow) { // the bucket is full
+			for (; slow; slow &= slow - 1u) {
+				const uint32_t p = (uint32_t)__builtin_ctz(slow) * kWL1Threads + tid;
+				const ull2 rcd = L.stage[p];
+				const uint32_t b = L.bucket_of[p];
+				wide_push_overflow(P, wide_record_key(rcd, wide_entry_bucket(b, G), G), (uint32_t)(rcd.y >> 3) & 7u, (uint32_t)rcd.y & 7u, ctr);
+			}
+		};
+		if (blockIdx.x < n_tiles) {
+			fill_pk(R, ra, rb2);
+			L.hist[tid] = 0u; // kBpt == 1
+			if (tid < 64u) L.hist[1024u + tid] = 0u;
+			lds_barrier();
+		}
+		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			WChunk16 c = decode(R, tile * kWL1Threads);
+			const Range Rn = range_of(tile + gridDim.x);
+			fetch(Rn, ra, rb2); // in flight during this tile
+			ull2 rec[8];
+			uint32_t bkt[8];
+			uint32_t rev_mask = 0, zero_lo = 0, slow = 0;
+#pragma unroll
+			for (uint32_t i = 0; i < 8u; i++) {
+				copy_elem(i, slow);
+				const WidePos o = wide_l1_position<WIDE_D>(G, c, K, i, tid);
+				uint32_t rbit = o.rev ? 1u : 0u, zbit = o.zero_lo ? 1u : 0u;
+				rev_mask |= rbit << i;
+				zero_lo |= zbit << i;
+				// (built HERE and kept: left to itself the compiler sinks the packing below the loop and keeps its inputs alive instead)
+				uint32_t w0 = (uint32_t)o.w, w1 = (uint32_t)(o.w >> 32);
+				asm volatile("" : "+v"(w0), "+v"(w1), "+v"(rev_mask), "+v"(zero_lo));
+				rec[i] = ull2{o.key_hi, ((uint64_t)w1 << 32) | w0};
+				if (i > 0u) asm volatile("" : "+v"(bkt[i - 1u]));
+				bkt[i] = (o.b << 16) | atomicAdd(&L.hist[o.b], 1u);
+			}
+			if (slow) copy_slow(slow);
+			// windows without a left / right neighbour: that side's code becomes 4 = none; keys with lo == 0 go through the atomic path
+			// with their final codes (their record has no bucket)
+			const uint32_t no_l = ~c.has_l & 0xFFu, no_r = ~c.has_r & 0xFFu, v8 = c.valid & 0xFFu;
+			if (const uint32_t fix = ((no_l | no_r) & v8) | zero_lo) {
+#pragma unroll
+				for (uint32_t i = 0; i < 8u; i++) {
+					if (!((fix >> i) & 1u)) continue;
+					const bool fwd_strand = !((rev_mask >> i) & 1u), nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+					uint32_t lb = ((uint32_t)rec[i].y >> 3) & 7u, rbb = (uint32_t)rec[i].y & 7u;
+					if (fwd_strand ? nl : nr) lb = 4u;
+					if (fwd_strand ? nr : nl) rbb = 4u;
+					rec[i].y = (rec[i].y & ~63ull) | (lb << 3) | rbb;
+				}
+				for (uint32_t z = zero_lo; z; z &= z - 1u) { // (rare: one inlined insert, the record picked by a chain of selects)
+					const uint32_t i = (uint32_t)__builtin_ctz(z);
+					ull2 r = rec[0];
+#pragma unroll
+					for (uint32_t j = 1; j < 8u; j++) r = (i == j) ? rec[j] : r;
+					if (G.pass == 0u) wide_insert(T, Key128{r.x, 0ull}, ((uint32_t)r.y >> 3) & 7u, (uint32_t)r.y & 7u, ctr, n_new, n_conf, full); // (once per job: the input is read once per pass)
+				}
+			}
+			lds_barrier(); // (C) every rank taken; the stage buffer, the tags and the descriptors of the tile before read out; the packed words decoded
+			// thread b: reserve bucket b's run, scan, clear the histogram entry for the next tile
+			const uint32_t c_t = L.hist[tid];
+			L.hist[tid] = 0u;
+			if (tid < 64u) L.hist[1024u + tid] = 0u; // (the bins of the positions without a record)
+			const uint32_t g_t = (tid < G.n_l1 && c_t) ? atomicAdd(&P.cnt1[tid], c_t) : 0u;
+			uint32_t inc = c_t;
+			{
+				const uint32_t lane = tid & 63u;
+#pragma unroll
+				for (int off = 1; off < 64; off <<= 1) {
+					const uint32_t n = __shfl_up(inc, off, 64);
+					if ((int)lane >= off) inc += n;
+				}
+				if (lane == 63u) L.wave_tot[tid >> 6] = inc;
+			}
+			lds_barrier();
+			uint32_t run = inc - c_t, all = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < kWL1Threads / 64; w++) {
+				const uint32_t wt = L.wave_tot[w];
+				run += (w < (tid >> 6)) ? wt : 0u;
+				all += wt;
+			}
+			L.lbase[tid] = run;
+			lds_barrier(); // every bucket's first staged index is known; `all` = the tile's records with a bucket
+#pragma unroll
+			for (uint32_t i = 0; i < 8u; i++)
+				if ((bkt[i] >> 16) < 1024u) {
+					const uint32_t at = L.lbase[bkt[i] >> 16] + (bkt[i] & 0xFFFFu);
+					L.stage[at] = rec[i];
+					L.bucket_of[at] = (uint16_t)(bkt[i] >> 16);
+				}
+			L.desc[tid] = g_t - run;
+			fill_pk(Rn, ra, rb2);
+			lds_barrier(); // (E) the tile is staged, the next one's packed words are in place
+			total_prev = all;
+			R = Rn;
+		}
+		{ // the workgroup's last tile
+			uint32_t slow = 0;
+#pragma unroll 1
+			for (uint32_t u = 0; u < 8u; u++) copy_elem(u, slow);
+			if (slow) copy_slow(slow);
+		}
+		wide_l1_finish(n_new, n_conf, full, ctr);
+		return;
+	}
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		fill_pk(R, ra, rb2);
+		const Range Rc = R;
 		R = range_of(tile + gridDim.x);
 		fetch(R, ra, rb2); // in flight during this tile
 		L.hist[tid] = 0u;
 		if (tid < 64u) L.hist[1024u + tid] = 0u;
 		lds_barrier();
-		WChunk16 c;
-		{
-			const uint32_t x = c0 + tid;
-			const uint32_t dr = (x * U.qmagic) >> 22;
-			const uint32_t cc = x - dr * U.Q;
-			const uint32_t first_w = 8u * cc;   // index of the lane's first window inside its read
-			const bool live = lane0 + tid < U.n_lanes && first_w < U.W;
-			const uint64_t p = (r0 + dr) * U.L + first_w; // flat position of the lane's first window
-			const uint64_t s0 = p ? p - 1u : 0u;           // the packed stream starts one base earlier (left neighbour)
-			const uint32_t rel = live ? (uint32_t)(s0 - B0) : 0u;
-			const uint32_t d = rel >> 4, sh = 2u * (rel & 15u);
-			const uint32_t x0 = pk[d], x1 = pk[d + 1], x2 = pk[d + 2], x3 = pk[d + 3], x4 = pk[d + 4], x5 = pk[d + 5], x6 = pk[d + 6];
-			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh),
-			               X4 = funnel_left(x4, x5, sh), X5 = funnel_left(x5, x6, sh);
-			// stream Y starts at position p (X starts at p - 1 unless p == 0)
-			const uint32_t adv = p ? 2u : 0u;
-			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = funnel_left(X3, X4, adv),
-			               Y4 = funnel_left(X4, X5, adv);
-			c.lw = p ? X0 : (X0 >> 2); // bases p-1 .. p+14 (the base before position 0 does not exist: has_l excludes it)
-			const uint64_t A = ((uint64_t)Y0 << 32) | Y1, B = ((uint64_t)Y2 << 32) | Y3, C = (uint64_t)Y4 << 32;
-			if (2u * k <= 64u) {
-				c.fwd.hi = 0ull;
-				c.fwd.lo = A >> (64u - 2u * k);
-			} else {
-				const uint32_t s2 = 128u - 2u * k; // 2..62
-				c.fwd.hi = A >> s2;
-				c.fwd.lo = (B >> s2) | (A << (64u - s2));
-			}
-			c.rc = dbgk_wide::revcomp(c.fwd, (int)k);
-			{
-				const uint32_t off = 2u * k; // 2..126
-				const uint64_t top = (uint64_t)(((((u128)A << 64) | B) << off) >> 64);
-				const uint64_t tail = off > 64u ? (C >> (128u - off)) : 0ull;
-				c.nb = (uint32_t)((top | tail) >> 32);
-			}
-			const uint32_t nv = live ? min(8u, U.W - first_w) : 0u;
-			const uint32_t nr = (live && first_w + 1u < U.W) ? min(8u, U.W - 1u - first_w) : 0u;
-			c.valid = (1u << nv) - 1u;
-			c.has_r = (1u << nr) - 1u;          // the read's last window has no right neighbour
-			c.has_l = cc ? 0xFFu : 0xFEu;       // its first window no left one
-		}
+		WChunk16 c = decode(Rc, tile * kWL1Threads);
 		wide_l1_tile<WIDE_D>(L, G, P, T, ctr, c, K, n_new, n_conf, full);
 	}
 	wide_l1_finish(n_new, n_conf, full, ctr);

@@ -367,10 +367,16 @@ def test_wide_records_path_cfg5_shaped_sample_PARITY_UNPINNED(capi, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,L", [(63, 150), (63, 64), (63, 63), (47, 100), (33, 250), (32, 150), (17, 150), (5, 36)])
-def test_wide_records_path_equal_length_reads_PARITY_UNPINNED_above_k32(capi, oracle, k, L):
+@pytest.mark.parametrize("k,L,plain", [(63, 150, 0), (63, 150, 1), (63, 64, 0), (63, 63, 0), (47, 100, 0), (33, 250, 0), (33, 250, 1), (32, 150, 0), (17, 150, 0),
+                                       (5, 36, 0)])
+def test_wide_records_path_equal_length_reads_PARITY_UNPINNED_above_k32(capi, oracle, monkeypatch, k, L, plain):
     """batches of equal-length reads take k_wide_scatter_l1_uniform (lanes mapped to chunks of 8 valid windows, bases
-    funnelled out of an LDS-packed byte range) unless k is so small against L that the flat kernel wastes nothing"""
+    funnelled out of an LDS-packed byte range) unless k is so small against L that the flat kernel wastes nothing; its pipelined
+    form (copy-out of a tile inside the next tile's positions) where a tile's packed words fit beside the stage buffer -- (63, 150),
+    (33, 250), (32, 150) -- and the plain form elsewhere or when the hook asks for it"""
+    if plain:
+        from helpers import set_hooks
+        set_hooks(monkeypatch, wide_l1_plain=1)
     rng = random.Random(k * 1000 + L)
     G = 20000
     g = "".join(rng.choice("ACGT") for _ in range(G))
