@@ -853,27 +853,29 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 		const ull2 *in = P.l2 + (uint64_t)fl * G.cap2;
 		uint32_t n_new_r = 0, n_conf_r = 0, sat = 0; // of this region: committed only when the region is emitted
 		bool flag = false;
-		for (uint32_t base = 0; base < filled; base += kWBuildThreads) {
+		// two records per thread in flight: the pair of the NEXT round is requested before this round's records are probed (the
+		// kernel's read rate is bytes in flight / latency: one 16-byte load per thread and round kept it at 2.8 TB/s)
+		// (every lane loads, past the end the bucket's last record again: a load under a branch would make the compiler wait for ALL
+		// loads in flight at the next use -- `live` decides what is used)
+		const uint32_t last = filled ? filled - 1u : 0u;
+		auto load_rec = [&](uint32_t i) { return __builtin_nontemporal_load(in + min(i, last)); };
+		auto round = [&](const ull2 &rec, uint32_t base) { // one record per thread: records base .. base + kWBuildThreads - 1
 			const uint32_t i = base + t;
 			const bool live = i < filled;
-			const ull2 rec = live ? __builtin_nontemporal_load(in + i) : ull2{0ull, 0ull};
 			const unsigned long long id = (rec.y >> 6) + 1ull, want_hi1 = rec.x + 1ull;
 			const uint32_t lb = (uint32_t)(rec.y >> 3) & 7u, rb = (uint32_t)rec.y & 7u;
 			const uint32_t home = (uint32_t)(rec.y >> 6) & (kWRegionSlots - 1u);
 			uint32_t idx = home;
 			bool probing = live, lost = false;
 			while (probing) {
-				unsigned long long cur = __hip_atomic_load(&L.ident[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				bool mine = false;
-				if (cur == 0ull) {
-					const unsigned long long prev = atomicCAS(&L.ident[idx], 0ull, id);
-					if (prev == 0ull) {
-						__hip_atomic_store(&L.hi1[idx], want_hi1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						mine = true;
-						n_new_r += idx < region_len ? 1u : 0u; // spilled nodes are counted when they are merged
-					}
-					cur = prev == 0ull ? id : prev;
+				// one compare-swap per probe, whatever the slot holds: it claims an empty slot or tells whose it is (no load in front of it)
+				const unsigned long long prev = atomicCAS(&L.ident[idx], 0ull, id);
+				const bool mine = prev == 0ull;
+				if (mine) {
+					__hip_atomic_store(&L.hi1[idx], want_hi1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					n_new_r += idx < region_len ? 1u : 0u; // spilled nodes are counted when they are merged
 				}
+				const unsigned long long cur = mine ? id : prev;
 				bool hit = mine, step = cur != id;
 				if (cur == id && !mine) {
 					const unsigned long long h1 = __hip_atomic_load(&L.hi1[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -911,6 +913,14 @@ __global__ __launch_bounds__(kWBuildThreads) void k_wide_build_regions(WPartGeom
 				old = prev;
 			}
 			if (!FAST && live && lost) wide_push_overflow(P, wide_record_key(rec, b1, G), lb, rb, ctr);
+		};
+		// (two rounds per trip, each with a register pair of its own: nothing is copied, so nothing waits for the load behind it)
+		ull2 ra = load_rec(t), rb2 = load_rec(kWBuildThreads + t);
+		for (uint32_t base = 0; base < filled; base += 2u * kWBuildThreads) {
+			round(ra, base);
+			ra = load_rec(base + 2u * kWBuildThreads + t);
+			if (base + kWBuildThreads < filled) round(rb2, base + kWBuildThreads); // (workgroup-uniform)
+			rb2 = load_rec(base + 3u * kWBuildThreads + t);
 		}
 		bool redo_region = false;
 		if constexpr (FAST) {
