@@ -423,16 +423,15 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 			uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * cap + dst;
 			if ((uint64_t)dst + n <= cap) {
 				typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-				for (uint32_t i = 4u * lane; i < n; i += 256u) { // four records per lane and store instruction
-					const uint32_t v0 = (uint32_t)L.stage[src + i];
-					if (i + 3u < n) {
-						const u32x4_a4 v = {v0, (uint32_t)L.stage[src + i + 1u], (uint32_t)L.stage[src + i + 2u], (uint32_t)L.stage[src + i + 3u]};
-						*reinterpret_cast<u32x4_a4 *>(o32 + i) = v;
-					} else {
-						o32[i] = v0;
-						if (i + 1u < n) o32[i + 1u] = (uint32_t)L.stage[src + i + 1u];
-						if (i + 2u < n) o32[i + 2u] = (uint32_t)L.stage[src + i + 2u];
+				if (n >= 4u) { // four records per lane and store instruction; the lane whose four would reach past the run takes the run's
+					// LAST four (a few records written twice with the same value: no narrow store instructions behind the wide one)
+					for (uint32_t i = 4u * lane; i < n; i += 256u) {
+						const uint32_t j = min(i, n - 4u);
+						const u32x4_a4 v = {(uint32_t)L.stage[src + j], (uint32_t)L.stage[src + j + 1u], (uint32_t)L.stage[src + j + 2u], (uint32_t)L.stage[src + j + 3u]};
+						*reinterpret_cast<u32x4_a4 *>(o32 + j) = v;
 					}
+				} else if (lane < n) {
+					o32[lane] = (uint32_t)L.stage[src + lane];
 				}
 			} else {
 				for (uint32_t i = lane; i < n; i += 64) {
@@ -450,20 +449,16 @@ __device__ __forceinline__ void scatter_stage_copy(LDS &L, const uint64_t (&rec)
 			// two records per lane and store instruction (16 bytes, 8-byte aligned): the memory pipe charges per instruction,
 			// whatever its lane count (level 1: 5.68 -> 5.54 ms against one record per lane, profiles/ab_bench.sh)
 			typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-			for (uint32_t i = 2u * lane; i < n; i += 128u) {
-				const uint64_t a = L.stage[src + i];
-				if (i + 1u < n) {
-					const uint64_t b2 = L.stage[src + i + 1u];
+			if (n >= 2u) { // the lane left with the odd last record takes the run's last TWO (round 5: one store instruction per 128 records
+				// whatever the run's length -- level 1 4.11 -> 3.92 ms in the pipelined form, profiles/r05_l1_overlap_store_ab.txt)
+				for (uint32_t i = 2u * lane; i < n; i += 128u) {
+					const uint32_t j = min(i, n - 2u);
+					const uint64_t a = L.stage[src + j], b2 = L.stage[src + j + 1u];
 					const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
-#if defined(DBGK_NT_COPYOUT)
-					if ((DBGK_NT_COPYOUT & 1) && bucket_is_b1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8 *>(o + i));
-					else if ((DBGK_NT_COPYOUT & 2) && !bucket_is_b1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a8 *>(o + i));
-					else
-#endif
-					*reinterpret_cast<u32x4_a8 *>(o + i) = v;
-				} else {
-					o[i] = a;
+					*reinterpret_cast<u32x4_a8 *>(o + j) = v;
 				}
+			} else if (lane == 0u) {
+				o[0] = L.stage[src];
 			}
 		} else { // the bucket is full: records beyond its capacity go to the overflow list
 			for (uint32_t i = lane; i < n; i += 64) {
@@ -1280,30 +1275,30 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 				static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
 				uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
 				typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-				for (uint32_t i = 4u * lane; i < n; i += 256u) {
-					const uint32_t v0 = stage32[src + i];
-					if (i + 3u < n) {
-						const u32x4_a4 v = {v0, stage32[src + i + 1u], stage32[src + i + 2u], stage32[src + i + 3u]};
-						*reinterpret_cast<u32x4_a4 *>(o32 + i) = v;
-					} else {
-						o32[i] = v0;
-						if (i + 1u < n) o32[i + 1u] = stage32[src + i + 1u];
-						if (i + 2u < n) o32[i + 2u] = stage32[src + i + 2u];
+				if (n >= 4u) { // (wave-uniform) the lane whose four would reach past the run takes the run's LAST four instead: one store
+					// instruction per 256 records whatever the run's length, a few records written twice with the same value
+					for (uint32_t i = 4u * lane; i < n; i += 256u) {
+						const uint32_t j = min(i, n - 4u);
+						const u32x4_a4 v = {stage32[src + j], stage32[src + j + 1u], stage32[src + j + 2u], stage32[src + j + 3u]};
+						*reinterpret_cast<u32x4_a4 *>(o32 + j) = v;
 					}
+				} else if (lane < n) {
+					o32[lane] = stage32[src + lane];
 				}
 				return;
 			}
 			uint64_t *o = out + (uint64_t)b * bucket_stride + dst;
 			typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-			for (uint32_t i = 2u * lane; i < n; i += 128u) { // two records per lane and store instruction (scatter_stage_copy)
-				const uint64_t a = L.stage[src + i];
-				if (i + 1u < n) {
-					const uint64_t b2 = L.stage[src + i + 1u];
+			if (n >= 2u) { // (wave-uniform) two records per lane and store instruction; the lane left with the odd last record takes the
+				// run's last TWO instead (one record written twice with the same value: no 8-byte store instruction behind the others)
+				for (uint32_t i = 2u * lane; i < n; i += 128u) {
+					const uint32_t j = min(i, n - 2u);
+					const uint64_t a = L.stage[src + j], b2 = L.stage[src + j + 1u];
 					const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
-					*reinterpret_cast<u32x4_a8 *>(o + i) = v;
-				} else {
-					o[i] = a;
+					*reinterpret_cast<u32x4_a8 *>(o + j) = v;
 				}
+			} else if (lane == 0u) {
+				o[0] = L.stage[src];
 			}
 		};
 		auto copy_slow = [&](uint64_t slow) {
