@@ -576,8 +576,6 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 		}
 		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 			WChunk16 c = decode(R, tile * kWL1Threads);
-			const Range Rn = range_of(tile + gridDim.x);
-			fetch(Rn, ra, rb2); // in flight during this tile
 			ull2 rec[8];
 			uint32_t bkt[8];
 			uint32_t rev_mask = 0, zero_lo = 0, slow = 0;
@@ -617,6 +615,10 @@ __global__ __launch_bounds__(kWL1Threads) void k_wide_scatter_l1_uniform(ReadBat
 					if (G.pass == 0u) wide_insert(T, Key128{r.x, 0ull}, ((uint32_t)r.y >> 3) & 7u, (uint32_t)r.y & 7u, ctr, n_new, n_conf, full); // (once per job: the input is read once per pass)
 				}
 			}
+			// the next tile's blocks: requested behind the positions (the eight registers of an ASCII batch's two blocks are not there to
+			// be had during them), in flight across the barrier, the scan and the staging
+			const Range Rn = range_of(tile + gridDim.x);
+			fetch(Rn, ra, rb2);
 			lds_barrier(); // (C) every rank taken; the stage buffer, the tags and the descriptors of the tile before read out; the packed words decoded
 			// thread b: reserve bucket b's run, scan, clear the histogram entry for the next tile
 			const uint32_t c_t = L.hist[tid];
