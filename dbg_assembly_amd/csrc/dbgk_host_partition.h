@@ -160,8 +160,11 @@ static int plan_partition(dbgk_handle *h)
 	const double per_slot = (double)expected / (double)h->size;
 	G.cap1 = (uint64_t)(per_slot * (double)(1ull << r) * 1.05 / (double)G.n_sub) + 65536 / G.n_sub + (G.n_sub > 1 ? 8192 : 0); // per sub-store
 	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
-	G.cap1 = (G.cap1 + 15u) & ~15ull; // every bucket starts on a 128-byte line: the 16-byte record loads of level 2 and of the build are aligned
-	G.cap2 = (G.cap2 + 15u) & ~15ull;
+	// every bucket starts on a 128-byte line (the 16-byte record loads of level 2 and of the build are aligned), and a bucket is an ODD
+	// number of lines long: the append points of neighbouring buckets then fall on neighbouring lines modulo any power of two, whatever
+	// the memory system's channel interleave (WIDE level 2 moved between 44 and 50 ms from process to process until its strides were odd)
+	G.cap1 = ((G.cap1 + 15u) & ~15ull) | 16u;
+	G.cap2 = ((G.cap2 + 15u) & ~15ull) | 16u;
 	G.r_rec = r;
 	G.l2_shift = 0;
 	G.l2_records = 16u * (uint32_t)l2_threads((int)G.n2);

@@ -86,6 +86,10 @@ static bool plan_wide_partition(dbgk_handle *h, bool *err)
 	const double per_slot_mine = (double)h->cfg.expected_kmers / (double)h->size;
 	G.cap1 = (uint64_t)(per_slot_mine * (double)(1ull << r) * 1.05) + 65536;
 	G.cap2 = (uint64_t)(per_slot_mine * (double)n_ranks * (double)kWRegionSlots * 1.25) + 512;
+	// bucket strides of an ODD number of 128-byte lines: the append points of neighbouring buckets then fall on neighbouring lines
+	// (modulo any power of two), whatever the memory system's channel interleave
+	G.cap1 = ((G.cap1 + 7u) & ~7ull) | 8u;
+	G.cap2 = ((G.cap2 + 7u) & ~7ull) | 8u;
 	G.chunk_buckets = (G.Bp + 7u) / 8u;
 	h->wmulti = want_shard || n_passes > 1;
 	h->sharded = n_ranks > 1;
