@@ -35,10 +35,10 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	U.n_lanes = n_reads * Q;
 	U.lq = 0;
 	U.tile_blocks = 0; // 0: no regular tiles
-	// (the regular form also assumes k >= 17 -- the rolls then only touch the high words --, reads that fill their lanes exactly,
-	// and a graph handle: no KFREQ neighbour codes)
+	// (the regular form also assumes k >= 17 -- the rolls then only touch the high words -- and a graph handle: no KFREQ neighbour
+	// codes; reads that fill their lanes exactly, Q C == W, take its FULL instantiation, the others test every position's validity)
 	if ((Q & (Q - 1)) == 0 && Q <= (uint64_t)kL1Threads && (((uint64_t)kL1Threads / Q) * L) % 16 == 0 &&
-	    ((uint64_t)kL1Threads / Q) * L / 16 + 8 <= (uint64_t)kPkWords && k >= 17 && Q * C == (uint64_t)W && !h->kfreq) {
+	    ((uint64_t)kL1Threads / Q) * L / 16 + 8 <= (uint64_t)kPkWords && k >= 17 && !h->kfreq) {
 		while ((1ull << U.lq) < Q) U.lq++;
 		U.tile_blocks = (uint32_t)(((uint64_t)kL1Threads / Q) * L / 16);
 	}
@@ -351,9 +351,16 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 				ReadBatch rr = rb;
 				rr.n_bases = full_tiles * reads_per_tile * U.L;
 				const int grid_r = (int)std::min<uint64_t>(full_tiles, (uint64_t)h->n_cu * l1_wgs_per_cu());
+				const bool full = (uint64_t)U.Q * (c15 ? 15u : 16u) == (uint64_t)U.W; // the reads fill their lanes exactly
 #define DBGK_LAUNCH_REG(WIDE, CC, PK)                                                                                                                  \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true, PK>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds), h->stream, rr, \
-	                   UR, d_offsets, h->geom, h->store, h->d_ctr)
+	do {                                                                                                                                               \
+		if (full)                                                                                                                                      \
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true, PK, true>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds),  \
+			                   h->stream, rr, UR, d_offsets, h->geom, h->store, h->d_ctr);                                                            \
+		else                                                                                                                                           \
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, true, PK, false>), dim3(grid_r), dim3(kL1Threads), sizeof(UniformLds), \
+			                   h->stream, rr, UR, d_offsets, h->geom, h->store, h->d_ctr);                                                            \
+	} while (0)
 				if (d_packed) {
 					if (c15) { if (wide == 2) DBGK_LAUNCH_REG(2, 15, true); else if (wide == 1) DBGK_LAUNCH_REG(1, 15, true); else DBGK_LAUNCH_REG(0, 15, true); }
 					else { if (wide == 2) DBGK_LAUNCH_REG(2, 16, true); else if (wide == 1) DBGK_LAUNCH_REG(1, 16, true); else DBGK_LAUNCH_REG(0, 16, true); }

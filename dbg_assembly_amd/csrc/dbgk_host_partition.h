@@ -270,8 +270,14 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true>), sizeof(UniformLds));  \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, true>), sizeof(UniformLds));  \
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true>), sizeof(UniformLds)); \
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, false, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true, false, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, true, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true, true, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, false, false>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true, false, false>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, true, false>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true, true, false>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter<true, 0, W>), sizeof(ScatterLds));              \
 	DBGK_LDS_ATTR((k_extract_scatter<false, 0, W>), sizeof(ScatterLds))
 #ifdef DBGK_EXPERIMENTS // timing experiments (DBGK_DEBUG_MODE, results are wrong): not in the product library

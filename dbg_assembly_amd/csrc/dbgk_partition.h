@@ -682,7 +682,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
                                              uint32_t rel_mask, uint32_t q_shift, uint32_t (&bkt)[16], uint64_t *rec = nullptr,
                                              uint32_t hist_off = 0u, Mid mid = Mid()) // hist_off: the histogram in use, in words from L.hist
 {
-	static_assert(!IN_REGS || SPECIAL || WIDE_D == 3, "records in registers: regular tiles of a graph handle, or a KFREQ handle with direct blocks (nothing to patch)");
+	static_assert(!IN_REGS || SPECIAL || ROLL32 || WIDE_D == 3, "records in registers: regular tiles of a graph handle, or a KFREQ handle with direct blocks (nothing to patch)");
 	uint32_t *const hh = L.hist + (IN_REGS ? hist_off : 0u);
 	// The per-position path assumes both neighbours exist; the ~2 % of positions at a read's
 	// first / last window are patched afterwards (rare per lane, so the loop stays lean).
@@ -786,7 +786,21 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	}
 	// windows without a left / right neighbour: that side's code becomes 4 = none
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
-	if constexpr (IN_REGS) { // (SPECIAL: only a read's first window, a lane's position 0, and its last one, a lane's position NPOS - 1, lack a side)
+	if constexpr (IN_REGS && !SPECIAL && WIDE_D != 3) { // any position may be a read's first or last window: a predicated pass over the registers
+		if (const uint32_t fix = (no_l | no_r) & c.valid) {
+#pragma unroll
+			for (uint32_t i = 0; i < (uint32_t)NPOS; i++) {
+				if (!((fix >> i) & 1u)) continue;
+				const bool nl = (no_l >> i) & 1u, nr = (no_r >> i) & 1u;
+				const bool fwd = !((rev_mask >> ((uint32_t)NPOS - 1u - i)) & 1u);
+				uint32_t lb = ((uint32_t)rec[i] >> 3) & 7u, rbb = (uint32_t)rec[i] & 7u;
+				if (fwd ? nl : nr) lb = 4u;
+				if (fwd ? nr : nl) rbb = 4u;
+				rec[i] = (rec[i] & ~63ull) | (lb << 3) | rbb;
+			}
+		}
+		return zero_acc != 0u;
+	} else if constexpr (IN_REGS) { // (SPECIAL: only a read's first window, a lane's position 0, and its last one, a lane's position NPOS - 1, lack a side)
 #pragma unroll
 		for (uint32_t e = 0; e < (WIDE_D == 3 ? 0u : 2u); e++) {
 			const uint32_t i = e ? (uint32_t)NPOS - 1u : 0u;
@@ -1090,13 +1104,16 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // the reads that are left
 // PACKED (regular tiles only; the other forms test rb.packed at run time): the batch came 2-bit packed -- a tile is tile_blocks
 // WORDS, one or two per lane, and nothing is packed on the way into LDS
-template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false, bool PACKED = false>
+// FULL (regular tiles): the reads fill their lanes exactly (W = Q C: every window of every lane is valid); without it the last lane of
+// a read holds fewer than C windows (151-base reads at k = 31: 121 = 7 * 16 + 9) and the positions test their validity
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false, bool PACKED = false, bool FULL = true>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
 	static_assert(!LIN || C == 8 || C == 12, "the linear form stages 8 or 12 records per thread");
 	static_assert(!REG || (!RAGGED && !LIN), "regular tiles: equal-length reads, wave-per-bucket form");
 	static_assert(!PACKED || REG, "the other forms test rb.packed at run time");
+	static_assert(FULL || (REG && DBG == 0), "partly filled lanes: the pipelined regular tiles");
 	using ULds = typename std::conditional<LIN, UniformLdsLin<LIN ? C : 8>, UniformLds>::type;
 	using SLds = typename std::conditional<LIN, ScatterLdsLin<LIN ? C : 8>, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1328,7 +1345,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			uint32_t bkt[16];
 			uint64_t rec[16];
 			uint64_t slow = 0ull;
-			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG, REG, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG && FULL, REG, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
 			                                                                    [&](uint32_t i) { copy_run(i, slow); });
 			for (uint32_t kk = (uint32_t)C; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow); // (more than 16 C buckets)
 			if (slow) copy_slow(slow);
@@ -1348,7 +1365,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			const uint32_t c_mine = lane < per_wave ? L.hist[cur + mine] : 0u;
 			scan_hist_per_wave(L, G.n1, cur);
 			d_lo = (c_mine << 16) | (lane < per_wave ? L.lbase[mine] : 0u);
-			if (REG && __builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
+			if (REG && FULL && __builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
 				uint32_t at[C];
 #pragma unroll
 				for (int u = 0; u < C; u++) at[u] = L.lbase[bkt[u] >> 16];
