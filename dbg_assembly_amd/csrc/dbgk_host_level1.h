@@ -325,14 +325,20 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		h->uniform_launches++;
 		const int wide = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // (direct blocks: the 64-bit slot path)
 		const bool ragged = umode == 2;
+		const bool k17 = h->cfg.kmer_size >= 17 && !dbgk_hook("l1_plain"); // equal lengths: the pipelined tile loop (32-bit rolls)
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
+#define DBGK_LAUNCH_UNIFORM_K17(WIDE, CC)                                                                                                         \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, false, false, true, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), \
+	                   h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr)
 #define DBGK_LAUNCH_UNIFORM_W(WIDE)                                    \
 	do {                                                               \
 		if (c15 && ragged) DBGK_LAUNCH_UNIFORM(WIDE, 15, true);        \
-		else if (c15) DBGK_LAUNCH_UNIFORM(WIDE, 15, false);            \
 		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);          \
+		else if (k17 && c15) DBGK_LAUNCH_UNIFORM_K17(WIDE, 15);        \
+		else if (k17) DBGK_LAUNCH_UNIFORM_K17(WIDE, 16);               \
+		else if (c15) DBGK_LAUNCH_UNIFORM(WIDE, 15, false);            \
 		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
 	} while (0)
 #define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \
@@ -341,7 +347,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		static const int dbg_mode_u = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE")) : 0;
 		static const bool no_reg = DBGK_EXPERIMENT_ENV("DBGK_L1_NO_REG") != nullptr; // A/B: the general form everywhere
 		bool rest_only = false;
-		if (!dbg_mode_u && !no_reg && umode == 1 && !lin8 && U.tile_blocks) {
+		if (!dbg_mode_u && !no_reg && !dbgk_hook("l1_plain") && umode == 1 && !lin8 && U.tile_blocks) {
 			// regular tiles: kL1Threads / Q whole reads each, from a 16-byte boundary; the reads behind the last whole tile
 			// (fewer than kL1Threads / Q) go through the general form below
 			const uint64_t reads_per_tile = (uint64_t)kL1Threads / U.Q, full_tiles = n_reads / reads_per_tile;
@@ -402,6 +408,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		else DBGK_LAUNCH_UNIFORM_W(0);
 #undef DBGK_LAUNCH_UNIFORM8
 #undef DBGK_LAUNCH_UNIFORM_W
+#undef DBGK_LAUNCH_UNIFORM_K17
 #undef DBGK_LAUNCH_UNIFORM
 	} else if (h->part) {
 		const uint64_t n_tiles = (n_chunks + kL1Threads - 1) / kL1Threads;

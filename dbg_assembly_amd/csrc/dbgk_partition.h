@@ -787,7 +787,7 @@ __device__ __forceinline__ bool l1_positions(LDS &L, const PartGeom &G, Chunk16 
 	// windows without a left / right neighbour: that side's code becomes 4 = none
 	const uint32_t no_l = ~c.has_l & 0xFFFFu, no_r = ~c.has_r & 0xFFFFu;
 	if constexpr (IN_REGS && !SPECIAL && WIDE_D != 3) { // any position may be a read's first or last window: a predicated pass over the registers
-		if (const uint32_t fix = (no_l | no_r) & c.valid) {
+		if (const uint32_t fix = G.kf ? 0u : (no_l | no_r) & c.valid) { // (KFREQ through hashed regions: (lb, rb) = (0, none) everywhere)
 #pragma unroll
 			for (uint32_t i = 0; i < (uint32_t)NPOS; i++) {
 				if (!((fix >> i) & 1u)) continue;
@@ -1106,7 +1106,10 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 // WORDS, one or two per lane, and nothing is packed on the way into LDS
 // FULL (regular tiles): the reads fill their lanes exactly (W = Q C: every window of every lane is valid); without it the last lane of
 // a read holds fewer than C windows (151-base reads at k = 31: 121 = 7 * 16 + 9) and the positions test their validity
-template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false, bool PACKED = false, bool FULL = true>
+// K17 (the general equal-length form): k >= 17 -- the launch may take the pipelined tile loop with the 32-bit rolls (regular tiles
+// always have it)
+template <int DBG = 0, int WIDE_D = 0, int C = 16, bool RAGGED = false, bool LIN = false, bool REG = false, bool PACKED = false, bool FULL = true,
+          bool K17 = REG>
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatch rb, UniformGeom U, const uint64_t *__restrict__ offsets,
                                                                          PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
@@ -1114,6 +1117,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	static_assert(!REG || (!RAGGED && !LIN), "regular tiles: equal-length reads, wave-per-bucket form");
 	static_assert(!PACKED || REG, "the other forms test rb.packed at run time");
 	static_assert(FULL || (REG && DBG == 0), "partly filled lanes: the pipelined regular tiles");
+	static_assert(K17 || !REG, "regular tiles: k >= 17");
 	using ULds = typename std::conditional<LIN, UniformLdsLin<LIN ? C : 8>, UniformLds>::type;
 	using SLds = typename std::conditional<LIN, ScatterLdsLin<LIN ? C : 8>, ScatterLds>::type;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1261,7 +1265,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	// The same for a KFREQ handle with direct blocks (WIDE_D == 3, equal-length reads of any length): 32-bit records, four per lane
 	// and store in the copy-out, the stage buffer used as 32-bit words.
 	constexpr bool kRec32 = WIDE_D == 3;
-	constexpr bool kPipe = !LIN && DBG == 0 && (REG || (kRec32 && !RAGGED));
+	constexpr bool kPipe = !LIN && DBG == 0 && (REG || ((kRec32 || K17) && !RAGGED));
 	if constexpr (kPipe) {
 		uint32_t *const stage32 = reinterpret_cast<uint32_t *>(L.stage);
 		constexpr uint32_t kWaves = kL1Threads / 64;
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			uint32_t bkt[16];
 			uint64_t rec[16];
 			uint64_t slow = 0ull;
-			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG && FULL, REG, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG && FULL, K17, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
 			                                                                    [&](uint32_t i) { copy_run(i, slow); });
 			for (uint32_t kk = (uint32_t)C; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow); // (more than 16 C buckets)
 			if (slow) copy_slow(slow);

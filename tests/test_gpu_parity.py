@@ -1013,8 +1013,9 @@ def test_push_reads_from_page_locked_memory_skips_the_staging_copy(capi, oracle)
             assert np.array_equal(g.export_sorted(), ref.nodes)
 
 
-@pytest.mark.parametrize("k,L", [(31, 150), (23, 150), (31, 94), (17, 136), (32, 151), (31, 151), (25, 140), (31, 145), (21, 151)])
-def test_equal_length_reads_in_regular_tiles_equal_oracle(capi, oracle, k, L):
+@pytest.mark.parametrize("k,L,plain", [(31, 150, 0), (23, 150, 0), (31, 94, 0), (17, 136, 0), (32, 151, 0), (31, 151, 0), (25, 140, 0), (31, 145, 0),
+                                       (21, 151, 0), (31, 100, 0), (19, 250, 0), (15, 100, 0), (31, 150, 1), (21, 151, 1)])
+def test_equal_length_reads_in_regular_tiles_equal_oracle(capi, oracle, monkeypatch, k, L, plain):
     """The regular-tile form of the equal-length level-1 kernel (every tile = 1024 / Q whole reads from a 16-byte boundary,
     Q a power of two, reads that fill their lanes exactly, k >= 17: rolls on 32-bit halves, no per-position validity test)
     on the inputs its short cuts could get wrong: poly-A / poly-T reads and long A / T runs inside reads (key 0 is kept
@@ -1022,13 +1023,17 @@ def test_equal_length_reads_in_regular_tiles_equal_oracle(capi, oracle, k, L):
     and a remainder that takes the general form.  (k, L) cover 15 and 16 windows per lane, 4 / 8 lanes per read, k = 17
     (the entering complement base lands on bit 0 of the high word) and k = 32 (mask of all ones); the last four are reads that do
     NOT fill their lanes (151 bases at k = 31: 121 windows = 7 x 16 + 9; 140 at k = 25: 7 x 15 + 11; 145 at k = 31: 7 x 15 + 10;
-    151 at k = 21: 8 x 16 + 3 ... in 16 lanes it is not regular: 9 x 15 - 4), the form whose positions test their validity."""
+    151 at k = 21: 8 x 16 + 3 ... in 16 lanes it is not regular: 9 x 15 - 4), the form whose positions test their validity.
+    Lane counts that are no power of two (nine lanes at (21, 151), five at (31, 100), fifteen at (19, 250)) take the general
+    equal-length form, pipelined from k = 17 on ((15, 100): its plain tile loop); plain = 1 forces the plain loop everywhere."""
+    if plain:
+        set_hooks(monkeypatch, l1_plain=1)
     rng = random.Random(31000 + 100 * k + L)
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
     genome = "".join(rng.choice("ACGT") for _ in range(6000))
     genome = genome[:2000] + "A" * (k + 5) + genome[2000:4000] + "T" * (2 * k) + genome[4000:]
     reads = []
-    lanes_per_read = {(31, 150): 8, (23, 150): 8, (31, 94): 4, (17, 136): 8, (32, 151): 8, (31, 151): 8, (25, 140): 8, (31, 145): 8, (21, 151): 9}[(k, L)]
+    lanes_per_read = {(31, 150): 8, (23, 150): 8, (31, 94): 4, (17, 136): 8, (32, 151): 8, (31, 151): 8, (25, 140): 8, (31, 145): 8, (21, 151): 9, (31, 100): 5, (19, 250): 15, (15, 100): 6}[(k, L)]
     n = 5 * (1024 // lanes_per_read) + 37
     for i in range(n):
         x = rng.random()
