@@ -329,16 +329,18 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)
-#define DBGK_LAUNCH_UNIFORM_K17(WIDE, CC)                                                                                                         \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, false, false, false, false, true, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), \
+#define DBGK_LAUNCH_UNIFORM_K17(WIDE, CC, RAG)                                                                                                    \
+	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, false, false, false, true, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), \
 	                   h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr)
 #define DBGK_LAUNCH_UNIFORM_W(WIDE)                                    \
 	do {                                                               \
-		if (c15 && ragged) DBGK_LAUNCH_UNIFORM(WIDE, 15, true);        \
-		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);          \
-		else if (k17 && c15) DBGK_LAUNCH_UNIFORM_K17(WIDE, 15);        \
-		else if (k17) DBGK_LAUNCH_UNIFORM_K17(WIDE, 16);               \
-		else if (c15) DBGK_LAUNCH_UNIFORM(WIDE, 15, false);            \
+		if (k17 && c15 && ragged) DBGK_LAUNCH_UNIFORM_K17(WIDE, 15, true); \
+		else if (k17 && ragged) DBGK_LAUNCH_UNIFORM_K17(WIDE, 16, true);   \
+		else if (k17 && c15) DBGK_LAUNCH_UNIFORM_K17(WIDE, 15, false);     \
+		else if (k17) DBGK_LAUNCH_UNIFORM_K17(WIDE, 16, false);            \
+		else if (c15 && ragged) DBGK_LAUNCH_UNIFORM(WIDE, 15, true);       \
+		else if (ragged) DBGK_LAUNCH_UNIFORM(WIDE, 16, true);              \
+		else if (c15) DBGK_LAUNCH_UNIFORM(WIDE, 15, false);                \
 		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
 	} while (0)
 #define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \

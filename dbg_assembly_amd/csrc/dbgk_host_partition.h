@@ -272,6 +272,8 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, true>), sizeof(UniformLds));  \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, false, false, true, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, false, false, true, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, true, false, false, false, true, true>), sizeof(UniformLds)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, true, false, false, false, true, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, false, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 15, false, false, true, false, true>), sizeof(UniformLds)); \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 16, false, false, true, true, true>), sizeof(UniformLds)); \

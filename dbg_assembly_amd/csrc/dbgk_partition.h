@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 	// The same for a KFREQ handle with direct blocks (WIDE_D == 3, equal-length reads of any length): 32-bit records, four per lane
 	// and store in the copy-out, the stage buffer used as 32-bit words.
 	constexpr bool kRec32 = WIDE_D == 3;
-	constexpr bool kPipe = !LIN && DBG == 0 && (REG || ((kRec32 || K17) && !RAGGED));
+	constexpr bool kPipe = !LIN && DBG == 0 && (REG || K17 || (kRec32 && !RAGGED));
 	if constexpr (kPipe) {
 		uint32_t *const stage32 = reinterpret_cast<uint32_t *>(L.stage);
 		constexpr uint32_t kWaves = kL1Threads / 64;
