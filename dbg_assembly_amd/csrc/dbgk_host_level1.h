@@ -311,7 +311,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		                   (uint32_t)h->cfg.max_read_len, h->pf_bsum, h->pf_ent, h->pf_tile_first, h->d_ctr);                                     \
 		hipLaunchKernelGGL((k_prefix_tiles<CC>), dim3((tiles_max + 255) / 256), dim3(256), 0, h->stream, h->pf_ent, h->pf_tile_first, h->pf_tot,    \
 		                   (uint32_t)h->cfg.kmer_size, n_bases, h->pf_tiles);                                                                     \
-		if (h->cfg.kmer_size >= 17)                                                                                                                 \
+		if (h->cfg.kmer_size >= 17 && h->geom.kf != 2u && h->geom.n1 <= kPrefixPipeMaxB && !dbgk_hook("l1_plain")) /* the pipelined tile loop */   \
 			hipLaunchKernelGGL((k_extract_scatter_prefix<WIDE, CC, true>), dim3(grid_p), dim3(kL1Threads), sizeof(PrefixLds), h->stream, rb, h->pf_ent, \
 			                   h->pf_tiles, h->pf_tot, h->geom, h->store, h->d_ctr);                                                              \
 		else                                                                                                                                      \
@@ -325,7 +325,8 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		h->uniform_launches++;
 		const int wide = (h->geom.kf == 2u || h->geom.size >= (1ull << 32)) ? 2 : (h->geom.size >= (1ull << 31) ? 1 : 0); // (direct blocks: the 64-bit slot path)
 		const bool ragged = umode == 2;
-		const bool k17 = h->cfg.kmer_size >= 17 && !dbgk_hook("l1_plain"); // equal lengths: the pipelined tile loop (32-bit rolls)
+		// equal lengths, ragged: the pipelined tile loop (32-bit rolls; 64-bit records -- a KFREQ handle with direct blocks has its own instantiation)
+		const bool k17 = h->cfg.kmer_size >= 17 && h->geom.kf != 2u && !dbgk_hook("l1_plain");
 #define DBGK_LAUNCH_UNIFORM(WIDE, CC, RAG)                                                                                                   \
 	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG>), dim3(grid), dim3(kL1Threads), sizeof(UniformLds), h->stream, rb, U, \
 	                   d_offsets, h->geom, h->store, h->d_ctr)

@@ -1094,6 +1094,155 @@ __device__ __forceinline__ void l1_key0_from_chunk(Chunk16 c, uint64_t head_mask
 	}
 }
 
+// ---- the pipelined tile loop of level 1 (k_extract_scatter_uniform, k_extract_scatter_prefix) ------------------------------------
+// (round 5: level 1 4.74 -> 3.92 ms on cfg2, profiles/r05_l1_pipelined_ab.txt.)  The copy-out of a tile runs INSIDE the position loop
+// of the next one -- a run's LDS read and its store between two positions' arithmetic, instead of a phase of its own in which the
+// vector ALUs idle.  The records of a tile stay in registers until they are staged in sorted order (nothing is parked in the stage
+// buffer, which holds the tile before), the ranks of consecutive tiles go to two histograms in turn (the second one lives in the
+// descriptor array: the copying wave holds its buckets' descriptors in registers -- lane l of wave w copies bucket w + 16 l; count and
+// first staged index it reads itself, the reserved place comes from the reserving thread through `gbase` in LDS), the next tile is
+// opened in the tail, and a tile costs TWO barriers: (C) ranks complete and the stage buffer read out, (E) records staged, the next
+// tile's words and cleared histogram in place.  Per tile:
+//     positions (l1_positions<..., IN_REGS>, mid(i) = copy_run(i)); copy_rest; fetch of the tile after; barrier (C);
+//     tail(rec, bkt, ..., open_next)   -- reserve, scan, stage, hand-over, open_next(histogram to clear), barrier (E)
+// and after the last tile copy_rest(0).  REC32: a KFREQ handle with direct blocks -- 32-bit records, four per lane and store, the
+// stage buffer used as 32-bit words.
+template <bool REC32>
+struct L1Pipe {
+	static constexpr uint32_t kWaves = kL1Threads / 64;
+	static constexpr uint32_t kHist2 = (uint32_t)((offsetof(ScatterLds, desc) - offsetof(ScatterLds, hist)) / 4u);
+	static_assert(sizeof(ScatterLds::desc) >= sizeof(ScatterLds::hist), "the second histogram lives in the descriptor array");
+	static_assert(kL1MaxB <= kL1Threads, "thread b reserves bucket b");
+	ScatterLds &L;
+	uint32_t *const gbase; // LDS, >= n1 words: a bucket's reserved place, from the thread that reserved it to the wave that copies the run
+	const PartGeom &G;
+	const PartStore &P;
+	Counters *const ctr;
+	uint32_t tid, lane, wave, per_wave, mine;
+	uint64_t *out;
+	uint32_t *cnt;
+	uint64_t bucket_stride;
+	uint32_t d_lo = 0u, d_gb = 0u; // the runs this wave copies out of the stage buffer: lane l = records << 16 | first staged index, and the global base
+	uint32_t cur = 0u;             // the histogram of the current tile, in words from L.hist: 0 or kHist2
+
+	__device__ __forceinline__ L1Pipe(ScatterLds &L_, uint32_t *gbase_, const PartGeom &G_, const PartStore &P_, Counters *ctr_)
+	    : L(L_), gbase(gbase_), G(G_), P(P_), ctr(ctr_)
+	{
+		tid = fresh_tid();
+		lane = tid & 63u;
+		wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+		per_wave = (G.n1 + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * l < n1  (<= 64)
+		mine = wave + kWaves * lane;
+		const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (l1_scatter_tail)
+		out = P.l1 + (uint64_t)sub * G.cap1;
+		cnt = P.cnt1 + sub;
+		bucket_stride = (uint64_t)G.n_sub * G.cap1;
+	}
+	__device__ __forceinline__ uint32_t *stage32() const { return reinterpret_cast<uint32_t *>(L.stage); }
+
+	__device__ __forceinline__ void copy_run(uint32_t kk, uint64_t &slow) const // (kk: wave-uniform)
+	{
+		const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
+		const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
+		if (n == 0u) return;
+		if ((uint64_t)dst + n > G.cap1) { // the bucket is full: after the positions, record by record
+			slow |= 1ull << kk;
+			return;
+		}
+		// (the bucket's address is scalar arithmetic redone per run: hoisted out of the tile loop, fifteen 64-bit bases cost more
+		// registers than the kernel has)
+		uint32_t b = wave + kWaves * kk;
+		asm volatile("" : "+s"(b));
+		if constexpr (REC32) { // (a level-1 record is (place in the bucket) << 6 | 4 and travels as 32 bits, scatter_stage_copy)
+			static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
+			uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
+			const uint32_t *s32 = stage32();
+			typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+			if (n >= 4u) { // (wave-uniform) the lane whose four would reach past the run takes the run's LAST four instead: one store
+				// instruction per 256 records whatever the run's length, a few records written twice with the same value
+				for (uint32_t i = 4u * lane; i < n; i += 256u) {
+					const uint32_t j = min(i, n - 4u);
+					const u32x4_a4 v = {s32[src + j], s32[src + j + 1u], s32[src + j + 2u], s32[src + j + 3u]};
+					*reinterpret_cast<u32x4_a4 *>(o32 + j) = v;
+				}
+			} else if (lane < n) {
+				o32[lane] = s32[src + lane];
+			}
+			return;
+		}
+		uint64_t *o = out + (uint64_t)b * bucket_stride + dst;
+		typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+		if (n >= 2u) { // (wave-uniform) two records per lane and store instruction; the lane left with the odd last record takes the
+			// run's last TWO instead (one record written twice with the same value: no 8-byte store instruction behind the others)
+			for (uint32_t i = 2u * lane; i < n; i += 128u) {
+				const uint32_t j = min(i, n - 2u);
+				const uint64_t a = L.stage[src + j], b2 = L.stage[src + j + 1u];
+				const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
+				*reinterpret_cast<u32x4_a8 *>(o + j) = v;
+			}
+		} else if (lane == 0u) {
+			o[0] = L.stage[src];
+		}
+	}
+	__device__ __forceinline__ void copy_slow(uint64_t slow) const
+	{
+		while (slow) {
+			const uint32_t kk = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(slow));
+			slow &= slow - 1ull;
+			const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
+			const uint32_t n = lo >> 16, src = lo & 0xFFFFu, b = wave + kWaves * kk;
+			uint64_t *o = out + (uint64_t)b * G.n_sub * G.cap1 + dst;
+			uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
+			for (uint32_t i = lane; i < n; i += 64u) {
+				const uint64_t rcd = REC32 ? (uint64_t)stage32()[src + i] : L.stage[src + i];
+				if ((uint64_t)dst + i < G.cap1) {
+					if constexpr (REC32) o32[i] = (uint32_t)rcd;
+					else o[i] = rcd;
+				} else push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+			}
+		}
+	}
+	// the wave's runs from the `from`-th on (behind the positions: more than 16 C buckets; behind the last tile: all), then the full buckets
+	__device__ __forceinline__ void copy_rest(uint32_t from, uint64_t slow) const
+	{
+		for (uint32_t kk = from; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow);
+		if (slow) copy_slow(slow);
+	}
+	// behind barrier (C): reserve, scan, stage the tile's records, hand the reservations over, open the next tile, barrier (E).
+	// SURE: the caller's lanes hold C records each, all with a bucket, unless a lane has seen a zero key (regular tiles that fill their lanes)
+	template <int C, bool SURE, class Open>
+	__device__ __forceinline__ void tail(const uint64_t (&rec)[16], const uint32_t (&bkt)[16], bool zero_seen, Open open_next)
+	{
+		// one reservation per non-empty bucket, by thread b as everywhere else: consecutive lanes, consecutive counters -- a handful of
+		// atomic REQUESTS per tile.  (Reserved by the copying lanes themselves -- bucket w + 16 l, sixteen instructions of nine scattered
+		// lanes -- the same 144 atomics took 23 ms instead of 4.7: the counters' five cache lines saw sixteen times the requests.)
+		const uint32_t c_t = tid < G.n1 ? L.hist[cur + tid] : 0u;
+		const uint32_t g_t = c_t ? atomicAdd(&cnt[tid * G.n_sub], c_t) : 0u;
+		const uint32_t c_mine = lane < per_wave ? L.hist[cur + mine] : 0u;
+		scan_hist_per_wave(L, G.n1, cur);
+		d_lo = (c_mine << 16) | (lane < per_wave ? L.lbase[mine] : 0u);
+		if (SURE && __builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
+			uint32_t at[C];
+#pragma unroll
+			for (int u = 0; u < C; u++) at[u] = L.lbase[bkt[u] >> 16];
+#pragma unroll
+			for (int u = 0; u < C; u++) L.stage[at[u] + (bkt[u] & 0xFFFFu)] = rec[u];
+		} else {
+#pragma unroll
+			for (int u = 0; u < C; u++)
+				if ((bkt[u] >> 16) < (uint32_t)kL1MaxB) {
+					if constexpr (REC32) stage32()[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = (uint32_t)rec[u];
+					else L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
+				}
+		}
+		if (tid < G.n1) gbase[tid] = g_t;
+		open_next(cur ^ kHist2);
+		lds_barrier(); // (E) the tile is staged, the next one's packed words and cleared histogram are in place
+		d_gb = lane < per_wave ? gbase[mine] : 0u;
+		cur ^= kHist2;
+	}
+};
+
 // RAGGED: the reads are NOT all L long.  Every read still gets Q = ceil(W_max / C) lanes (W_max from the
 // longest read of the batch, L holds its length), a read's own offset and length come from `offsets`, and
 // the lanes past a shorter read's last window stay empty.  Worth it when most reads have (nearly) the full
@@ -1254,92 +1403,13 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		c.has_l = raw.cc ? 0xFFFFu : 0xFFFEu; // its first window no left one
 		return c;
 	};
-	// PIPELINED regular tiles (round 5: level 1 4.74 -> 4.13 ms, profiles/r05_l1_pipelined_ab.txt): the copy-out of a tile runs INSIDE
-	// the position loop of the next one -- a run's LDS read and its store between two positions' arithmetic, instead of a phase of its
-	// own in which the vector ALUs idle.  The records of a tile stay in registers until they are staged in sorted order (nothing is
-	// parked in the stage buffer, which holds the tile before), the ranks of consecutive tiles go to two histograms in turn (the second
-	// one lives in the descriptor array: the copying wave holds its buckets' descriptors in registers -- lane l of wave w copies
-	// bucket w + 16 l; count and first staged index it reads itself, the global base comes from the reserving thread through
-	// UniformLds::gbase), the next tile's packed words are written in the tail, and a tile costs TWO barriers: (C) ranks complete and
-	// the stage buffer read out, (E) records staged, the next tile's words and cleared histogram in place.
-	// The same for a KFREQ handle with direct blocks (WIDE_D == 3, equal-length reads of any length): 32-bit records, four per lane
-	// and store in the copy-out, the stage buffer used as 32-bit words.
+	// PIPELINED tile loop (L1Pipe): regular tiles, every batch of equal-length or mostly full-length reads from k = 17 on, and
+	// a KFREQ handle with direct blocks (WIDE_D == 3, equal-length reads of any length: 32-bit records).
 	constexpr bool kRec32 = WIDE_D == 3;
 	constexpr bool kPipe = !LIN && DBG == 0 && (REG || K17 || (kRec32 && !RAGGED));
 	if constexpr (kPipe) {
-		uint32_t *const stage32 = reinterpret_cast<uint32_t *>(L.stage);
-		constexpr uint32_t kWaves = kL1Threads / 64;
-		constexpr uint32_t kHist2 = (uint32_t)((offsetof(ScatterLds, desc) - offsetof(ScatterLds, hist)) / 4u);
-		static_assert(sizeof(ScatterLds::desc) >= sizeof(ScatterLds::hist), "the second histogram lives in the descriptor array");
-		const uint32_t tid = fresh_tid(), lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-		static_assert(kL1MaxB <= kL1Threads, "thread b reserves bucket b");
-		const uint32_t per_wave = (G.n1 + kWaves - 1u - wave) / kWaves; // buckets wave + kWaves * l < n1  (<= 64)
-		const uint32_t mine = wave + kWaves * lane;
-		const uint32_t sub = blockIdx.x % G.n_sub; // this workgroup's sub-store (l1_scatter_tail)
-		uint64_t *const out = P.l1 + (uint64_t)sub * G.cap1;
-		uint32_t *const cnt = P.cnt1 + sub;
-		const uint64_t bucket_stride = (uint64_t)G.n_sub * G.cap1;
-		uint32_t d_lo = 0u, d_gb = 0u; // the runs this wave copies out of the stage buffer: lane l = records << 16 | first staged index, and the global base
-		auto copy_run = [&](uint32_t kk, uint64_t &slow) { // (kk: wave-uniform)
-			const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
-			const uint32_t n = lo >> 16, src = lo & 0xFFFFu;
-			if (n == 0u) return;
-			if ((uint64_t)dst + n > G.cap1) { // the bucket is full: after the positions, record by record
-				slow |= 1ull << kk;
-				return;
-			}
-			// (the bucket's address is scalar arithmetic redone per run: hoisted out of the tile loop, fifteen 64-bit bases cost more
-			// registers than the kernel has)
-			uint32_t b = wave + kWaves * kk;
-			asm volatile("" : "+s"(b));
-			if constexpr (kRec32) { // (a level-1 record is (place in the bucket) << 6 | 4 and travels as 32 bits, scatter_stage_copy)
-				static_assert(kSubStores == 1, "the 32-bit level-1 store is addressed without sub-stores");
-				uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
-				typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-				if (n >= 4u) { // (wave-uniform) the lane whose four would reach past the run takes the run's LAST four instead: one store
-					// instruction per 256 records whatever the run's length, a few records written twice with the same value
-					for (uint32_t i = 4u * lane; i < n; i += 256u) {
-						const uint32_t j = min(i, n - 4u);
-						const u32x4_a4 v = {stage32[src + j], stage32[src + j + 1u], stage32[src + j + 2u], stage32[src + j + 3u]};
-						*reinterpret_cast<u32x4_a4 *>(o32 + j) = v;
-					}
-				} else if (lane < n) {
-					o32[lane] = stage32[src + lane];
-				}
-				return;
-			}
-			uint64_t *o = out + (uint64_t)b * bucket_stride + dst;
-			typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-			if (n >= 2u) { // (wave-uniform) two records per lane and store instruction; the lane left with the odd last record takes the
-				// run's last TWO instead (one record written twice with the same value: no 8-byte store instruction behind the others)
-				for (uint32_t i = 2u * lane; i < n; i += 128u) {
-					const uint32_t j = min(i, n - 2u);
-					const uint64_t a = L.stage[src + j], b2 = L.stage[src + j + 1u];
-					const u32x4_a8 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b2, (uint32_t)(b2 >> 32)};
-					*reinterpret_cast<u32x4_a8 *>(o + j) = v;
-				}
-			} else if (lane == 0u) {
-				o[0] = L.stage[src];
-			}
-		};
-		auto copy_slow = [&](uint64_t slow) {
-			while (slow) {
-				const uint32_t kk = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_ctzll(slow));
-				slow &= slow - 1ull;
-				const uint32_t lo = __builtin_amdgcn_readlane(d_lo, kk), dst = __builtin_amdgcn_readlane(d_gb, kk);
-				const uint32_t n = lo >> 16, src = lo & 0xFFFFu, b = wave + kWaves * kk;
-				uint64_t *o = out + (uint64_t)b * G.n_sub * G.cap1 + dst;
-				uint32_t *o32 = reinterpret_cast<uint32_t *>(out) + (uint64_t)b * G.cap1 + dst;
-				for (uint32_t i = lane; i < n; i += 64u) {
-					const uint64_t rcd = kRec32 ? (uint64_t)stage32[src + i] : L.stage[src + i];
-					if ((uint64_t)dst + i < G.cap1) {
-						if constexpr (kRec32) o32[i] = (uint32_t)rcd;
-						else o[i] = rcd;
-					} else push_overflow(P, record_key(rcd, b, G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
-				}
-			}
-		};
-		uint32_t cur = 0u; // the histogram of the current tile, in words from L.hist: 0 or kHist2
+		L1Pipe<kRec32> pp(L, UL.gbase, G, P, ctr);
+		const uint32_t tid = pp.tid;
 		if (blockIdx.x < n_tiles) {
 			open_tile(raw, 0u);
 			lds_barrier();
@@ -1349,10 +1419,9 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			uint32_t bkt[16];
 			uint64_t rec[16];
 			uint64_t slow = 0ull;
-			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG && FULL, K17, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, cur,
-			                                                                    [&](uint32_t i) { copy_run(i, slow); });
-			for (uint32_t kk = (uint32_t)C; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow); // (more than 16 C buckets)
-			if (slow) copy_slow(slow);
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, REG && FULL, K17, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, pp.cur,
+			                                                                    [&](uint32_t i) { pp.copy_run(i, slow); });
+			pp.copy_rest((uint32_t)C, slow); // (more than 16 C buckets; the full ones)
 			if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 			if constexpr (!REG) { // (regular tiles: fetch works from the tile index alone)
 				r0 += stride_r;
@@ -1361,38 +1430,10 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 			}
 			const RawU nxt = fetch(tile + gridDim.x, r0, c0);
 			lds_barrier(); // (C) every rank of this tile has been taken, every wave has copied its runs of the tile before
-			// one reservation per non-empty bucket, by thread b as everywhere else: consecutive lanes, consecutive counters -- a handful of
-			// atomic REQUESTS per tile.  (Reserved by the copying lanes themselves -- bucket w + 16 l, sixteen instructions of nine scattered
-			// lanes -- the same 144 atomics took 23 ms instead of 4.7: the counters' five cache lines saw sixteen times the requests.)
-			const uint32_t c_t = tid < G.n1 ? L.hist[cur + tid] : 0u;
-			const uint32_t g_t = c_t ? atomicAdd(&cnt[tid * G.n_sub], c_t) : 0u;
-			const uint32_t c_mine = lane < per_wave ? L.hist[cur + mine] : 0u;
-			scan_hist_per_wave(L, G.n1, cur);
-			d_lo = (c_mine << 16) | (lane < per_wave ? L.lbase[mine] : 0u);
-			if (REG && FULL && __builtin_amdgcn_ballot_w64(zero_seen) == 0ull) { // (wave-uniform) every record of every lane has a bucket
-				uint32_t at[C];
-#pragma unroll
-				for (int u = 0; u < C; u++) at[u] = L.lbase[bkt[u] >> 16];
-#pragma unroll
-				for (int u = 0; u < C; u++) L.stage[at[u] + (bkt[u] & 0xFFFFu)] = rec[u];
-			} else {
-#pragma unroll
-				for (int u = 0; u < C; u++)
-					if ((bkt[u] >> 16) < (uint32_t)kL1MaxB) {
-						if constexpr (kRec32) stage32[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = (uint32_t)rec[u];
-						else L.stage[L.lbase[bkt[u] >> 16] + (bkt[u] & 0xFFFFu)] = rec[u];
-					}
-			}
-			if (tid < G.n1) UL.gbase[tid] = g_t;
-			open_tile(nxt, cur ^ kHist2);
-			lds_barrier(); // (E) the tile is staged, the next one's packed words and cleared histogram are in place
-			d_gb = lane < per_wave ? UL.gbase[mine] : 0u;
-			cur ^= kHist2;
+			pp.template tail<C, (REG && FULL)>(rec, bkt, zero_seen, [&](uint32_t hist_next) { open_tile(nxt, hist_next); });
 			raw = nxt;
 		}
-		uint64_t slow = 0ull; // the runs of the workgroup's last tile
-		for (uint32_t kk = 0; kk < per_wave; kk++) copy_run(__builtin_amdgcn_readfirstlane(kk), slow);
-		if (slow) copy_slow(slow);
+		pp.copy_rest(0u, 0ull); // the runs of the workgroup's last tile
 		return;
 	}
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1588,13 +1629,17 @@ __global__ __launch_bounds__(256) void k_prefix_tiles(const ReadLanes *__restric
 }
 
 struct PrefixLds {
-	ScatterLds s;                  // (s.lbase doubles as the per-entry meta array while a tile is decoded: W << 10 | lane inside the tile)
+	ScatterLds s;
 	uint32_t pk[kPkWords];
 	uint32_t ent_start[kL1Threads]; // start of the tile's i-th entry, relative to the tile's base0
-	unsigned long long starts[kL1Threads / 64]; // bit l: an entry begins at lane l of the tile
+	uint32_t meta[kL1Threads];      // its windows << 10 | the lane of the tile it begins at
+	unsigned long long starts[2][kL1Threads / 64]; // bit l: an entry begins at lane l of the tile (two tiles in turn: the pipelined loop opens the next tile in the tail of this one)
 };
+static_assert(sizeof(PrefixLds) <= 160 * 1024, "one workgroup per CU");
+// the pipelined loop's hand-over array lives behind the second histogram in the descriptor array: room for this many buckets
+constexpr uint32_t kPrefixPipeMaxB = (uint32_t)(sizeof(ScatterLds::desc) / 4u) - (uint32_t)(kL1MaxB + 64);
 
-template <int WIDE_D = 0, int C = 16, bool K17 = false> // K17: k >= 17 (the 32-bit rolls of l1_positions)
+template <int WIDE_D = 0, int C = 16, bool K17 = false> // K17: k >= 17 and n1 <= kPrefixPipeMaxB -- the 32-bit rolls of l1_positions and the pipelined tile loop (L1Pipe)
 __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch rb, const ReadLanes *__restrict__ ent, const PrefixTile *__restrict__ tiles,
                                                                         const PrefixTotals *__restrict__ tot, PartGeom G, PartStore P, Counters *__restrict__ ctr)
 {
@@ -1639,34 +1684,30 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 		}
 		return raw;
 	};
-
-	if (fresh_tid() < (uint32_t)(kL1Threads / 64)) UL.starts[fresh_tid()] = 0ull;
-	PrefixTile M = tile_meta(blockIdx.x), M_next = tile_meta((uint64_t)blockIdx.x + gridDim.x);
-	RawP raw = fetch(blockIdx.x, M);
-	lds_barrier();
-	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	// a tile is opened: its packed words, its entries (bitmap `sb`, start and meta of entry tid), the histogram at hist_off cleared
+	auto open = [&](const RawP &rw, const PrefixTile &Mx, uint32_t sb, uint32_t hist_off) {
+		const uint32_t tid = fresh_tid();
+		if (tid < Mx.n_words) UL.pk[tid] = rw.a;
+		if (tid + kL1Threads < Mx.n_words) UL.pk[tid + kL1Threads] = rw.b;
+		if (rw.meta != 0xFFFFFFFFu) {
+			const uint32_t at = rw.meta & 1023u;
+			atomicOr(&UL.starts[sb][at >> 6], 1ull << (at & 63u));
+			UL.ent_start[tid] = rw.start_rel;
+			UL.meta[tid] = rw.meta;
+		}
+#pragma unroll
+		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[hist_off + ScatterLds::kBpt * tid + j] = 0;
+	};
+	// the lane's read -- the number of entries that begin at or before this lane -- and its window of C positions
+	auto decode = [&](uint64_t tile, const PrefixTile &Mx, uint32_t sb) {
 		const uint32_t tid = fresh_tid();
 		const uint64_t lane_first = tile * kL1Threads, lane_end = min(lane_first + (uint64_t)kL1Threads, n_lanes);
-		if (tid < M.n_words) UL.pk[tid] = raw.a;
-		if (tid + kL1Threads < M.n_words) UL.pk[tid + kL1Threads] = raw.b;
-		// this thread's entry of the tile: where it begins among the tile's lanes, its start and windows
-		if (raw.meta != 0xFFFFFFFFu) {
-			const uint32_t at = raw.meta & 1023u;
-			atomicOr(&UL.starts[at >> 6], 1ull << (at & 63u));
-			UL.ent_start[tid] = raw.start_rel;
-			L.lbase[tid] = raw.meta;
-		}
-		uint32_t bkt[16];
-#pragma unroll
-		for (int j = 0; j < ScatterLds::kBpt; j++) L.hist[ScatterLds::kBpt * tid + j] = 0;
-		lds_barrier();
-		// the lane's read: the number of entries that begin at or before this lane
 		const bool live = lane_first + tid < lane_end;
 		uint32_t idx;
 		{
 			const uint32_t lane = tid & 63u, wave = tid >> 6;
-			const unsigned long long mine = UL.starts[wave];
-			uint32_t before = (lane < (uint32_t)(kL1Threads / 64) && lane < wave) ? (uint32_t)__popcll(UL.starts[lane]) : 0u;
+			const unsigned long long mine = UL.starts[sb][wave];
+			uint32_t before = (lane < (uint32_t)(kL1Threads / 64) && lane < wave) ? (uint32_t)__popcll(UL.starts[sb][lane]) : 0u;
 #pragma unroll
 			for (int off = 8; off > 0; off >>= 1) before += __shfl_xor(before, off, 64); // lanes 0..15 hold the per-wave counts: sum over them
 			before = __builtin_amdgcn_readfirstlane(before);
@@ -1675,50 +1716,95 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_prefix(ReadBatch
 		uint64_t p = 0;        // flat position of the lane's first window
 		uint32_t cc = 0, W = 0;
 		if (live) {
-			const uint32_t meta = L.lbase[idx];
+			const uint32_t meta = UL.meta[idx];
 			W = meta >> 10;
-			cc = tid - (meta & 1023u) + (idx == 0u ? M.cc0 : 0u);
-			p = M.base0 + UL.ent_start[idx] + (uint64_t)C * cc;
+			cc = tid - (meta & 1023u) + (idx == 0u ? Mx.cc0 : 0u);
+			p = Mx.base0 + UL.ent_start[idx] + (uint64_t)C * cc;
 		}
 		const bool no_prev = p == 0u;
 		const uint64_t s0 = no_prev ? p : p - 1u;
 		const uint32_t first_w = (uint32_t)C * cc;
 		Chunk16 c;
-		{
-			uint32_t x0, x1, x2, x3, x4;
-			const uint32_t sh = 2u * ((uint32_t)s0 & 15u);
-			if (M.n_words) { // (tile-uniform) the range sits in LDS
-				const uint32_t rel = live ? (uint32_t)(s0 - M.B0) : 0u;
-				const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u);
-				x0 = UL.pk[d]; x1 = UL.pk[d + 1]; x2 = UL.pk[d + 2]; x3 = UL.pk[d + 3]; x4 = UL.pk[d + 4];
-			} else {         // a range too long for the image: every lane reads its five words from global memory
-				const uint64_t wi = live ? s0 >> 4 : 0ull, last = n_words_total ? n_words_total - 1u : 0u;
-				x0 = rb.packed[min(wi, last)]; x1 = rb.packed[min(wi + 1u, last)]; x2 = rb.packed[min(wi + 2u, last)];
-				x3 = rb.packed[min(wi + 3u, last)]; x4 = rb.packed[min(wi + 4u, last)];
-			}
-			const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
-			const uint32_t adv = no_prev ? 0u : 2u;
-			const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
-			c.lw = no_prev ? (X0 >> 2) : X0;
-			c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
-			c.rc = revcomp_kbit(c.kbit, (int)k);
-			const uint32_t widx = k >> 4, wsh = 2u * (k & 15u);
-			const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
-			c.nb = funnel_left(ya, yb, wsh);
-			const uint32_t nv = (live && first_w < W) ? min((uint32_t)C, W - first_w) : 0u;
-			const uint32_t nr = (live && first_w + 1u < W) ? min((uint32_t)C, W - 1u - first_w) : 0u;
-			c.valid = (1u << nv) - 1u;
-			c.has_r = (1u << nr) - 1u;            // the read's last window (after trimming) has no right neighbour
-			c.has_l = cc ? 0xFFFFu : 0xFFFEu;     // its first window no left one
+		uint32_t x0, x1, x2, x3, x4;
+		const uint32_t sh = 2u * ((uint32_t)s0 & 15u);
+		if (Mx.n_words) { // (tile-uniform) the range sits in LDS
+			const uint32_t rel = live ? (uint32_t)(s0 - Mx.B0) : 0u;
+			const uint32_t d = min(rel >> 4, (uint32_t)kPkWords - 5u);
+			x0 = UL.pk[d]; x1 = UL.pk[d + 1]; x2 = UL.pk[d + 2]; x3 = UL.pk[d + 3]; x4 = UL.pk[d + 4];
+		} else {         // a range too long for the image: every lane reads its five words from global memory
+			const uint64_t wi = live ? s0 >> 4 : 0ull, last = n_words_total ? n_words_total - 1u : 0u;
+			x0 = rb.packed[min(wi, last)]; x1 = rb.packed[min(wi + 1u, last)]; x2 = rb.packed[min(wi + 2u, last)];
+			x3 = rb.packed[min(wi + 3u, last)]; x4 = rb.packed[min(wi + 4u, last)];
 		}
+		const uint32_t X0 = funnel_left(x0, x1, sh), X1 = funnel_left(x1, x2, sh), X2 = funnel_left(x2, x3, sh), X3 = funnel_left(x3, x4, sh);
+		const uint32_t adv = no_prev ? 0u : 2u;
+		const uint32_t Y0 = funnel_left(X0, X1, adv), Y1 = funnel_left(X1, X2, adv), Y2 = funnel_left(X2, X3, adv), Y3 = X3 << adv;
+		c.lw = no_prev ? (X0 >> 2) : X0;
+		c.kbit = ((((uint64_t)Y0 << 32) | Y1)) >> (64u - 2u * k);
+		c.rc = revcomp_kbit(c.kbit, (int)k);
+		const uint32_t widx = k >> 4, wsh = 2u * (k & 15u);
+		const uint32_t ya = widx == 0u ? Y0 : (widx == 1u ? Y1 : Y2), yb = widx == 0u ? Y1 : (widx == 1u ? Y2 : Y3);
+		c.nb = funnel_left(ya, yb, wsh);
+		const uint32_t nv = (live && first_w < W) ? min((uint32_t)C, W - first_w) : 0u;
+		const uint32_t nr = (live && first_w + 1u < W) ? min((uint32_t)C, W - 1u - first_w) : 0u;
+		c.valid = (1u << nv) - 1u;
+		c.has_r = (1u << nr) - 1u;            // the read's last window (after trimming) has no right neighbour
+		c.has_l = cc ? 0xFFFFu : 0xFFFEu;     // its first window no left one
+		return c;
+	};
+
+	if (fresh_tid() < (uint32_t)(kL1Threads / 64)) UL.starts[0][fresh_tid()] = UL.starts[1][fresh_tid()] = 0ull;
+	PrefixTile M = tile_meta(blockIdx.x), M_next = tile_meta((uint64_t)blockIdx.x + gridDim.x);
+	RawP raw = fetch(blockIdx.x, M);
+	lds_barrier();
+	if constexpr (K17) { // the pipelined tile loop (L1Pipe)
+		L1Pipe<false> pp(L, reinterpret_cast<uint32_t *>(L.desc) + (kL1MaxB + 64), G, P, ctr);
+		const uint32_t tid = pp.tid;
+		uint32_t sb = 0u; // the bitmap of the current tile
+		if (blockIdx.x < n_tiles) {
+			open(raw, M, 0u, 0u);
+			lds_barrier();
+		}
+		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			const Chunk16 c = decode(tile, M, sb);
+			uint32_t bkt[16];
+			uint64_t rec[16];
+			uint64_t slow = 0ull;
+			const bool zero_seen = l1_positions<WIDE_D, C, ScatterLds, false, true, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, pp.cur,
+			                                                                           [&](uint32_t i) { pp.copy_run(i, slow); });
+			pp.copy_rest((uint32_t)C, slow);
+			if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
+			// next tile: its words and entries travel across the barrier and the tail; the meta data of the tile after it as well
+			const uint64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
+			const RawP nxt = fetch(t1, M_next);
+			const PrefixTile M_after = tile_meta(t2);
+			lds_barrier(); // (C) every rank taken, the runs of the tile before copied, and every lane has read its bitmap, entries and words
+			pp.template tail<C, false>(rec, bkt, zero_seen, [&](uint32_t hist_next) {
+				if (tid < (uint32_t)(kL1Threads / 64)) UL.starts[sb][tid] = 0ull; // (this tile's bitmap: set again two tiles on)
+				open(nxt, M_next, sb ^ 1u, hist_next);
+			});
+			sb ^= 1u;
+			raw = nxt;
+			M = M_next;
+			M_next = M_after;
+		}
+		pp.copy_rest(0u, 0ull); // the runs of the workgroup's last tile
+		return;
+	}
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t tid = fresh_tid();
+		open(raw, M, 0u, 0u);
+		uint32_t bkt[16];
+		lds_barrier();
+		const Chunk16 c = decode(tile, M, 0u);
 		const bool zero_seen = l1_positions<WIDE_D, C, ScatterLds, false, K17>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt);
 		if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
 		// next tile: its words and entries travel during this tile's scatter; the meta data of the tile after it as well
 		const uint64_t t1 = tile + gridDim.x, t2 = t1 + gridDim.x;
 		const RawP nxt = fetch(t1, M_next);
 		const PrefixTile M_after = tile_meta(t2);
-		lds_barrier(); // hist complete (as l1_scatter_tail begins) -- and every lane has read starts / ent_start / the meta words in lbase
-		if (tid < (uint32_t)(kL1Threads / 64)) UL.starts[tid] = 0ull; // (for the next tile: set again only after that tile's threads passed the barriers below)
+		lds_barrier(); // hist complete (as l1_scatter_tail begins) -- and every lane has read starts / ent_start / meta
+		if (tid < (uint32_t)(kL1Threads / 64)) UL.starts[0][tid] = 0ull; // (for the next tile: set again only after that tile's threads passed the barriers below)
 		{
 			uint64_t rec[16];
 #pragma unroll

@@ -88,8 +88,10 @@ def test_prefix_level1_kernel_equals_oracle(oracle, monkeypatch, shape, k, r):
     want = ref.nodes.astype(capi.NODE_DTYPE)
     words, other = capi.pack_bases(bases)
     size = capi.find_next_prime_ref(70000000)
-    for env, packed, batch in (("1", False, 0), ("1", True, 0), ("1", True, 1 << 15), ("0", False, 0)):
-        set_hooks(monkeypatch, l1_prefix=env)
+    # (plain = 1: the tile loop with its phases one after the other -- what k < 17 and tables of more than 960 level-1 buckets take --
+    # instead of the pipelined one)
+    for env, packed, batch, plain in (("1", False, 0, None), ("1", True, 0, None), ("1", True, 1 << 15, None), ("0", False, 0, None), ("1", True, 0, 1)):
+        set_hooks(monkeypatch, l1_prefix=env, l1_plain=plain)
         with capi.Graph(k=k, table_slots=size, max_read_len=r, engine=capi.ENGINE_PARTITION, expected_kmers=max(len(bases), 1), max_batch_bases=batch) as g:
             if packed:
                 g.push_reads_packed(words, offsets, other)
