@@ -58,10 +58,9 @@ static int uniform_mode(const dbgk_handle *h, int64_t uniform_len, uint64_t len_
 	const uint64_t QL = lin12 ? q12 : q8, CL = lin12 ? 12 : 8;
 	bool fits = QL < 2048 && n_reads * QL < (1ull << 32) && ((uint64_t)kL1Threads / QL + 2) * L + 96 <= (uint64_t)kPkWords * 16;
 	if (mode == 2) fits = fits && (double)(n_reads * QL * CL) <= 0.93 * (double)n_bases;
-	// (round 5, profiles/r05_l1_forms_by_buckets.txt: with the copy-out pipelined into the positions the wave-per-bucket form holds out
-	// longer -- n1 = 287: 4.72 against 5.98 ms, 573: 6.78 / 6.79, 1023: 12.25 / 7.36 -- so from k = 17 on the linear form starts at 512)
-	const uint32_t lin_from = (k >= 17 && !dbgk_hook("l1_plain")) ? 512u : 320u;
-	if (fits && (force == 1 || (force < 0 && h->geom.n1 > lin_from))) {
+	// (round 5, both forms pipelined, profiles/r05_l1_forms_by_buckets.txt, wave-per-bucket / linear with 12 windows: n1 = 144: 4.34 / 5.08,
+	// 287: 4.80 / 5.26, 573: 6.83 / 5.87, 1023: 12.27 / 6.11 -- the lines cross near 330)
+	if (fits && (force == 1 || (force < 0 && h->geom.n1 > 320u))) {
 		lin = true;
 		U.tile_blocks = 0;
 		U.Q = (uint32_t)QL;
@@ -191,7 +190,7 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		static const bool dbg = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") != nullptr;
 		const int force_lin = dbgk_hook("l1_linear") ? atoi(dbgk_hook("l1_linear")) : -1;
 		if (!h->part || h->seed || wrec || flat_only || dbg || prefix_env == 0) return false;
-		if (force_lin == 1 || (force_lin < 0 && h->geom.n1 > ((h->cfg.kmer_size >= 17 && !dbgk_hook("l1_plain")) ? 512u : 320u))) return false; // (as uniform_mode)
+		if (force_lin == 1 || (force_lin < 0 && h->geom.n1 > 320u)) return false;
 		if (len_max > (uint64_t)kPrefixMaxW || n_bases / 15 + n_reads >= (1ull << 32)) return false;
 		return um == 0 || um == 2; // (measured on cfg2t, level 1 per step: prefix 5.32 ms, ragged 5.72, flat 6.05 + 0.14 of bitmaps: profiles/r04_cfg2t_level1_forms_ab.json)
 	};
@@ -348,8 +347,14 @@ static int launch_batch(dbgk_handle *h, const char *d_bases, const uint64_t *d_o
 		else DBGK_LAUNCH_UNIFORM(WIDE, 16, false);                     \
 	} while (0)
 #define DBGK_LAUNCH_UNIFORM8(WIDE, CC, RAG)                                                                                                               \
-	hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, U, \
-	                   d_offsets, h->geom, h->store, h->d_ctr)
+	do {                                                                                                                                                  \
+		if (k17) /* the pipelined linear form */                                                                                                          \
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true, false, false, true, true>), dim3(grid), dim3(kL1Threads),                \
+			                   sizeof(UniformLdsLin<CC>), h->stream, rb, U, d_offsets, h->geom, h->store, h->d_ctr);                                      \
+		else                                                                                                                                              \
+			hipLaunchKernelGGL((k_extract_scatter_uniform<0, WIDE, CC, RAG, true>), dim3(grid), dim3(kL1Threads), sizeof(UniformLdsLin<CC>), h->stream, rb, \
+			                   U, d_offsets, h->geom, h->store, h->d_ctr);                                                                                \
+	} while (0)
 		static const int dbg_mode_u = DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE") ? atoi(DBGK_EXPERIMENT_ENV("DBGK_DEBUG_MODE")) : 0;
 		static const bool no_reg = DBGK_EXPERIMENT_ENV("DBGK_L1_NO_REG") != nullptr; // A/B: the general form everywhere
 		bool rest_only = false;

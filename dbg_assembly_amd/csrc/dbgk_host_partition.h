@@ -306,7 +306,11 @@ static int setup_partition(dbgk_handle *h)
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, false, true>), sizeof(UniformLdsLin<8>));   \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, true, true>), sizeof(UniformLdsLin<8>));    \
 	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, false, true>), sizeof(UniformLdsLin<12>)); \
-	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, true, true>), sizeof(UniformLdsLin<12>))
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, true, true>), sizeof(UniformLdsLin<12>)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, false, true, false, false, true, true>), sizeof(UniformLdsLin<8>));   \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 8, true, true, false, false, true, true>), sizeof(UniformLdsLin<8>));    \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, false, true, false, false, true, true>), sizeof(UniformLdsLin<12>)); \
+	DBGK_LDS_ATTR((k_extract_scatter_uniform<0, W, 12, true, true, false, false, true, true>), sizeof(UniformLdsLin<12>))
 	DBGK_LIN_ATTRS(0);
 	DBGK_LIN_ATTRS(1);
 	DBGK_LIN_ATTRS(2);

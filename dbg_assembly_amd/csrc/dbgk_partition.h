@@ -1436,6 +1436,98 @@ __global__ __launch_bounds__(kL1Threads) void k_extract_scatter_uniform(ReadBatc
 		pp.copy_rest(0u, 0ull); // the runs of the workgroup's last tile
 		return;
 	}
+	// The LINEAR form pipelined (k >= 17, a graph handle): as L1Pipe, with the linear copy-out -- element u of the tile before (staged
+	// record u * 1024 + tid, its bucket from the tag array, its place = desc[bucket] + index) goes out in front of position u; ONE
+	// histogram, cleared by the thread that owns the entry right after it has read it; the classic scan (four barriers per tile).
+	if constexpr (LIN && K17 && DBG == 0) {
+		const uint32_t tid = fresh_tid();
+		const uint32_t sub = blockIdx.x % G.n_sub;
+		uint64_t *const out = P.l1 + (uint64_t)sub * G.cap1; // bucket b lives at out + b * n_sub * cap1
+		uint32_t *const cnt = P.cnt1 + sub;
+		uint32_t total_prev = 0u; // records of the tile before, sorted in the stage buffer
+		static_assert(SLds::kBpt == 1, "thread b owns bucket b");
+		auto copy_elem = [&](uint32_t u, uint32_t &slow) {
+			const uint32_t p = u * kL1Threads + tid;
+			if (p >= total_prev) return;
+			const uint64_t rcd = L.stage[p];
+			const uint32_t b = L.bucket_of[p];
+			const uint64_t off = (uint64_t)(uint32_t)(L.desc[b] + p); // desc = reserved place - first staged index
+			if (off < G.cap1) out[(uint64_t)b * G.n_sub * G.cap1 + off] = rcd;
+			else slow |= 1u << u; // the bucket is full: behind the positions
+		};
+		auto copy_slow = [&](uint32_t slow) {
+			for (; slow; slow &= slow - 1u) {
+				const uint32_t p = (uint32_t)__builtin_ctz(slow) * kL1Threads + tid;
+				const uint64_t rcd = L.stage[p];
+				push_overflow(P, record_key(rcd, L.bucket_of[p], G), (uint32_t)(rcd >> 3) & 7u, (uint32_t)rcd & 7u, ctr);
+			}
+		};
+		if (blockIdx.x < n_tiles) {
+			open_tile(raw);
+			if (tid < 64u) L.hist[kL1MaxB + tid] = 0u;
+			lds_barrier();
+		}
+		for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+			const Chunk16 c = decode(raw);
+			uint32_t bkt[16];
+			uint64_t rec[16];
+			uint32_t slow = 0u;
+			const bool zero_seen = l1_positions<WIDE_D, C, SLds, false, true, true>(L, G, c, tid, head_mask, rc_shift, rel_mask, q_shift, bkt, rec, 0u,
+			                                                                     [&](uint32_t i) { copy_elem(i, slow); });
+			if (slow) copy_slow(slow);
+			if (zero_seen) l1_key0_from_chunk(c, head_mask, rc_shift, G.kf, ctr);
+			r0 += stride_r;
+			c0 += stride_c;
+			if (c0 >= U.Q) { c0 -= U.Q; r0 += 1u; }
+			const RawU nxt = fetch(tile + gridDim.x, r0, c0);
+			lds_barrier(); // (C) every rank taken; the stage buffer, the tags and the descriptors of the tile before read out; the packed words decoded
+			const uint32_t c_t = L.hist[tid];
+			L.hist[tid] = 0u; // (for the next tile; nobody else reads this entry)
+			if (tid < 64u) L.hist[kL1MaxB + tid] = 0u; // (the bins of the positions without a record)
+			const uint32_t g_t = (tid < G.n1 && c_t) ? atomicAdd(&cnt[tid * G.n_sub], c_t) : 0u;
+			uint32_t inc = c_t;
+			{
+				const uint32_t lane = tid & 63u;
+#pragma unroll
+				for (int off = 1; off < 64; off <<= 1) {
+					const uint32_t n = __shfl_up(inc, off, 64);
+					if ((int)lane >= off) inc += n;
+				}
+				if (lane == 63u) L.wave_tot[tid >> 6] = inc;
+			}
+			lds_barrier();
+			uint32_t run = inc - c_t, all = 0;
+#pragma unroll
+			for (uint32_t w = 0; w < (uint32_t)kL1Threads / 64u; w++) {
+				const uint32_t wt = L.wave_tot[w];
+				run += (w < (tid >> 6)) ? wt : 0u;
+				all += wt;
+			}
+			L.lbase[tid] = run;
+			lds_barrier(); // every bucket's first staged index is known; `all` = the tile's records with a bucket
+#pragma unroll
+			for (int u = 0; u < C; u++) {
+				const uint32_t b = bkt[u] >> 16;
+				if (b < (uint32_t)kL1MaxB) {
+					const uint32_t at = L.lbase[b] + (bkt[u] & 0xFFFFu);
+					L.stage[at] = rec[u];
+					L.bucket_of[at] = (uint16_t)b;
+				}
+			}
+			L.desc[tid] = g_t - run;
+			open_tile(nxt); // (its histogram clearing repeats what the owners did above)
+			lds_barrier(); // (E) the tile is staged, the next one's packed words are in place
+			total_prev = all;
+			raw = nxt;
+		}
+		{ // the workgroup's last tile
+			uint32_t slow = 0u;
+#pragma unroll 1
+			for (uint32_t u = 0; u < (uint32_t)C; u++) copy_elem(u, slow);
+			if (slow) copy_slow(slow);
+		}
+		return;
+	}
 	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const uint32_t tid = fresh_tid();
 		uint32_t bkt[16];
