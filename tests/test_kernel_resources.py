@@ -64,7 +64,9 @@ def test_hot_kernels_stay_inside_their_register_budget(tmp_path):
     # level 1, 1024 threads per workgroup: 128 VGPRs is all there is; the forms the bench workloads take must not spill
     check(r"k_extract_scatter_uniformILi0ELi[0-3]ELi15ELb0ELb0ELb1ELb[01]E", 128, 0, at_least=6)   # regular tiles (cfg2, cfg3)
     check(r"k_extract_scatter_uniformILi0ELi3ELi1[56]ELb0ELb0ELb0ELb0E", 128, 0, at_least=2)       # KFREQ, direct blocks (cfg4)
-    check(r"k_extract_scatter_prefixILi[0-2]ELi15ELb[01]E", 128, 0, at_least=6)                     # mixed lengths (cfg2t)
+    check(r"k_extract_scatter_prefixILi[0-2]ELi1[56]ELb[01]E", 128, 0, at_least=12)                 # mixed lengths (cfg2t): pipelined (Lb1) and plain
+    check(r"k_extract_scatter_uniformILi0ELi[0-2]ELi1[56]ELb[01]ELb0ELb0ELb0ELb1ELb1E", 128, 0, at_least=12)  # equal / mostly equal lengths, any lane count, pipelined
+    check(r"k_extract_scatter_uniformILi0ELi[0-2]ELi(8|12)ELb[01]ELb1ELb0ELb0ELb1ELb1E", 128, 0, at_least=12)  # the linear form, pipelined (every rank of a job on >= 4 GPUs)
     check(r"k_wide_scatter_l1_uniformILi[0-2]E", 128, 0, at_least=3)                               # k <= 63 (cfg5)
     # every level-1 form at all: never beyond the file, and no large spills
     check(r"k_extract_scatter(_uniform|_prefix|_lin)?I", 128, 64, at_least=40)
