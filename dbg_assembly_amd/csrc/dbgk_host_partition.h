@@ -162,7 +162,8 @@ static int plan_partition(dbgk_handle *h)
 	G.cap2 = (uint64_t)(per_slot * (double)n_ranks * (double)kRegionSlots * 1.15) + 512;
 	// every bucket starts on a 128-byte line (the 16-byte record loads of level 2 and of the build are aligned), and a bucket is an ODD
 	// number of lines long: the append points of neighbouring buckets then fall on neighbouring lines modulo any power of two, whatever
-	// the memory system's channel interleave (WIDE level 2 moved between 44 and 50 ms from process to process until its strides were odd)
+	// the memory system's channel interleave (on one box WIDE level 2 moved between 44 and 50 ms from process to process until its strides
+	// were odd; other boxes run it at 44 or at 49 whatever the strides, profiles/r05_cfg5_wide_l2_variants.txt)
 	G.cap1 = ((G.cap1 + 15u) & ~15ull) | 16u;
 	G.cap2 = ((G.cap2 + 15u) & ~15ull) | 16u;
 	G.r_rec = r;
